@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (/root/reference) here.
+
+Runs only in the build container (the reference does not exist on the GPU box);
+its outputs (tests/golden/*.json, *.npz) are committed data.  Nothing of the
+reference's source travels: only inputs, orders and the numbers it produced.
+
+Harness recipe: stub the absent `seaborn`/`tensorboardX`
+modules, make `.cuda()` the identity, alias torch.cuda.FloatTensor, and replace
+`utils.local_training.DataLoader` by a fixed-order, in-process loader (the
+reference draws shuffles from the global RNG and forks workers; fork isolation
+of the label mutation, SURVEY Q13, is emulated by a dataset that returns copies).
+The model is the oracle's torchvision-topology ResNet-18 (torchvision itself is
+absent), initialised by fedmlp_amd.spec.init_state.
+
+usage: python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+# ---- stubs / monkeypatches --------------------------------------------------
+for name in ("seaborn", "tensorboardX"):
+    m = types.ModuleType(name)
+    if name == "tensorboardX":
+        class SummaryWriter:  # noqa: D401
+            def __init__(self, *a, **k): pass
+            def add_scalar(self, *a, **k): pass
+        m.SummaryWriter = SummaryWriter
+    sys.modules[name] = m
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+torch.cuda.FloatTensor = torch.FloatTensor
+
+import utils.local_training as LT          # noqa: E402  (reference)
+import utils.FedAvg as FA                  # noqa: E402  (reference)
+import utils.FedNoRo as FN                 # noqa: E402  (reference)
+import utils.utils as UU                   # noqa: E402  (reference)
+
+from fedmlp_amd import spec                # noqa: E402
+from oracle.resnet18_ref import ResNet18Ref  # noqa: E402
+from tests.synth import synth_arrays, class_lists  # noqa: E402
+
+torch.set_num_threads(8)
+torch.use_deterministic_algorithms(True)
+
+ORDERS = []       # queue of explicit orders for shuffle=True loaders
+
+
+class FixedLoader(torch.utils.data.DataLoader):
+    """Drop-in for the reference's DataLoader: same batching/collation, but
+    in-process and, for shuffle=True, with the next order popped from ORDERS."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, num_workers=0, **kw):
+        if shuffle:
+            # LocalUpdate.__init__ builds a shuffled loader before any order is queued
+            order = ORDERS.pop(0) if ORDERS else list(range(len(dataset)))
+            assert len(order) == len(dataset)
+            super().__init__(dataset, batch_size=batch_size, sampler=list(order), num_workers=0)
+        else:
+            super().__init__(dataset, batch_size=batch_size, shuffle=False, num_workers=0)
+
+
+LT.DataLoader = FixedLoader
+
+
+class SynthDataset(torch.utils.data.Dataset):
+    """Output contract of dataset/all_dataset.py:64-83 on synthetic tensors."""
+
+    def __init__(self, n, C, hw, seed, two_view, p_pos=0.3):
+        self.two_view = two_view
+        self.targets, self.x1, self.x2 = synth_arrays(n, C, hw, seed, two_view, p_pos)
+
+    def __len__(self):
+        return len(self.targets)
+
+    def __getitem__(self, i):
+        t = self.targets[i].copy()      # copy == fork isolation of the mutation (Q13)
+        if self.two_view:
+            return {"image_aug_1": torch.from_numpy(self.x1[i]),
+                    "image_aug_2": torch.from_numpy(self.x2[i]),
+                    "target": t, "index": i}
+        return {"image": torch.from_numpy(self.x1[i]), "target": t, "index": i}
+
+
+def make_args(**kw):
+    a = types.SimpleNamespace(
+        batch_size=32, base_lr=3e-5, annotation_num=1, n_classes=5, n_clients=2, local_ep=1,
+        device="cpu", rounds_FedMLP_stage1=2, U=0.7, L=0.3, clean_threshold=0.005,
+        noise_threshold=0.01, feature_dim=512, model="Resnet18")
+    a.__dict__.update(kw)
+    return a
+
+
+def build_net(C, seed):
+    net = ResNet18Ref(C)
+    flat, cnt = spec.init_state("Resnet18", C, seed)
+    sd = spec.flat_to_state_dict("Resnet18", C, flat, cnt)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return net
+
+
+def tensor_norms(sd):
+    return {k: float(torch.linalg.vector_norm(v.double())) for k, v in sd.items()}
+
+
+def probe(net, x):
+    net = deepcopy(net).eval()
+    with torch.no_grad():
+        f, z = net(x)
+    return f, z
+
+
+# ---- G1: known-answer tests on reference-owned functions ---------------------
+def g_kat(out):
+    rs = np.random.RandomState(7)
+    kat = {}
+    # FedAvg with float tensors + an int64 counter (utils/FedAvg.py:7-14)
+    ws, lens = [], [3, 5, 2]
+    for i in range(3):
+        ws.append({"a.weight": torch.from_numpy(rs.standard_normal((4, 3)).astype(np.float32)),
+                   "a.running_var": torch.from_numpy(rs.uniform(0.5, 2, 4).astype(np.float32)),
+                   "a.num_batches_tracked": torch.tensor(10 + 7 * i, dtype=torch.int64)})
+    avg = FA.FedAvg(ws, lens)
+    kat["fedavg"] = {"w": [{k: v.tolist() for k, v in w.items()} for w in ws], "lens": lens,
+                     "out": {k: v.tolist() for k, v in avg.items()},
+                     "out_dtype": {k: str(v.dtype) for k, v in avg.items()}}
+    # FedAvg_tao / FedAvg_proto incl. empty-class cases (utils/FedAvg.py:51-93)
+    t = [rs.uniform(size=4), rs.uniform(size=4), rs.uniform(size=4)]
+    cl = [[0, 2], [1], [], [0, 1, 2]]
+    kat["fedavg_tao"] = {"t": [v.tolist() for v in t], "weight": lens, "clients": cl,
+                         "out": FA.FedAvg_tao(t, lens, cl).tolist()}
+    P = [torch.from_numpy(rs.standard_normal((8, 6)).astype(np.float32)) for _ in range(3)]
+    po = FA.FedAvg_proto(P, lens, cl)
+    kat["fedavg_proto"] = {"P": [p.tolist() for p in P], "weight": lens, "clients": cl,
+                           "out": [[None if np.isnan(x) else x for x in r] for r in po.tolist()]}
+    # CosineSimilarityFast (utils/local_training.py:1417-1435)
+    f = torch.from_numpy(rs.standard_normal((9, 16)).astype(np.float32))
+    p0 = torch.from_numpy(rs.standard_normal(16).astype(np.float32))
+    p1 = torch.from_numpy(rs.standard_normal(16).astype(np.float32))
+    cs = LT.CosineSimilarityFast()
+    kat["cosine"] = {"f": f.tolist(), "p0": p0.tolist(), "p1": p1.tolist(),
+                     "sim": (cs(f, p0.unsqueeze(0)) - cs(f, p1.unsqueeze(0))).tolist()}
+    f3 = torch.tensor([[1., 2, 3], [0, -1, .5], [2, 0, 0]])
+    kat["cosine_survey"] = {"sim": (cs(f3, torch.tensor([[1., 0, 0]]))
+                                    - cs(f3, torch.tensor([[0., 1, 1]]))).tolist()}
+    # stable top/bottom-k with ties (utils/utils.py:24-35)
+    lst = [0.1, 0.5, 0.5, -1.0, 0.5, -1.0, 3.0, 0.1]
+    kat["topk"] = {"lst": lst, "max": {str(n): UU.max_m_indices(lst, n) for n in range(0, 9)},
+                   "min": {str(n): UU.min_n_indices(lst, n) for n in range(0, 9)}}
+    # BCE on probabilities incl. saturation (utils/FedNoRo.py:9-22)
+    crit = FN.LogitAdjust_Multilabel(cls_num_list=[1., 2, 3, 4], num=10)
+    p = torch.tensor([[0.2, 0.9, 1.0, 0.0], [0.5, 1e-30, 0.7, 1.0]])
+    y = torch.tensor([[0., 1, 0, 1], [1., 1, 0, 0]])
+    kat["bce_probs"] = {"p": p.tolist(), "y": y.tolist(), "out": crit(p, y).tolist()}
+    # find_indices_in_a (utils/local_training.py:901-902)
+    a = torch.tensor([5., 9, 2, 7, 11]); b = torch.tensor([7, 5, 11])
+    kat["find_indices"] = {"a": a.tolist(), "b": b.tolist(),
+                           "out": LT.LocalUpdate.find_indices_in_a(None, a, b).tolist()}
+    # DatasetSplit / DatasetSplit_pseudo label semantics on a toy set
+    ds = SynthDataset(12, 4, 2, 3, True, p_pos=0.5)
+    pos, neg = class_lists(ds.targets, 4)
+    args = make_args(n_classes=4)
+    idxs = [1, 3, 4, 6, 7, 9, 10, 11]
+    sp = LT.DatasetSplit(ds, idxs, 1, args, neg, active_class_list=[1])
+    ym = np.stack([sp[i][0]["target"] for i in range(len(idxs))])
+    tr = [[3, 9], [6], [], [10, 1], [4], [7, 11]]
+    psd = LT.DatasetSplit_pseudo(ds, idxs, 1, args, [1], [0, 2, 3], tr)
+    yp = np.stack([psd[i][0]["target"] for i in range(len(idxs))])
+    dp = np.stack([psd[i][2].numpy() for i in range(len(idxs))])
+    kat["dataset_split"] = {"targets": ds.targets.tolist(), "idxs": idxs, "active": [1],
+                            "class_neg_idx": [v.tolist() for v in neg],
+                            "masked": ym.tolist(), "counts": sp.get_num_of_each_class(args),
+                            "negative": [0, 2, 3], "traindata_idx": tr,
+                            "pseudo_y": yp.tolist(), "pseudo_distill": dp.tolist()}
+    # loss-head KATs recorded by the survey from the reference code
+    kat["loss_survey"] = {
+        "z1": [[.5, -1, 2, 0], [-.25, .75, -3, 1.5], [1, .1, -.2, -2]],
+        "z2": [[.4, -.8, 1.5, .2], [-.5, 1, -2.5, 1], [.8, -.1, .3, -1.5]],
+        "g1": [[0, .2, -.1, .3], [.1, -.3, .5, -.6], [-.4, .6, 0, .2]],
+        "g2": [[.1, .1, -.2, .2], [0, -.2, .4, -.5], [-.3, .5, .1, .1]],
+        "y": [[0, 1, 0, 0], [0, 0, 0, 0], [0, 1, 0, 0]], "bs_norm": 4, "active": [1],
+        "negative": [0, 2, 3], "pos_weight": [3, 1.5, 4, 2],
+        "distill_cls": [[1, 0, 0, 1], [0, 0, 1, 1], [1, 0, 1, 0]],
+        "stage1_sup": 0.7904110551, "stage1_dis": 0.0740893111, "stage1_total": 0.8645003438,
+        "train": 0.7644862533, "stage2": 0.6540541053}
+    json.dump(kat, open(os.path.join(out, "kat.json"), "w"), indent=1)
+
+
+# ---- G2: trajectories through the reference trainer --------------------------
+def new_orders(rs, n, k):
+    return [rs.permutation(n).tolist() for _ in range(k)]
+
+
+def g_train_traj(out):
+    """config 1: 2 clients, ResNet-18, plain BCE warm-up (LocalUpdate.train
+    utils/local_training.py:628-703) + FedAvg, bs 32, 2 rounds, 32x32 inputs."""
+    C, n_cl, N, hw = 5, 2, 80, 32
+    args = make_args(n_classes=C, n_clients=n_cl)
+    ds = SynthDataset(n_cl * N, C, hw, 11, False)
+    pos, neg = class_lists(ds.targets, C)
+    users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
+    rs = np.random.RandomState(101)
+    netglob = build_net(C, 1037)
+    locals_ = [LT.LocalUpdate(args, i, deepcopy(ds), users[i], pos, neg, active_class_list=[i])
+               for i in range(n_cl)]
+    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": 11, "init_seed": 1037,
+           "bs": 32, "lr": args.base_lr, "users": users, "rounds": []}
+    xprobe = torch.from_numpy(ds.x1[:4])
+    for rnd in range(2):
+        w, r = [], {"orders": [], "loss": [], "norms": []}
+        for i in range(n_cl):
+            order = rs.permutation(N).tolist()
+            ORDERS.append(order)
+            locals_[i].ldr_train = FixedLoader(locals_[i].local_dataset, 32, True)
+            ret = locals_[i].train(rnd, deepcopy(netglob), None)
+            w.append(deepcopy(ret[0]))
+            r["orders"].append(order); r["loss"].append(float(ret[1]))
+            r["norms"].append(tensor_norms(ret[0]))
+            r.setdefault("neg", []).append(ret[4]); r.setdefault("act", []).append(ret[5])
+        avg = FA.FedAvg(w, [N] * n_cl)
+        netglob.load_state_dict(avg)
+        f, z = probe(netglob, xprobe)
+        r["glob_norms"] = tensor_norms(netglob.state_dict())
+        r["probe_logits"] = z.tolist()
+        r["probe_feat_norm"] = torch.linalg.vector_norm(f, dim=1).tolist()
+        rec["rounds"].append(r)
+    rec["loss_w"] = [l.loss_w for l in locals_]
+    json.dump(rec, open(os.path.join(out, "traj_train.json"), "w"), indent=1)
+
+
+def g_fedmlp_traj(out):
+    """full FedMLP two-stage flow (train_FedMLP, utils/local_training.py:904-1256
+    + main.py:178-237 aggregation): 2 clients x 512 samples, C=4, bs 32, 32x32,
+    S1 = 2 (rounds 0-1 stage 1, prototype pass at rnd 1; rounds 2-3 stage 2)."""
+    C, n_cl, N, hw = 4, 2, 512, 32
+    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=2)
+    ds = SynthDataset(n_cl * N, C, hw, 23, True)
+    pos, neg = class_lists(ds.targets, C)
+    users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
+    rs = np.random.RandomState(202)
+    netglob = build_net(C, 1037)
+    locals_ = [LT.LocalUpdate(args, i, deepcopy(ds), users[i], pos, neg, active_class_list=[i])
+               for i in range(n_cl)]
+    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": 23, "init_seed": 1037,
+           "bs": 32, "S1": 2, "users": users, "rounds": []}
+    xprobe = torch.from_numpy(ds.x1[:4])
+    tao, Prototype = [0] * C, []
+    neg_lists, act_lists = [None] * n_cl, [None] * n_cl
+    protos_npz = {}
+    for rnd in range(4):
+        r = {"loss": [], "norms": [], "train_orders": [], "feat_orders": []}
+        w, taos, protos = [], [], []
+        for i in range(n_cl):
+            if rnd < args.rounds_FedMLP_stage1:
+                order = rs.permutation(N).tolist()
+                ORDERS.append(order)
+                locals_[i].ldr_train = FixedLoader(locals_[i].local_dataset, 32, True)
+                r["train_orders"].append(order)
+                if rnd < args.rounds_FedMLP_stage1 - 1:
+                    ret = locals_[i].train_FedMLP(rnd, tao, Prototype, None, None, None,
+                                                  net=deepcopy(netglob))
+                else:
+                    ret = locals_[i].train_FedMLP(rnd, tao, Prototype, None, neg_lists[i],
+                                                  act_lists[i], net=deepcopy(netglob))
+            else:
+                fo, to = rs.permutation(N).tolist(), rs.permutation(N).tolist()
+                ORDERS.append(fo)
+                locals_[i].ldr_train = FixedLoader(locals_[i].local_dataset, 32, True)
+                ORDERS.append(to)        # consumed by the DatasetSplit_pseudo loader (:1167)
+                r["feat_orders"].append(fo); r["train_orders"].append(to)
+                ret = locals_[i].train_FedMLP(rnd, tao, Prototype, None, neg_lists[i],
+                                              act_lists[i], net=deepcopy(netglob))
+                r.setdefault("traindata_idx", []).append(
+                    [[int(v) for v in lst] for lst in locals_[i].traindata_idx])
+                r.setdefault("class_num_list", []).append(list(locals_[i].class_num_list))
+            if rnd == 0:
+                neg_lists[i], act_lists[i] = ret[4], ret[5]
+            w.append(deepcopy(ret[0]))
+            r["loss"].append(float(ret[1])); r["norms"].append(tensor_norms(ret[0]))
+            if len(ret) == 8:
+                taos.append(deepcopy(ret[6])); protos.append(deepcopy(ret[7]))
+                protos_npz[f"r{rnd}_c{i}_proto"] = ret[7].numpy().copy()
+                protos_npz[f"r{rnd}_c{i}_t"] = np.asarray(ret[6], dtype=np.float64)
+        if rnd == 0:   # main.py:200-210
+            cls_act = [[i for i in range(n_cl) if c in act_lists[i]] for c in range(C)]
+            cls_neg = [[i for i in range(n_cl) if c in neg_lists[i]] for c in range(C)]
+            rec["neg_lists"], rec["act_lists"] = neg_lists, act_lists
+            rec["class_active_client_list"], rec["class_negative_client_list"] = cls_act, cls_neg
+        netglob.load_state_dict(FA.FedAvg(w, [N] * n_cl))
+        if rnd >= args.rounds_FedMLP_stage1 - 1:          # main.py:223-234
+            tao = FA.FedAvg_tao(taos, [N] * n_cl, cls_neg)
+            Prototype = FA.FedAvg_proto(protos, [N] * n_cl, cls_act)
+            r["tao"] = tao.tolist()
+            protos_npz[f"r{rnd}_glob_proto"] = Prototype.numpy().copy()
+        f, z = probe(netglob, xprobe)
+        r["glob_norms"] = tensor_norms(netglob.state_dict())
+        r["probe_logits"] = z.tolist()
+        rec["rounds"].append(r)
+    json.dump(rec, open(os.path.join(out, "traj_fedmlp.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(out, "traj_fedmlp_protos.npz"), **protos_npz)
+
+
+def g_fixmatch_traj(out):
+    """FedAVG+FixMatch baseline step (train_FixMatch, utils/local_training.py:771-825):
+    1 client, 96 samples, C=4, bs 32, one round."""
+    C, N, hw = 4, 96, 32
+    args = make_args(n_classes=C, n_clients=1)
+    ds = SynthDataset(N, C, hw, 31, True)
+    pos, neg = class_lists(ds.targets, C)
+    rs = np.random.RandomState(303)
+    net = build_net(C, 1037)
+    # confident rows need saturated probabilities: scale fc so some |z| are large
+    with torch.no_grad():
+        net.fc.weight.mul_(40.0)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[0])
+    order = rs.permutation(N).tolist()
+    ORDERS.append(order)
+    loc.ldr_train = FixedLoader(loc.local_dataset, 32, True)
+    ret = loc.train_FixMatch(0, deepcopy(net))
+    rec = {"C": C, "N": N, "hw": hw, "data_seed": 31, "init_seed": 1037, "fc_scale": 40.0,
+           "bs": 32, "order": order, "loss": float(ret[1]), "norms": tensor_norms(ret[0]),
+           "loss_w": loc.loss_w, "loss_w_unknown": loc.loss_w_unknown}
+    json.dump(rec, open(os.path.join(out, "traj_fixmatch.json"), "w"), indent=1)
+
+
+def g_step224(out):
+    """One LocalUpdate.train step and one stage-1 step at the real 3x224x224 size
+    (bs 8) so the GPU engine is also pinned at full spatial size."""
+    C, N, hw = 5, 8, 224
+    args = make_args(n_classes=C, n_clients=1, batch_size=8)
+    ds = SynthDataset(N, C, hw, 41, True)
+    ds1 = SynthDataset(N, C, hw, 41, False)
+    pos, neg = class_lists(ds.targets, C)
+    net = build_net(C, 1037)
+    rec = {"C": C, "N": N, "hw": hw, "data_seed": 41, "init_seed": 1037, "bs": 8}
+    f, z = probe(net, torch.from_numpy(ds.x1[:4]))
+    rec["init_probe_logits"] = z.tolist()
+    rec["init_probe_feat_norm"] = torch.linalg.vector_norm(f, dim=1).tolist()
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds1), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 8, True)
+    ret = loc.train(0, deepcopy(net), None)
+    rec["train"] = {"loss": float(ret[1]), "norms": tensor_norms(ret[0])}
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 8, True)
+    ret = loc.train_FedMLP(0, [0] * C, [], None, None, None, net=deepcopy(net))
+    rec["stage1"] = {"loss": float(ret[1]), "norms": tensor_norms(ret[0])}
+    json.dump(rec, open(os.path.join(out, "step224.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224"]
+    fns = {"kat": g_kat, "train": g_train_traj, "fedmlp": g_fedmlp_traj,
+           "fixmatch": g_fixmatch_traj, "step224": g_step224}
+    for w in which:
+        print("==> golden:", w, flush=True)
+        fns[w](HERE)
+    assert not ORDERS, "unconsumed loader orders"

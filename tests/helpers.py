@@ -1,0 +1,60 @@
+"""Shared helpers for the oracle / engine parity tests."""
+import json
+import os
+import types
+
+import numpy as np
+import torch
+
+from fedmlp_amd import spec
+from tests.synth import synth_arrays, class_lists
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def make_args(**kw):
+    """Reference defaults (utils/options.py:20-64) for the flags the path reads."""
+    a = types.SimpleNamespace(
+        batch_size=32, base_lr=3e-5, annotation_num=1, n_classes=5, n_clients=2, local_ep=1,
+        device="cpu", rounds_FedMLP_stage1=2, U=0.7, L=0.3, clean_threshold=0.005,
+        noise_threshold=0.01, feature_dim=512, model="Resnet18", pretrained=0)
+    a.__dict__.update(kw)
+    return a
+
+
+def oracle_net(C, seed):
+    from oracle.resnet18_ref import ResNet18Ref
+    net = ResNet18Ref(C)
+    flat, cnt = spec.init_state("Resnet18", C, seed)
+    sd = spec.flat_to_state_dict("Resnet18", C, flat, cnt)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return net
+
+
+def data_dict(n, C, hw, seed, two_view):
+    t, x1, x2 = synth_arrays(n, C, hw, seed, two_view)
+    d = {"targets": t}
+    if two_view:
+        d["image_aug_1"], d["image_aug_2"] = torch.from_numpy(x1), torch.from_numpy(x2)
+    else:
+        d["image"] = torch.from_numpy(x1)
+    return d
+
+
+def norms_of(sd):
+    out = {}
+    for k, v in sd.items():
+        v = torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
+        out[k] = float(torch.linalg.vector_norm(v.double()))
+    return out
+
+
+def assert_norms_close(got, want, rtol, atol=1e-7, what=""):
+    for k, w in want.items():
+        g = got[k]
+        assert abs(g - w) <= atol + rtol * abs(w), f"{what} {k}: got {g} want {w}"
