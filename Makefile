@@ -1,0 +1,21 @@
+# Builds the C-ABI HIP library (gfx950 only) and the oracle-side helpers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+SRC   := $(wildcard fedmlp_amd/csrc/*.hip)
+HDR   := $(wildcard fedmlp_amd/csrc/*.h) include/fedmlp_hip.h
+OBJ   := $(patsubst fedmlp_amd/csrc/%.hip,build/%.o,$(SRC))
+LIB   := fedmlp_amd/libfedmlp_hip.so
+
+all: $(LIB)
+
+build/%.o: fedmlp_amd/csrc/%.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -c $< -o $@
+
+$(LIB): $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+clean:
+	rm -rf build $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,53 @@
+// Shared declarations for the FedMLP HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution (forward and data-gradient), fp32 MFMA.
+//   D[m][n] = sum_k Wp[m][k] * Xg[n][k]
+//   m: output channel, n: output pixel (per BN-statistics group), k: (tap, ci)
+// The K axis is cut in steps of 32 floats = 8 chunks of 16 B; `tab` gives, per
+// (step, chunk), where that chunk's 4 input channels come from relative to the
+// output pixel: {dh, dw, ci0, valid}.  The kernel itself knows nothing about
+// taps, strides or padding, so forward convs, the 7x7 stem (kw folded into K)
+// and the per-parity-class data gradients all run through it.
+// ---------------------------------------------------------------------------
+struct IgemmParams {
+    const float* W;       // packed weights [M][nsteps*32]
+    const float* X;       // input activations NHWC [imgs][Hi][Wi][Ci]
+    float* Y;             // output NHWC [imgs][Ho][Wo][Co]
+    const int4* tab;      // [nsteps][8]
+    const float* res;     // optional residual, indexed like Y (may alias Y)
+    const float* scale;   // optional per-m affine (eval-mode BN folded), else null
+    const float* shift;
+    float* stats;         // optional BN partials [group][tilesN][2][M]
+    int M, nsteps;
+    int Hi, Wi, Ci;
+    int Hg, Wg, sg;       // virtual output grid per image and its stride into the input
+    int Ho, Wo, Co;       // output tensor dims
+    int os, oh0, ow0;     // output placement: oh = hg*os + oh0
+    int imgs_per_group;   // images per BN-statistics group (grid.y = group)
+    int tilesM, tilesN;   // tiles per group
+    int relu;
+};
+
+// Weight-gradient GEMM: dW[m][n] = sum_p dY[p][m] * Xg[p][n], split over p.
+struct WgradParams {
+    const float* dY;      // [imgs][Ho][Wo][M]
+    const float* X;       // [imgs][Hi][Wi][Ci]
+    float* slab;          // [splits][M][Nw]
+    const int4* tab;      // [Nw/4]: {dh, dw, ci0, valid} per 4-column chunk
+    int M, Nw;
+    int Ho, Wo, Hi, Wi, Ci, stride;
+    int npix;             // imgs*Ho*Wo
+    int pix_per_split;    // multiple of 32
+    int tilesM, tilesN;
+};
+
+void launch_igemm(const IgemmParams& p, int groups, hipStream_t s);
+void launch_wgrad(const WgradParams& p, int splits, hipStream_t s);
+int igemm_tile_n(int M);   // pixel-tile width the igemm uses for this M
+int igemm_tile_m(int M);

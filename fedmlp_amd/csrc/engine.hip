@@ -1,0 +1,975 @@
+// FedMLP engine: ResNet-18 training/eval graph over the HIP kernels + the C ABI
+// of include/fedmlp_hip.h.  Host code only (kernels live in igemm/wgrad/
+// elementwise/heads.hip).  One engine per process/GPU.
+//
+// Data layout in HBM (all fp32):
+//   state   : [conv weights OHWI (stem padded to [64][7][8][4])][fc.W][fc.b][pad]
+//             [gamma of all 20 BN][beta of all 20 BN] | [running_mean all][running_var all]
+//             `- trainable (Adam, grads mirror this part) -'   `- FedAvg'd, not trained -'
+//   activations NHWC; train-mode forward keeps per conv the raw output y, per block
+//   the post-BN/ReLU z1 and the block output; the two views of a FedMLP step are
+//   one batch of 2B images with per-view ("group") BN statistics.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fedmlp_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+const char* fm_last_error(void) { return g_err.c_str(); }
+const char* fm_version(void) { return "fedmlp_hip 0.1 (gfx950)"; }
+
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            char b_[512];                                                                      \
+            snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            g_err = b_;                                                                        \
+            return FM_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+#define ARGCHK(c, msg)                                                       \
+    do {                                                                     \
+        if (!(c)) { g_err = std::string("bad argument: ") + msg; return FM_ERR_ARG; } \
+    } while (0)
+
+namespace {
+
+struct DgradClass {
+    TapList taps;
+    int dh[9], dw[9];
+    int ph, pw;
+    int nsteps;
+    int4* tab = nullptr;
+    float* wpack = nullptr;
+};
+
+struct Conv {
+    int cin, cout, k, stride, pad;
+    int cin_p, kw_p;          // padded input channels / kernel width of the engine layout
+    int hin, win, hout, wout;
+    size_t w_off;             // offset into the state arena
+    size_t w_numel;           // cout*k*kw_p*cin_p
+    int Kw;                   // k*kw_p*cin_p  (GEMM K of fwd, N of wgrad)
+    int nsteps;               // Kw/32
+    int4* tab = nullptr;      // [Kw/4]
+    int ncls = 0;
+    DgradClass cls[4];
+    int bn;                   // index of the BatchNorm that follows
+    double macs_per_img;      // algorithmic MACs (real k, real cin)
+    float* y = nullptr;       // raw conv output (train) [max_images][hout][wout][cout]
+};
+
+struct Bn {
+    int C;
+    int ch_off;               // channel offset inside the all-BN vectors
+    float *mean, *istd, *scale, *shift;   // [2][C] train-mode per-group
+};
+
+struct Block {
+    int c1, c2, ds;
+    float* z1 = nullptr;
+    float* out = nullptr;
+};
+
+struct StateEntry {           // one state_dict entry, in reference key order
+    int kind;                 // 0 conv weight, 1 float vector, 2 int64 counter
+    int conv;                 // conv index (kind 0)
+    size_t eng_off;           // engine arena offset (kind 1)
+    size_t n;                 // elements in state_dict form
+    int bn;                   // counter's BN index (kind 2)
+};
+
+struct EvPair { hipEvent_t a, b; int family; double flops; };
+
+}  // namespace
+
+struct fm_engine {
+    fm_config cfg;
+    hipStream_t st = nullptr;
+    int C = 0, D = 512, H = 0, W = 0, maxB = 0;
+    std::vector<Conv> convs;
+    std::vector<Bn> bns;
+    std::vector<Block> blocks;
+    std::vector<StateEntry> entries;
+    int n_bn_ch = 0;
+    size_t NP = 0, NS = 0;            // trainable floats (padded to 4), whole state floats
+    size_t off_fcw = 0, off_fcb = 0, off_gamma = 0, off_beta = 0, off_rm = 0, off_rv = 0;
+    int64_t nf_sd = 0, ni_sd = 0;     // state_dict sizes
+    float *state = nullptr, *tstate = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float *ev_scale = nullptr, *ev_shift = nullptr, *tev_scale = nullptr, *tev_shift = nullptr;
+    float* stage_sd = nullptr;        // device staging buffer in state_dict order
+    std::vector<int64_t> counters;    // num_batches_tracked per BN
+    fm_adam hp{3e-5f, 0.9f, 0.999f, 1e-8f, 5e-4f};
+    int64_t adam_t = 0;
+    bool ev_dirty = true, tev_dirty = true;
+    // workspaces
+    float *x4 = nullptr, *p0 = nullptr, *dyh0 = nullptr;
+    uint8_t* idx0 = nullptr;
+    float *GA = nullptr, *GB = nullptr, *GC = nullptr, *GD = nullptr, *GE = nullptr;
+    float *ws_stats = nullptr, *ws_part = nullptr, *ws_slab = nullptr;
+    size_t slab_floats = 0;
+    float *ca = nullptr, *cb = nullptr, *cc = nullptr;
+    float *feat = nullptr, *logits = nullptr, *tfeat = nullptr, *tlogits = nullptr, *dlogits = nullptr;
+    // prototypes
+    float* psum = nullptr;
+    int64_t *pcnt = nullptr, *tcnt = nullptr;
+    int *sel_counts = nullptr, *sel_top = nullptr, *sel_bot = nullptr, *cls_dev = nullptr;
+    int sel_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<EvPair> evs;
+    std::vector<hipEvent_t> ev_free;
+    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
+    int64_t prof_n[2] = {0, 0};
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(fm_engine* e, T** p, size_t n)
+{
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    e->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return FM_OK;
+}
+#define DALLOC(p, n)                                   \
+    do {                                               \
+        int rc_ = dalloc(e, &(p), (n));                \
+        if (rc_ != FM_OK) return rc_;                  \
+    } while (0)
+
+int upload_tab(fm_engine* e, const std::vector<int4>& h, int4** d)
+{
+    DALLOC(*d, h.size());
+    HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(int4), hipMemcpyHostToDevice));
+    return FM_OK;
+}
+
+// ---- model construction -------------------------------------------------------
+int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hin, int win, size_t& off)
+{
+    Conv c{};
+    c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = pad;
+    c.cin_p = (cin == 3) ? 4 : cin;
+    c.kw_p = (cin == 3) ? 8 : k;
+    c.hin = hin; c.win = win;
+    c.hout = (hin + 2 * pad - k) / stride + 1;
+    c.wout = (win + 2 * pad - k) / stride + 1;
+    c.Kw = k * c.kw_p * c.cin_p;
+    c.nsteps = c.Kw / 32;
+    c.w_numel = (size_t)cout * c.Kw;
+    c.w_off = off;
+    off += c.w_numel;
+    c.macs_per_img = (double)c.hout * c.wout * cout * cin * k * k;
+    c.bn = (int)e->convs.size();
+    e->convs.push_back(c);
+    return (int)e->convs.size() - 1;
+}
+
+int build_tables(fm_engine* e)
+{
+    for (auto& c : e->convs) {
+        if (c.Kw % 32 != 0) { g_err = "conv K not a multiple of 32"; return FM_ERR_ARG; }
+        // forward / wgrad table: chunk q -> (kh, kw, ci0)
+        std::vector<int4> t(c.Kw / 4);
+        for (int q = 0; q < c.Kw / 4; ++q) {
+            const int n = 4 * q;
+            const int tap = n / c.cin_p, ci0 = n % c.cin_p;
+            const int kh = tap / c.kw_p, kw = tap % c.kw_p;
+            t[q] = make_int4(kh - c.pad, kw - c.pad, ci0, kw < c.k ? 1 : 0);
+        }
+        int rc = upload_tab(e, t, &c.tab);
+        if (rc) return rc;
+        if (c.cin == 3) continue;          // the stem needs no input gradient
+        // data-gradient parity classes
+        const int s = c.stride;
+        for (int ph = 0; ph < s; ++ph)
+            for (int pw = 0; pw < s; ++pw) {
+                DgradClass d{};
+                d.ph = ph; d.pw = pw; d.taps.n = 0;
+                for (int kh = 0; kh < c.k; ++kh)
+                    for (int kw = 0; kw < c.k; ++kw) {
+                        if ((ph + c.pad - kh) % s != 0 || (pw + c.pad - kw) % s != 0) continue;
+                        const int j = d.taps.n++;
+                        d.taps.t[j] = kh * c.k + kw;
+                        d.dh[j] = (ph + c.pad - kh) / s;     // exact (divisible), may be negative
+                        d.dw[j] = (pw + c.pad - kw) / s;
+                    }
+                if (d.taps.n == 0) continue;
+                const int K = d.taps.n * c.cout;
+                d.nsteps = K / 32;
+                std::vector<int4> dt(K / 4);
+                for (int q = 0; q < K / 4; ++q) {
+                    const int kk = 4 * q, j = kk / c.cout, co0 = kk % c.cout;
+                    dt[q] = make_int4(d.dh[j], d.dw[j], co0, 1);
+                }
+                rc = upload_tab(e, dt, &d.tab);
+                if (rc) return rc;
+                DALLOC(d.wpack, (size_t)c.cin * K);
+                c.cls[c.ncls++] = d;
+            }
+    }
+    return FM_OK;
+}
+
+int build_resnet18(fm_engine* e)
+{
+    size_t off = 0;
+    int h = e->H, w = e->W;
+    add_conv(e, 3, 64, 7, 2, 3, h, w, off);
+    h /= 2; w /= 2;          // conv1
+    h /= 2; w /= 2;          // maxpool
+    int cin = 64;
+    const int widths[4] = {64, 128, 256, 512};
+    for (int li = 0; li < 4; ++li)
+        for (int b = 0; b < 2; ++b) {
+            const int wd = widths[li];
+            const int stride = (li > 0 && b == 0) ? 2 : 1;
+            Block blk{};
+            blk.c1 = add_conv(e, cin, wd, 3, stride, 1, h, w, off);
+            const int ho = e->convs[blk.c1].hout, wo = e->convs[blk.c1].wout;
+            blk.c2 = add_conv(e, wd, wd, 3, 1, 1, ho, wo, off);
+            blk.ds = (stride != 1 || cin != wd) ? add_conv(e, cin, wd, 1, stride, 0, h, w, off) : -1;
+            e->blocks.push_back(blk);
+            cin = wd; h = ho; w = wo;
+        }
+    e->off_fcw = off; off += (size_t)e->C * 512;
+    e->off_fcb = off; off += e->C;
+    off = (off + 3) & ~(size_t)3;
+    int ch = 0;
+    for (auto& c : e->convs) {
+        Bn b{};
+        b.C = c.cout; b.ch_off = ch; ch += c.cout;
+        e->bns.push_back(b);
+    }
+    e->n_bn_ch = ch;
+    e->off_gamma = off; off += ch;
+    e->off_beta = off; off += ch;
+    e->NP = off;             // ch is a multiple of 64 -> NP multiple of 4
+    e->off_rm = off; off += ch;
+    e->off_rv = off; off += ch;
+    e->NS = off;
+    // state_dict entry table (torchvision key order)
+    auto push_conv = [&](int ci) {
+        const Conv& c = e->convs[ci];
+        e->entries.push_back({0, ci, 0, (size_t)c.cout * c.cin * c.k * c.k, -1});
+    };
+    auto push_bn = [&](int bi) {
+        const Bn& b = e->bns[bi];
+        e->entries.push_back({1, -1, e->off_gamma + b.ch_off, (size_t)b.C, -1});
+        e->entries.push_back({1, -1, e->off_beta + b.ch_off, (size_t)b.C, -1});
+        e->entries.push_back({1, -1, e->off_rm + b.ch_off, (size_t)b.C, -1});
+        e->entries.push_back({1, -1, e->off_rv + b.ch_off, (size_t)b.C, -1});
+        e->entries.push_back({2, -1, 0, 1, bi});
+    };
+    push_conv(0); push_bn(0);
+    for (auto& blk : e->blocks) {
+        push_conv(blk.c1); push_bn(blk.c1);
+        push_conv(blk.c2); push_bn(blk.c2);
+        if (blk.ds >= 0) { push_conv(blk.ds); push_bn(blk.ds); }
+    }
+    e->entries.push_back({1, -1, e->off_fcw, (size_t)e->C * 512, -1});
+    e->entries.push_back({1, -1, e->off_fcb, (size_t)e->C, -1});
+    e->nf_sd = 0; e->ni_sd = 0;
+    for (auto& en : e->entries) (en.kind == 2 ? e->ni_sd : e->nf_sd) += (int64_t)en.n;
+    e->counters.assign(e->bns.size(), 0);
+    return FM_OK;
+}
+
+int alloc_workspaces(fm_engine* e)
+{
+    const size_t B = e->maxB;
+    DALLOC(e->state, e->NS); DALLOC(e->tstate, e->NS);
+    DALLOC(e->grad, e->NP); DALLOC(e->adam_m, e->NP); DALLOC(e->adam_v, e->NP);
+    HIPCHK(hipMemset(e->state, 0, e->NS * 4)); HIPCHK(hipMemset(e->tstate, 0, e->NS * 4));
+    HIPCHK(hipMemset(e->grad, 0, e->NP * 4));
+    HIPCHK(hipMemset(e->adam_m, 0, e->NP * 4)); HIPCHK(hipMemset(e->adam_v, 0, e->NP * 4));
+    DALLOC(e->ev_scale, e->n_bn_ch); DALLOC(e->ev_shift, e->n_bn_ch);
+    DALLOC(e->tev_scale, e->n_bn_ch); DALLOC(e->tev_shift, e->n_bn_ch);
+    DALLOC(e->stage_sd, (size_t)e->nf_sd);
+    DALLOC(e->x4, B * e->H * e->W * 4);
+    size_t max_stats = 0, max_slab = 0;
+    for (auto& c : e->convs) {
+        DALLOC(c.y, B * c.hout * c.wout * c.cout);
+        const size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout) - 1) / igemm_tile_n(c.cout) + 2;
+        max_stats = std::max(max_stats, tiles * 2 * c.cout);
+        max_slab = std::max(max_slab, c.w_numel);
+    }
+    for (auto& b : e->bns) {
+        DALLOC(b.mean, 2 * b.C); DALLOC(b.istd, 2 * b.C); DALLOC(b.scale, 2 * b.C); DALLOC(b.shift, 2 * b.C);
+    }
+    const Conv& c0 = e->convs[0];
+    const size_t pooled = B * (c0.hout / 2) * (c0.wout / 2) * 64;
+    DALLOC(e->p0, pooled); DALLOC(e->idx0, pooled);
+    DALLOC(e->dyh0, B * c0.hout * c0.wout * 64);
+    for (auto& blk : e->blocks) {
+        const Conv& c = e->convs[blk.c1];
+        const size_t n = B * c.hout * c.wout * c.cout;
+        DALLOC(blk.z1, n); DALLOC(blk.out, n);
+    }
+    DALLOC(e->GA, pooled); DALLOC(e->GB, pooled); DALLOC(e->GC, pooled); DALLOC(e->GD, pooled); DALLOC(e->GE, pooled);
+    DALLOC(e->ws_stats, max_stats);
+    DALLOC(e->ws_part, (size_t)2 * 512 * 2 * 512);
+    e->slab_floats = std::max<size_t>(max_slab * 8, (size_t)48 << 20);   // >= 192 MB of partial slabs
+    DALLOC(e->ws_slab, e->slab_floats);
+    DALLOC(e->ca, 2 * 512); DALLOC(e->cb, 2 * 512); DALLOC(e->cc, 2 * 512);
+    DALLOC(e->feat, B * 512); DALLOC(e->tfeat, B * 512);
+    DALLOC(e->logits, B * e->C); DALLOC(e->tlogits, B * e->C); DALLOC(e->dlogits, B * e->C);
+    DALLOC(e->psum, (size_t)2 * e->C * 512); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
+    DALLOC(e->sel_counts, 2); DALLOC(e->cls_dev, FM_MAX_CLASSES);
+    return FM_OK;
+}
+
+// ---- profiling helpers -----------------------------------------------------------
+hipEvent_t get_ev(fm_engine* e)
+{
+    if (!e->ev_free.empty()) { hipEvent_t v = e->ev_free.back(); e->ev_free.pop_back(); return v; }
+    hipEvent_t v; (void)hipEventCreate(&v); return v;
+}
+struct ProfScope {
+    fm_engine* e; hipEvent_t a{}, b{}; int fam; double fl; bool on;
+    ProfScope(fm_engine* e_, int family, double flops) : e(e_), fam(family), fl(flops), on(e_->prof)
+    {
+        if (on) { a = get_ev(e); b = get_ev(e); (void)hipEventRecord(a, e->st); }
+    }
+    ~ProfScope()
+    {
+        if (on) { (void)hipEventRecord(b, e->st); e->evs.push_back({a, b, fam, fl}); }
+    }
+};
+
+// ---- layer launchers --------------------------------------------------------------
+void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, int imgs, int groups,
+              const float* scale, const float* shift, const float* res, int relu, float* stats)
+{
+    const Conv& c = e->convs[ci];
+    IgemmParams p{};
+    p.W = S + c.w_off; p.X = x; p.Y = y; p.tab = c.tab;
+    p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
+    p.M = c.cout; p.nsteps = c.nsteps;
+    p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
+    p.Hg = c.hout; p.Wg = c.wout; p.sg = c.stride;
+    p.Ho = c.hout; p.Wo = c.wout; p.Co = c.cout;
+    p.os = 1; p.oh0 = 0; p.ow0 = 0;
+    p.imgs_per_group = imgs / groups;
+    p.tilesM = c.cout / igemm_tile_m(c.cout);
+    const int bn = igemm_tile_n(c.cout);
+    p.tilesN = (p.imgs_per_group * c.hout * c.wout + bn - 1) / bn;
+    p.relu = relu;
+    ProfScope ps(e, 0, 2.0 * c.macs_per_img * imgs);
+    launch_igemm(p, groups, e->st);
+}
+
+int stats_tiles(fm_engine* e, int ci, int imgs_per_group)
+{
+    const Conv& c = e->convs[ci];
+    const int bn = igemm_tile_n(c.cout);
+    return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
+}
+
+// dx[imgs][hin][win][cin] = dgrad(dy[imgs][hout][wout][cout]); res: optional residual added
+// (for stride-2 convs `acc_cls0` adds the existing dx contents for parity class (0,0))
+void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx, int imgs, const float* res,
+                bool acc_cls0)
+{
+    Conv& c = e->convs[ci];
+    for (int k = 0; k < c.ncls; ++k) {
+        DgradClass& d = c.cls[k];
+        k_pack_dgrad(S + c.w_off, d.wpack, c.cout, c.k * c.k, c.cin, d.taps, e->st);
+        IgemmParams p{};
+        p.W = d.wpack; p.X = dy; p.Y = dx; p.tab = d.tab;
+        p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
+        p.M = c.cin; p.nsteps = d.nsteps;
+        p.Hi = c.hout; p.Wi = c.wout; p.Ci = c.cout;
+        p.Hg = (c.hin - d.ph + c.stride - 1) / c.stride;
+        p.Wg = (c.win - d.pw + c.stride - 1) / c.stride;
+        p.sg = 1;
+        p.Ho = c.hin; p.Wo = c.win; p.Co = c.cin;
+        p.os = c.stride; p.oh0 = d.ph; p.ow0 = d.pw;
+        p.imgs_per_group = imgs;
+        p.tilesM = c.cin / igemm_tile_m(c.cin);
+        const int bn = igemm_tile_n(c.cin);
+        p.tilesN = (imgs * p.Hg * p.Wg + bn - 1) / bn;
+        p.relu = 0;
+        ProfScope ps(e, 0, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
+        launch_igemm(p, 1, e->st);
+    }
+}
+
+void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
+{
+    const Conv& c = e->convs[ci];
+    WgradParams p{};
+    p.dY = dy; p.X = x; p.slab = e->ws_slab; p.tab = c.tab;
+    p.M = c.cout; p.Nw = c.Kw;
+    p.Ho = c.hout; p.Wo = c.wout; p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p; p.stride = c.stride;
+    p.npix = imgs * c.hout * c.wout;
+    const int bm = c.cout >= 128 ? 128 : 64, bn = c.cout >= 128 ? 128 : 256;
+    p.tilesM = c.cout / bm;
+    p.tilesN = (c.Kw + bn - 1) / bn;
+    const int tiles = p.tilesM * p.tilesN;
+    int splits = (1024 + tiles - 1) / tiles;
+    const int max_by_pix = std::max(1, p.npix / 256);
+    const int max_by_mem = (int)std::max<size_t>(1, e->slab_floats / c.w_numel);
+    splits = std::max(1, std::min(splits, std::min(max_by_pix, max_by_mem)));
+    p.pix_per_split = (((p.npix + splits - 1) / splits) + 31) & ~31;
+    splits = (p.npix + p.pix_per_split - 1) / p.pix_per_split;
+    {
+        ProfScope ps(e, 1, 2.0 * c.macs_per_img * imgs);
+        launch_wgrad(p, splits, e->st);
+    }
+    k_reduce_slabs(e->ws_slab, e->grad + c.w_off, splits, (int64_t)c.w_numel, e->st);
+}
+
+void bn_fwd_finalize(fm_engine* e, int bi, int groups, int imgs_per_group)
+{
+    const Conv& c = e->convs[bi];
+    Bn& b = e->bns[bi];
+    k_bn_finalize(e->ws_stats, groups, stats_tiles(e, bi, imgs_per_group), b.C, imgs_per_group * c.hout * c.wout,
+                  e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
+                  e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale,
+                  b.shift, 1e-5f, 0.1f, e->st);
+    e->counters[bi] += groups;
+}
+
+// backward through BN bi: dz (+ optional relu mask source z) -> dy ; optional masked grad out
+void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, float* dyh_out, int groups,
+            int imgs_per_group)
+{
+    const Conv& c = e->convs[bi];
+    Bn& b = e->bns[bi];
+    const int pix = imgs_per_group * c.hout * c.wout;
+    k_bn_bwd_reduce(dz, z, c.y, b.mean, b.istd, e->ws_part, groups, pix, b.C, e->st);
+    k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix), b.C, pix, e->state + e->off_gamma + b.ch_off, b.mean,
+                      b.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b.ch_off,
+                      e->grad + e->off_beta + b.ch_off, e->st);
+    k_bn_bwd_apply(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyh_out, groups, pix, b.C, e->st);
+}
+
+void to_nhwc4(fm_engine* e, const float* const* xs, int groups, int B)
+{
+    for (int g = 0; g < groups; ++g)
+        k_nchw_to_nhwc4(xs[g], e->x4 + (size_t)g * B * e->H * e->W * 4, B, e->H, e->W, e->st);
+}
+
+// train-mode forward of groups*B images already in e->x4; fills feat/logits
+void forward_train(fm_engine* e, int groups, int B)
+{
+    const int imgs = groups * B;
+    const float* S = e->state;
+    Conv& c0 = e->convs[0];
+    conv_fwd(e, 0, S, e->x4, c0.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+    bn_fwd_finalize(e, 0, groups, B);
+    k_stem_pool(c0.y, e->bns[0].scale, e->bns[0].shift, e->p0, e->idx0, groups, B, c0.hout, c0.wout, 64, e->st);
+    const float* cur = e->p0;
+    for (auto& blk : e->blocks) {
+        Conv& c1 = e->convs[blk.c1];
+        Conv& c2 = e->convs[blk.c2];
+        const int pix = B * c1.hout * c1.wout;
+        conv_fwd(e, blk.c1, S, cur, c1.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+        bn_fwd_finalize(e, blk.c1, groups, B);
+        k_bn_apply(c1.y, e->bns[blk.c1].scale, e->bns[blk.c1].shift, nullptr, nullptr, nullptr, nullptr, blk.z1,
+                   groups, pix, c1.cout, 1, e->st);
+        conv_fwd(e, blk.c2, S, blk.z1, c2.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+        bn_fwd_finalize(e, blk.c2, groups, B);
+        if (blk.ds >= 0) {
+            Conv& cd = e->convs[blk.ds];
+            conv_fwd(e, blk.ds, S, cur, cd.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+            bn_fwd_finalize(e, blk.ds, groups, B);
+            k_bn_apply(c2.y, e->bns[blk.c2].scale, e->bns[blk.c2].shift, nullptr, cd.y, e->bns[blk.ds].scale,
+                       e->bns[blk.ds].shift, blk.out, groups, pix, c2.cout, 1, e->st);
+        } else {
+            k_bn_apply(c2.y, e->bns[blk.c2].scale, e->bns[blk.c2].shift, cur, nullptr, nullptr, nullptr, blk.out,
+                       groups, pix, c2.cout, 1, e->st);
+        }
+        cur = blk.out;
+    }
+    const Conv& cl = e->convs[e->blocks.back().c2];
+    k_avgpool(cur, e->feat, imgs, cl.hout * cl.wout, 512, e->st);
+    k_fc_fwd(e->feat, S + e->off_fcw, S + e->off_fcb, e->logits, imgs, 512, e->C, e->st);
+    e->ev_dirty = true;      // running stats moved
+}
+
+// eval-mode forward (BN folded into the conv epilogue) of `imgs` images in e->x4
+void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& dirty, int imgs, float* feat,
+                  float* logits)
+{
+    if (dirty) {
+        k_bn_eval_affine(S + e->off_gamma, S + e->off_beta, S + e->off_rm, S + e->off_rv, evs, evh, e->n_bn_ch,
+                         1e-5f, e->st);
+        dirty = false;
+    }
+    auto sc = [&](int bi) { return evs + e->bns[bi].ch_off; };
+    auto sh = [&](int bi) { return evh + e->bns[bi].ch_off; };
+    Conv& c0 = e->convs[0];
+    conv_fwd(e, 0, S, e->x4, c0.y, imgs, 1, sc(0), sh(0), nullptr, 1, nullptr);
+    k_stem_pool(c0.y, nullptr, nullptr, e->p0, nullptr, 1, imgs, c0.hout, c0.wout, 64, e->st);
+    const float* cur = e->p0;
+    for (auto& blk : e->blocks) {
+        conv_fwd(e, blk.c1, S, cur, blk.z1, imgs, 1, sc(blk.c1), sh(blk.c1), nullptr, 1, nullptr);
+        const float* idt = cur;
+        if (blk.ds >= 0) {
+            Conv& cd = e->convs[blk.ds];
+            conv_fwd(e, blk.ds, S, cur, cd.y, imgs, 1, sc(blk.ds), sh(blk.ds), nullptr, 0, nullptr);
+            idt = cd.y;
+        }
+        conv_fwd(e, blk.c2, S, blk.z1, blk.out, imgs, 1, sc(blk.c2), sh(blk.c2), idt, 1, nullptr);
+        cur = blk.out;
+    }
+    const Conv& cl = e->convs[e->blocks.back().c2];
+    k_avgpool(cur, feat, imgs, cl.hout * cl.wout, 512, e->st);
+    k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, 512, e->C, e->st);
+}
+
+// backward from e->dlogits through the graph saved by forward_train, then Adam
+void backward_and_step(fm_engine* e, int groups, int B)
+{
+    const int imgs = groups * B;
+    const float* S = e->state;
+    const Conv& cl = e->convs[e->blocks.back().c2];
+    k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, imgs, 512,
+             e->C, cl.hout * cl.wout, e->st);
+    float *ga = e->GA, *ge = e->GE;
+    for (int b = (int)e->blocks.size() - 1; b >= 0; --b) {
+        Block& blk = e->blocks[b];
+        const float* in = b == 0 ? e->p0 : e->blocks[b - 1].out;
+        // out = relu(bn2(y2) + identity): masked grad dyh goes to bn2 and to the identity path
+        bn_bwd(e, blk.c2, ga, blk.out, e->GB, ga, groups, B);
+        if (blk.ds >= 0) bn_bwd(e, blk.ds, ga, nullptr, e->GC, nullptr, groups, B);
+        conv_wgrad(e, blk.c2, blk.z1, e->GB, imgs);
+        conv_dgrad(e, blk.c2, S, e->GB, e->GD, imgs, nullptr, false);
+        bn_bwd(e, blk.c1, e->GD, blk.z1, e->GD, nullptr, groups, B);
+        conv_wgrad(e, blk.c1, in, e->GD, imgs);
+        if (blk.ds >= 0) {
+            conv_wgrad(e, blk.ds, in, e->GC, imgs);
+            conv_dgrad(e, blk.ds, S, e->GC, ge, imgs, nullptr, false);   // writes parity class (0,0)
+            conv_dgrad(e, blk.c1, S, e->GD, ge, imgs, nullptr, true);    // all classes, (0,0) accumulates
+        } else {
+            conv_dgrad(e, blk.c1, S, e->GD, ge, imgs, ga, false);
+        }
+        std::swap(ga, ge);
+    }
+    const Conv& c0 = e->convs[0];
+    k_stem_pool_bwd(ga, e->p0, e->idx0, e->dyh0, imgs, c0.hout, c0.wout, 64, e->st);
+    bn_bwd(e, 0, e->dyh0, nullptr, e->dyh0, nullptr, groups, B);
+    conv_wgrad(e, 0, e->x4, e->dyh0, imgs);
+    // optimizer.step()
+    e->adam_t += 1;
+    const double bc1 = 1.0 - pow((double)e->hp.beta1, (double)e->adam_t);
+    const double bc2 = 1.0 - pow((double)e->hp.beta2, (double)e->adam_t);
+    k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
+           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
+    e->ev_dirty = true;
+}
+
+ClassVec to_cv(const float* h, int C)
+{
+    ClassVec v{};
+    for (int i = 0; i < C; ++i) v.v[i] = h[i];
+    return v;
+}
+
+}  // namespace
+
+// =============================== C ABI =======================================
+extern "C" {
+
+int fm_create(const fm_config* cfg, fm_engine** out)
+{
+    ARGCHK(cfg && out, "null cfg/out");
+    ARGCHK(cfg->model == 0, "only model 0 (ResNet-18) is built");
+    ARGCHK(cfg->n_classes >= 1 && cfg->n_classes <= FM_MAX_CLASSES, "n_classes out of range");
+    ARGCHK(cfg->in_h >= 32 && cfg->in_w >= 32 && cfg->in_h % 32 == 0 && cfg->in_w % 32 == 0,
+           "in_h/in_w must be multiples of 32");
+    ARGCHK(cfg->max_images >= 1, "max_images");
+    fm_engine* e = new fm_engine();
+    e->cfg = *cfg;
+    e->st = reinterpret_cast<hipStream_t>(cfg->stream);
+    e->C = cfg->n_classes; e->H = cfg->in_h; e->W = cfg->in_w; e->maxB = cfg->max_images;
+    int rc = build_resnet18(e);
+    if (rc == FM_OK) rc = build_tables(e);
+    if (rc == FM_OK) rc = alloc_workspaces(e);
+    if (rc != FM_OK) { fm_destroy(e); return rc; }
+    *out = e;
+    return FM_OK;
+}
+
+int fm_destroy(fm_engine* e)
+{
+    if (!e) return FM_OK;
+    (void)hipStreamSynchronize(e->st);
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (auto& p : e->evs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto v : e->ev_free) (void)hipEventDestroy(v);
+    delete e;
+    return FM_OK;
+}
+
+int fm_sync(fm_engine* e)
+{
+    ARGCHK(e, "null engine");
+    HIPCHK(hipStreamSynchronize(e->st));
+    HIPCHK(hipGetLastError());
+    return FM_OK;
+}
+
+int fm_state_sizes(fm_engine* e, int64_t* n_f32, int64_t* n_i64)
+{
+    ARGCHK(e, "null engine");
+    if (n_f32) *n_f32 = e->nf_sd;
+    if (n_i64) *n_i64 = e->ni_sd;
+    return FM_OK;
+}
+
+int fm_set_state(fm_engine* e, const float* host_f32, const int64_t* host_i64)
+{
+    ARGCHK(e && host_f32, "null engine/state");
+    HIPCHK(hipMemcpyAsync(e->stage_sd, host_f32, (size_t)e->nf_sd * 4, hipMemcpyHostToDevice, e->st));
+    size_t off = 0;
+    int ic = 0;
+    for (auto& en : e->entries) {
+        if (en.kind == 0) {
+            const Conv& c = e->convs[en.conv];
+            k_oihw_to_ohwi(e->stage_sd + off, e->state + c.w_off, c.cout, c.cin, c.k, c.k, c.kw_p, c.cin_p, e->st);
+            off += en.n;
+        } else if (en.kind == 1) {
+            HIPCHK(hipMemcpyAsync(e->state + en.eng_off, e->stage_sd + off, en.n * 4, hipMemcpyDeviceToDevice, e->st));
+            off += en.n;
+        } else {
+            e->counters[en.bn] = host_i64 ? host_i64[ic] : 0;
+            ++ic;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(e->st));
+    e->ev_dirty = true;
+    return FM_OK;
+}
+
+int fm_get_state(fm_engine* e, float* host_f32, int64_t* host_i64)
+{
+    ARGCHK(e && host_f32, "null engine/state");
+    size_t off = 0;
+    int ic = 0;
+    for (auto& en : e->entries) {
+        if (en.kind == 0) {
+            const Conv& c = e->convs[en.conv];
+            k_ohwi_to_oihw(e->state + c.w_off, e->stage_sd + off, c.cout, c.cin, c.k, c.k, c.kw_p, c.cin_p, e->st);
+            off += en.n;
+        } else if (en.kind == 1) {
+            HIPCHK(hipMemcpyAsync(e->stage_sd + off, e->state + en.eng_off, en.n * 4, hipMemcpyDeviceToDevice, e->st));
+            off += en.n;
+        } else {
+            if (host_i64) host_i64[ic] = e->counters[en.bn];
+            ++ic;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(host_f32, e->stage_sd, (size_t)e->nf_sd * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    return FM_OK;
+}
+
+int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel)
+{
+    ARGCHK(e && dev_ptr && numel, "null");
+    *dev_ptr = e->state;
+    *numel = (int64_t)e->NS;
+    e->ev_dirty = true;       // the caller is about to overwrite it (all-reduce)
+    return FM_OK;
+}
+
+int fm_state_scale(fm_engine* e, float w)
+{
+    ARGCHK(e, "null engine");
+    k_scale(e->state, w, (int64_t)e->NS, e->st);
+    e->ev_dirty = true;
+    return FM_OK;
+}
+
+int fm_teacher_snapshot(fm_engine* e)
+{
+    ARGCHK(e, "null engine");
+    HIPCHK(hipMemcpyAsync(e->tstate, e->state, e->NS * 4, hipMemcpyDeviceToDevice, e->st));
+    e->tev_dirty = true;
+    return FM_OK;
+}
+
+int fm_adam_reset(fm_engine* e, const fm_adam* hp)
+{
+    ARGCHK(e, "null engine");
+    if (hp) e->hp = *hp;
+    e->adam_t = 0;
+    HIPCHK(hipMemsetAsync(e->adam_m, 0, e->NP * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->adam_v, 0, e->NP * 4, e->st));
+    return FM_OK;
+}
+
+int fm_forward_eval(fm_engine* e, const float* x_dev, int32_t B, int32_t use_teacher, float* feat_dev,
+                    float* logits_dev)
+{
+    ARGCHK(e && x_dev, "null");
+    ARGCHK(B >= 1 && B <= e->maxB, "B exceeds max_images");
+    const float* xs[1] = {x_dev};
+    to_nhwc4(e, xs, 1, B);
+    if (use_teacher)
+        forward_eval(e, e->tstate, e->tev_scale, e->tev_shift, e->tev_dirty, B, e->tfeat, e->tlogits);
+    else
+        forward_eval(e, e->state, e->ev_scale, e->ev_shift, e->ev_dirty, B, e->feat, e->logits);
+    if (feat_dev)
+        HIPCHK(hipMemcpyAsync(feat_dev, use_teacher ? e->tfeat : e->feat, (size_t)B * 512 * 4,
+                              hipMemcpyDeviceToDevice, e->st));
+    if (logits_dev)
+        HIPCHK(hipMemcpyAsync(logits_dev, use_teacher ? e->tlogits : e->logits, (size_t)B * e->C * 4,
+                              hipMemcpyDeviceToDevice, e->st));
+    return FM_OK;
+}
+
+int fm_step_bce(fm_engine* e, const float* x_dev, const float* y_dev, int32_t B, const float* pos_weight_host,
+                int32_t bs_norm, float* loss_dev)
+{
+    ARGCHK(e && x_dev && y_dev && pos_weight_host && loss_dev, "null");
+    ARGCHK(B >= 1 && B <= e->maxB, "B exceeds max_images");
+    const float* xs[1] = {x_dev};
+    to_nhwc4(e, xs, 1, B);
+    forward_train(e, 1, B);
+    k_loss_bce(e->logits, y_dev, to_cv(pos_weight_host, e->C), B, e->C, 1.f / ((float)bs_norm * (float)e->C),
+               e->dlogits, loss_dev, e->st);
+    backward_and_step(e, 1, B);
+    return FM_OK;
+}
+
+int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const float* y_dev, int32_t B,
+                   const float* active_mask_host, int32_t annotation_num, int32_t bs_norm, float* loss_dev)
+{
+    ARGCHK(e && x1_dev && x2_dev && y_dev && active_mask_host && loss_dev, "null");
+    ARGCHK(B >= 1 && 2 * B <= e->maxB, "2*B exceeds max_images");
+    int n_neg = 0;
+    for (int c = 0; c < e->C; ++c) n_neg += active_mask_host[c] == 0.f;
+    const float* xs[2] = {x1_dev, x2_dev};
+    to_nhwc4(e, xs, 2, B);
+    // frozen teacher first (eval mode; its activations may be overwritten by the student)
+    forward_eval(e, e->tstate, e->tev_scale, e->tev_shift, e->tev_dirty, 2 * B, e->tfeat, e->tlogits);
+    forward_train(e, 2, B);
+    k_loss_stage1(e->logits, e->tlogits, y_dev, to_cv(active_mask_host, e->C), B, e->C,
+                  1.f / ((float)bs_norm * (float)annotation_num),
+                  n_neg ? 1.f / ((float)bs_norm * (float)n_neg) : 0.f, e->dlogits, loss_dev, e->st);
+    backward_and_step(e, 2, B);
+    return FM_OK;
+}
+
+int fm_step_stage2(fm_engine* e, const float* x_dev, const float* y_dev, const float* distill_dev, int32_t B,
+                   float* loss_dev)
+{
+    ARGCHK(e && x_dev && y_dev && distill_dev && loss_dev, "null");
+    ARGCHK(B >= 1 && B <= e->maxB, "B exceeds max_images");
+    const float* xs[1] = {x_dev};
+    to_nhwc4(e, xs, 1, B);
+    forward_train(e, 1, B);
+    k_loss_stage2(e->logits, y_dev, distill_dev, B, e->C, e->dlogits, loss_dev, e->st);
+    backward_and_step(e, 1, B);
+    return FM_OK;
+}
+
+int fm_step_fixmatch(fm_engine* e, const float* xw_dev, const float* xs_dev, const float* y_dev, int32_t B,
+                     const float* pos_weight_host, const float* pos_weight_unk_host, const float* active_mask_host,
+                     int32_t annotation_num, int32_t bs_norm, float* loss_dev)
+{
+    ARGCHK(e && xw_dev && xs_dev && y_dev && pos_weight_host && pos_weight_unk_host && active_mask_host && loss_dev,
+           "null");
+    ARGCHK(B >= 1 && 2 * B <= e->maxB && B <= 2048, "2*B exceeds max_images");
+    int n_neg = 0;
+    for (int c = 0; c < e->C; ++c) n_neg += active_mask_host[c] == 0.f;
+    const float* xs[2] = {xw_dev, xs_dev};
+    to_nhwc4(e, xs, 2, B);
+    forward_train(e, 2, B);
+    k_loss_fixmatch(e->logits, y_dev, to_cv(pos_weight_host, e->C), to_cv(pos_weight_unk_host, e->C),
+                    to_cv(active_mask_host, e->C), B, e->C, n_neg, 1.f / ((float)bs_norm * (float)annotation_num),
+                    e->C - annotation_num, e->dlogits, loss_dev, e->st);
+    backward_and_step(e, 2, B);
+    return FM_OK;
+}
+
+int fm_proto_reset(fm_engine* e)
+{
+    ARGCHK(e, "null engine");
+    HIPCHK(hipMemsetAsync(e->psum, 0, (size_t)2 * e->C * 512 * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->pcnt, 0, (size_t)2 * e->C * 8, e->st));
+    HIPCHK(hipMemsetAsync(e->tcnt, 0, (size_t)e->C * 8, e->st));
+    return FM_OK;
+}
+
+int fm_proto_accumulate(fm_engine* e, const float* feat_dev, const float* logits_dev, const float* labels_dev,
+                        int32_t B, const float* active_mask_host, const float* negative_mask_host, float L, float U)
+{
+    ARGCHK(e && feat_dev && logits_dev && labels_dev && active_mask_host && negative_mask_host, "null");
+    k_proto_accumulate(feat_dev, logits_dev, labels_dev, B, 512, e->C, to_cv(active_mask_host, e->C),
+                       to_cv(negative_mask_host, e->C), L, U, e->psum, e->pcnt, e->tcnt, e->st);
+    return FM_OK;
+}
+
+int fm_proto_finalize(fm_engine* e, int32_t zero_guard, int64_t n_local, const float* active_mask_host,
+                      float* proto_host, double* t_host)
+{
+    ARGCHK(e && active_mask_host && proto_host && t_host, "null");
+    std::vector<int64_t> pc(2 * e->C), tc(e->C);
+    HIPCHK(hipMemcpyAsync(proto_host, e->psum, (size_t)2 * e->C * 512 * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(pc.data(), e->pcnt, pc.size() * 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipMemcpyAsync(tc.data(), e->tcnt, tc.size() * 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (int c = 0; c < e->C; ++c) {
+        t_host[c] = (double)tc[c] / (double)n_local;
+        if (active_mask_host[c] == 0.f) continue;
+        for (int v = 0; v < 2; ++v) {
+            const int r = 2 * c + v;
+            if (zero_guard && pc[r] == 0) continue;
+            const float den = (float)pc[r];
+            for (int d = 0; d < 512; ++d) proto_host[(size_t)r * 512 + d] = proto_host[(size_t)r * 512 + d] / den;
+        }
+    }
+    return FM_OK;
+}
+
+int fm_cos_tag(fm_engine* e, const float* feat_dev, int64_t N, const float* proto_dev, const int32_t* classes_host,
+               int32_t n_cls, float* sim_dev)
+{
+    ARGCHK(e && feat_dev && proto_dev && classes_host && sim_dev, "null");
+    ARGCHK(n_cls >= 0 && n_cls <= FM_MAX_CLASSES, "n_cls");
+    if (n_cls == 0 || N == 0) return FM_OK;
+    HIPCHK(hipMemcpyAsync(e->cls_dev, classes_host, (size_t)n_cls * 4, hipMemcpyHostToDevice, e->st));
+    k_cos_tag(feat_dev, N, 512, proto_dev, e->cls_dev, n_cls, sim_dev, e->st);
+    return FM_OK;
+}
+
+int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_thr, double noise_thr, int32_t cap,
+                   int32_t* top_host, int32_t* n_top, int32_t* bot_host, int32_t* n_bot)
+{
+    ARGCHK(e && sim_dev && top_host && n_top && bot_host && n_bot, "null");
+    *n_top = *n_bot = 0;
+    if (N == 0) return FM_OK;
+    int counts[2];
+    k_count_sign(sim_dev, N, e->sel_counts, e->st);
+    HIPCHK(hipMemcpyAsync(counts, e->sel_counts, 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    const int kt = (int)(1 * clean_thr * counts[0]);      // int() truncation as in :1069-1070
+    const int kb = (int)(1 * noise_thr * counts[1]);
+    ARGCHK(kt <= cap && kb <= cap, "selection exceeds cap");
+    if (kt == 0 && kb == 0) return FM_OK;
+    if (e->sel_cap < std::max(kt, kb)) {
+        e->sel_cap = std::max(std::max(kt, kb), 1024);
+        DALLOC(e->sel_top, e->sel_cap);
+        DALLOC(e->sel_bot, e->sel_cap);
+    }
+    k_rank_select(sim_dev, N, kt, kb, e->sel_top, e->sel_bot, e->st);
+    if (kt) HIPCHK(hipMemcpyAsync(top_host, e->sel_top, (size_t)kt * 4, hipMemcpyDeviceToHost, e->st));
+    if (kb) HIPCHK(hipMemcpyAsync(bot_host, e->sel_bot, (size_t)kb * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    *n_top = kt; *n_bot = kb;
+    return FM_OK;
+}
+
+int fm_profile_enable(fm_engine* e, int32_t on)
+{
+    ARGCHK(e, "null engine");
+    e->prof = on != 0;
+    return FM_OK;
+}
+
+int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops)
+{
+    ARGCHK(e && family >= 0 && family < 2, "family");
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (auto& p : e->evs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+            e->prof_ms[p.family] += t; e->prof_flops[p.family] += p.flops; e->prof_n[p.family] += 1;
+        }
+        e->ev_free.push_back(p.a); e->ev_free.push_back(p.b);
+    }
+    e->evs.clear();
+    if (launches) *launches = e->prof_n[family];
+    if (ms) *ms = e->prof_ms[family];
+    if (flops) *flops = e->prof_flops[family];
+    e->prof_n[family] = 0; e->prof_ms[family] = 0; e->prof_flops[family] = 0;
+    return FM_OK;
+}
+
+int fm_debug_get_grads(fm_engine* e, float* host_f32)
+{
+    ARGCHK(e && host_f32, "null");
+    size_t off = 0;
+    for (auto& en : e->entries) {
+        if (en.kind == 0) {
+            const Conv& c = e->convs[en.conv];
+            k_ohwi_to_oihw(e->grad + c.w_off, e->stage_sd + off, c.cout, c.cin, c.k, c.k, c.kw_p, c.cin_p, e->st);
+            off += en.n;
+        } else if (en.kind == 1) {
+            if (en.eng_off < e->NP)
+                HIPCHK(hipMemcpyAsync(e->stage_sd + off, e->grad + en.eng_off, en.n * 4, hipMemcpyDeviceToDevice, e->st));
+            else
+                HIPCHK(hipMemsetAsync(e->stage_sd + off, 0, en.n * 4, e->st));
+            off += en.n;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(host_f32, e->stage_sd, (size_t)e->nf_sd * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    return FM_OK;
+}
+
+int fm_debug_num_convs(fm_engine* e) { return e ? (int)e->convs.size() : 0; }
+
+int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info12)
+{
+    ARGCHK(e && info12 && conv >= 0 && conv < (int)e->convs.size(), "conv index");
+    const Conv& c = e->convs[conv];
+    const int v[12] = {c.cin, c.cout, c.k, c.stride, c.pad, c.hin, c.win, c.hout, c.wout, c.cin_p, c.Kw, c.kw_p};
+    memcpy(info12, v, sizeof v);
+    return FM_OK;
+}
+
+int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, const float* dy_dev, float* out_dev,
+                  int32_t imgs, int32_t groups, float* stats_dev)
+{
+    ARGCHK(e && out_dev && conv >= 0 && conv < (int)e->convs.size(), "conv index");
+    ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs/groups");
+    Conv& c = e->convs[conv];
+    if (op == 0) {
+        ARGCHK(x_dev, "x");
+        conv_fwd(e, conv, e->state, x_dev, out_dev, imgs, groups, nullptr, nullptr, nullptr, 0,
+                 stats_dev ? e->ws_stats : nullptr);
+        if (stats_dev) {
+            // fold the per-tile partials with the finalize kernel's own reduction order: sum/sumsq only
+            const int tiles = stats_tiles(e, conv, imgs / groups);
+            std::vector<float> h((size_t)groups * tiles * 2 * c.cout), o((size_t)groups * 2 * c.cout, 0.f);
+            HIPCHK(hipMemcpyAsync(h.data(), e->ws_stats, h.size() * 4, hipMemcpyDeviceToHost, e->st));
+            HIPCHK(hipStreamSynchronize(e->st));
+            for (int g = 0; g < groups; ++g)
+                for (int k = 0; k < 2 * c.cout; ++k) {
+                    double s = 0;
+                    for (int t = 0; t < tiles; ++t) s += h[((size_t)g * tiles + t) * 2 * c.cout + k];
+                    o[(size_t)g * 2 * c.cout + k] = (float)s;
+                }
+            HIPCHK(hipMemcpy(stats_dev, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+        }
+    } else if (op == 1) {
+        ARGCHK(dy_dev && c.ncls > 0, "dgrad unavailable for this conv");
+        conv_dgrad(e, conv, e->state, dy_dev, out_dev, imgs, nullptr, false);
+    } else if (op == 2) {
+        ARGCHK(x_dev && dy_dev, "x/dy");
+        conv_wgrad(e, conv, x_dev, dy_dev, imgs);
+        HIPCHK(hipMemcpyAsync(out_dev, e->grad + c.w_off, c.w_numel * 4, hipMemcpyDeviceToDevice, e->st));
+    } else {
+        ARGCHK(false, "op");
+    }
+    return FM_OK;
+}
+
+}  // extern "C"

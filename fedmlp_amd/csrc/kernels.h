@@ -1,0 +1,86 @@
+// Launchers of the HBM-bound / small kernels of the FedMLP engine (elementwise.hip,
+// heads.hip).  All tensors are fp32; activations are NHWC.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FM_MAXC 32
+
+struct ClassVec { float v[FM_MAXC]; };
+struct TapList { int t[9]; int n; };
+
+// ---- layout -----------------------------------------------------------------
+void k_nchw_to_nhwc4(const float* x, float* y, int imgs, int H, int W, hipStream_t s);
+// dst[o][h][w(Wpad)][i(Ipad)] <- src[o][i][h][w]  (zero padded) and its inverse
+void k_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s);
+void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s);
+// dgrad pack: out[ci][j][co] = w[co][taps.t[j]][ci]   (w is [Co][T][Ci])
+void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList taps, hipStream_t s);
+void k_scale(float* x, float w, int64_t n, hipStream_t s);
+
+// ---- batch norm ---------------------------------------------------------------
+// stats: [groups][tiles][2][C] partial (sum, sumsq) from the conv epilogue.
+// Writes mean/istd/scale/shift [groups][C]; updates running stats group by group
+// (momentum 0.1, unbiased variance), like consecutive train-mode forwards.
+void k_bn_finalize(const float* stats, int groups, int tiles, int C, int count,
+                   const float* gamma, const float* beta, float* run_mean, float* run_var,
+                   float* mean, float* istd, float* scale, float* shift, float eps, float momentum,
+                   hipStream_t s);
+// eval-mode folded affine for all BN channels at once
+void k_bn_eval_affine(const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                      float* scale, float* shift, int n, float eps, hipStream_t s);
+// out = [relu]( y*scale+shift [+ res] [+ y2*scale2+shift2] ), per group
+void k_bn_apply(const float* y, const float* scale, const float* shift, const float* res,
+                const float* y2, const float* scale2, const float* shift2, float* out,
+                int groups, int pix_per_group, int C, int relu, hipStream_t s);
+// stem: pooled = maxpool3x3s2p1(relu(y*scale+shift)) (+argmax code) ; scale==null -> plain maxpool
+void k_stem_pool(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx,
+                 int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);
+void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, float* dy,
+                     int imgs, int H, int W, int C, hipStream_t s);
+// backward: partial sums of dyh = dz*(z>0) and dyh*xhat -> part[groups][nblk][2][C]
+int bn_bwd_blocks(int pix_per_group);
+void k_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* istd,
+                     float* part, int groups, int pix_per_group, int C, hipStream_t s);
+// coefficients ca,cb,cc [groups][C]; dgamma/dbeta written (summed over groups)
+void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count, const float* gamma,
+                       const float* mean, const float* istd, float* ca, float* cb, float* cc,
+                       float* dgamma, float* dbeta, hipStream_t s);
+// dy = ca*dyh + cb*y + cc ; optionally store dyh
+void k_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* ca, const float* cb,
+                    const float* cc, float* dy, float* dyh_out, int groups, int pix_per_group, int C,
+                    hipStream_t s);
+
+// ---- head ---------------------------------------------------------------------
+void k_avgpool(const float* x, float* feat, int imgs, int HW, int C, hipStream_t s);
+void k_fc_fwd(const float* feat, const float* W, const float* b, float* logits, int imgs, int D, int C,
+              hipStream_t s);
+// dW[k][d], db[k] written; dout[img][hw][d] = (sum_k dz[img][k] W[k][d]) / HW
+void k_fc_bwd(const float* dz, const float* feat, const float* W, float* dW, float* db, float* dout,
+              int imgs, int D, int C, int HW, hipStream_t s);
+
+// ---- losses (one block; deterministic) -------------------------------------------
+void k_loss_bce(const float* z, const float* y, ClassVec pos_w, int B, int C, float inv_norm,
+                float* dz, float* loss, hipStream_t s);
+void k_loss_stage1(const float* z, const float* g, const float* y, ClassVec active, int B, int C,
+                   float inv_sup, float inv_dis, float* dz, float* loss, hipStream_t s);
+void k_loss_stage2(const float* z, const float* y, const float* distill, int B, int C, float* dz,
+                   float* loss, hipStream_t s);
+void k_loss_fixmatch(const float* z, const float* y, ClassVec pos_w, ClassVec pos_wu, ClassVec active,
+                     int B, int C, int n_neg, float inv_sup, int n_cls_minus_ann, float* dz, float* loss,
+                     hipStream_t s);
+
+// ---- optimiser -------------------------------------------------------------------
+void k_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+            float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
+void k_reduce_slabs(const float* slab, float* out, int splits, int64_t n, hipStream_t s);
+
+// ---- prototypes / tagging ----------------------------------------------------------
+void k_proto_accumulate(const float* feat, const float* logits, const float* labels, int B, int D, int C,
+                        ClassVec active, ClassVec negative, float L, float U, float* psum,
+                        int64_t* pcnt, int64_t* tcnt, hipStream_t s);
+void k_cos_tag(const float* feat, int64_t N, int D, const float* proto, const int* classes, int ncls,
+               float* sim, hipStream_t s);
+void k_count_sign(const float* sim, int64_t N, int* counts /*[2]: >=0, <0*/, hipStream_t s);
+// stable ranks: top[rank_desc] = pos if rank_desc < ktop ; bot[rank_asc] = pos if rank_asc < kbot
+void k_rank_select(const float* sim, int64_t N, int ktop, int kbot, int* top, int* bot, hipStream_t s);

@@ -1,0 +1,216 @@
+"""Python handle over the C-ABI engine (include/fedmlp_hip.h).
+
+torch is used for device memory and streams only (tensor.data_ptr() crosses the
+ABI); all arithmetic on the path runs in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, spec
+
+MODEL_IDS = {"Resnet18": 0}
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.int32), \
+        (t.device, t.dtype, t.is_contiguous())
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One per process/GPU. Owns the device-resident model state, optimiser
+    moments, teacher snapshot and activation workspaces for `max_images`."""
+
+    def __init__(self, model, n_classes, in_h, in_w, max_images, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("fedmlp_amd.Engine needs a GPU (no CPU fallback)")
+        self.lib = _lib.load()
+        self.model, self.n_classes = model, int(n_classes)
+        self.in_h, self.in_w, self.max_images = int(in_h), int(in_w), int(max_images)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        cfg = _lib.FmConfig(MODEL_IDS[model], self.n_classes, self.in_h, self.in_w,
+                            self.max_images, (C.c_int32 * 3)(0, 0, 0), None)
+        h = C.c_void_p()
+        _lib.check(self.lib.fm_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        nf, ni = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.fm_state_sizes(self.h, C.byref(nf), C.byref(ni)))
+        self.nf, self.ni = nf.value, ni.value
+        assert (self.nf, self.ni) == spec.sizes(model, self.n_classes), \
+            "engine and fedmlp_amd.spec disagree on the state_dict layout"
+        self.feature_dim = spec.FEATURE_DIM[model]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state -----------------------------------------------------------------
+    def set_state(self, flat, counters):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        counters = np.ascontiguousarray(counters, dtype=np.int64)
+        assert flat.size == self.nf and counters.size == self.ni
+        _lib.check(self.lib.fm_set_state(self.h, flat.ctypes.data_as(C.c_void_p),
+                                         counters.ctypes.data_as(C.c_void_p)))
+
+    def get_state(self):
+        flat = np.empty(self.nf, np.float32)
+        counters = np.empty(self.ni, np.int64)
+        _lib.check(self.lib.fm_get_state(self.h, flat.ctypes.data_as(C.c_void_p),
+                                         counters.ctypes.data_as(C.c_void_p)))
+        return flat, counters
+
+    def state_tensor(self):
+        """torch view of the engine-layout device state (for the RCCL all-reduce)."""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.fm_state_device(self.h, C.byref(p), C.byref(n)))
+        return _device_view(p.value, n.value, self.device)
+
+    def state_scale(self, w):
+        _lib.check(self.lib.fm_state_scale(self.h, C.c_float(w)))
+
+    def teacher_snapshot(self):
+        _lib.check(self.lib.fm_teacher_snapshot(self.h))
+
+    def adam_reset(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4):
+        hp = _lib.FmAdam(lr, betas[0], betas[1], eps, weight_decay)
+        _lib.check(self.lib.fm_adam_reset(self.h, C.byref(hp)))
+
+    def sync(self):
+        _lib.check(self.lib.fm_sync(self.h))
+
+    # ---- forward / steps -----------------------------------------------------------
+    def forward_eval(self, x, teacher=False):
+        B = x.shape[0]
+        feat = torch.empty((B, self.feature_dim), device=self.device, dtype=torch.float32)
+        logits = torch.empty((B, self.n_classes), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.fm_forward_eval(self.h, _ptr(x), B, int(teacher), _ptr(feat), _ptr(logits)))
+        return feat, logits
+
+    def step_bce(self, x, y, pos_weight, bs_norm, loss_out):
+        _lib.check(self.lib.fm_step_bce(self.h, _ptr(x), _ptr(y), x.shape[0],
+                                        _lib.fvec(pos_weight, self.n_classes), int(bs_norm),
+                                        _ptr(loss_out)))
+
+    def step_stage1(self, x1, x2, y, active_mask, annotation_num, bs_norm, loss_out):
+        _lib.check(self.lib.fm_step_stage1(self.h, _ptr(x1), _ptr(x2), _ptr(y), x1.shape[0],
+                                           _lib.fvec(active_mask, self.n_classes),
+                                           int(annotation_num), int(bs_norm), _ptr(loss_out)))
+
+    def step_stage2(self, x, y, distill, loss_out):
+        _lib.check(self.lib.fm_step_stage2(self.h, _ptr(x), _ptr(y), _ptr(distill), x.shape[0],
+                                           _ptr(loss_out)))
+
+    def step_fixmatch(self, xw, xs, y, pos_weight, pos_weight_unk, active_mask, annotation_num,
+                      bs_norm, loss_out):
+        n = self.n_classes
+        _lib.check(self.lib.fm_step_fixmatch(
+            self.h, _ptr(xw), _ptr(xs), _ptr(y), xw.shape[0], _lib.fvec(pos_weight, n),
+            _lib.fvec(pos_weight_unk, n), _lib.fvec(active_mask, n), int(annotation_num),
+            int(bs_norm), _ptr(loss_out)))
+
+    # ---- prototypes / tagging ------------------------------------------------------
+    def proto_reset(self):
+        _lib.check(self.lib.fm_proto_reset(self.h))
+
+    def proto_accumulate(self, feat, logits, labels, active_mask, negative_mask, L, U):
+        n = self.n_classes
+        _lib.check(self.lib.fm_proto_accumulate(self.h, _ptr(feat), _ptr(logits), _ptr(labels),
+                                                feat.shape[0], _lib.fvec(active_mask, n),
+                                                _lib.fvec(negative_mask, n), C.c_float(L),
+                                                C.c_float(U)))
+
+    def proto_finalize(self, zero_guard, n_local, active_mask):
+        proto = np.empty((2 * self.n_classes, self.feature_dim), np.float32)
+        t = np.empty(self.n_classes, np.float64)
+        _lib.check(self.lib.fm_proto_finalize(self.h, int(zero_guard), int(n_local),
+                                              _lib.fvec(active_mask, self.n_classes),
+                                              proto.ctypes.data_as(C.c_void_p),
+                                              t.ctypes.data_as(C.c_void_p)))
+        return t, proto
+
+    def cos_tag(self, feat, proto, classes):
+        N = feat.shape[0]
+        sim = torch.empty((len(classes), N), device=self.device, dtype=torch.float32)
+        if len(classes) and N:
+            cls = (C.c_int32 * len(classes))(*[int(c) for c in classes])
+            _lib.check(self.lib.fm_cos_tag(self.h, _ptr(feat), N, _ptr(proto), cls, len(classes),
+                                           _ptr(sim)))
+        return sim
+
+    def select_topk(self, sim_row, clean_thr, noise_thr):
+        N = sim_row.shape[0]
+        cap = max(N, 1)
+        top, bot = (C.c_int32 * cap)(), (C.c_int32 * cap)()
+        nt, nb = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.fm_select_topk(self.h, _ptr(sim_row), N, float(clean_thr),
+                                           float(noise_thr), cap, top, C.byref(nt), bot,
+                                           C.byref(nb)))
+        return list(top[:nt.value]), list(bot[:nb.value])
+
+    # ---- measurement ------------------------------------------------------------------
+    def profile_enable(self, on):
+        _lib.check(self.lib.fm_profile_enable(self.h, int(on)))
+
+    def profile_read(self, family):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self.lib.fm_profile_read(self.h, family, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+    # ---- kernel-level test hooks ----------------------------------------------------------
+    def debug_conv_info(self, conv):
+        info = (C.c_int32 * 12)()
+        _lib.check(self.lib.fm_debug_conv_info(self.h, conv, info))
+        keys = ("cin", "cout", "k", "stride", "pad", "hin", "win", "hout", "wout", "cin_p", "Kw", "kw_p")
+        return dict(zip(keys, list(info)))
+
+    def debug_get_grads(self):
+        flat = np.empty(self.nf, np.float32)
+        _lib.check(self.lib.fm_debug_get_grads(self.h, flat.ctypes.data_as(C.c_void_p)))
+        return flat
+
+    def debug_num_convs(self):
+        return self.lib.fm_debug_num_convs(self.h)
+
+    def debug_conv(self, op, conv, x, dy, out, imgs, groups=1, stats=None):
+        _lib.check(self.lib.fm_debug_conv(self.h, op, conv, _ptr(x), _ptr(dy), _ptr(out), imgs, groups,
+                                          _ptr(stats)))
+
+
+class _CudaArrayView:
+    """Minimal __cuda_array_interface__ carrier so torch can alias engine memory."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def _device_view(ptr, n, device):
+    return torch.as_tensor(_CudaArrayView(ptr, n), device=device)
+
+
+_ENGINES = {}
+
+
+def get_engine(model, n_classes, in_h, in_w, max_images, device="cuda:0"):
+    """Process-wide engine cache (engines own GBs of workspace; the reference's
+    cheap deepcopy(net) objects map onto ONE engine whose state is swapped)."""
+    key = (model, int(n_classes), int(in_h), int(in_w), str(device))
+    e = _ENGINES.get(key)
+    if e is None or e.max_images < max_images:
+        if e is not None:
+            e.close()
+        e = Engine(model, n_classes, in_h, in_w, max_images, device)
+        _ENGINES[key] = e
+    return e

@@ -1,0 +1,182 @@
+/*
+ * fedmlp_hip.h -- C ABI of the MI355X-native FedMLP per-client training engine.
+ *
+ * The reference (szbonaldo/FedMLP) has no FFI layer: its boundary for this path
+ * is the Python call surface build_model() / LocalUpdate / FedAvg* (SURVEY.md
+ * 8b).  This library is what a ctypes binding of that surface calls; the
+ * reference-side stub is shown in INTEGRATION.md.  Plain pointers and sizes
+ * only: no torch types, no C++ types, no exceptions across the boundary.
+ *
+ * Conventions
+ *   - One opaque engine per GPU/process; not thread-safe per handle
+ *     (the reference drives the model from a single thread, main.py:135).
+ *   - Every function returns 0 on success, a negative code on failure;
+ *     fm_last_error() returns a human-readable message for the calling thread.
+ *   - "dev" pointers are HIP device pointers owned by the caller (the Python
+ *     shim passes torch tensor data_ptr()s); "host" pointers are host memory.
+ *   - Images are fp32 NCHW [B,3,H,W] exactly as the reference's DataLoader
+ *     yields them (dataset/all_dataset.py:73-83); labels/masks fp32 [B,C].
+ *   - All work is enqueued on the stream given at fm_create (0 = the null
+ *     stream, which is also torch's default stream); nothing synchronises
+ *     except fm_sync, fm_get_state, fm_set_state and the *_host getters.
+ *   - The model state crosses the boundary in the reference's state_dict
+ *     order (torchvision key order, conv weights OIHW): one flat fp32 buffer
+ *     + one int64 buffer of num_batches_tracked counters (fedmlp_amd/spec.py).
+ */
+#ifndef FEDMLP_HIP_H
+#define FEDMLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FM_MAX_CLASSES 32
+
+#define FM_OK 0
+#define FM_ERR_ARG (-1)     /* bad argument / unsupported configuration */
+#define FM_ERR_HIP (-2)     /* a HIP runtime call failed                */
+#define FM_ERR_STATE (-3)   /* call sequence error                      */
+
+typedef struct fm_engine fm_engine;
+
+typedef struct fm_config {
+    int32_t model;        /* 0 = ResNet-18 (model/all_models.py:53-54, 117-120)      */
+    int32_t n_classes;    /* args.n_classes, <= FM_MAX_CLASSES                       */
+    int32_t in_h, in_w;   /* input spatial size (224 in the reference, >= 32)        */
+    int32_t max_images;   /* max images in ONE forward call (views x batch; eval     */
+                          /* passes use 4*batch_size, utils/local_training.py:977)   */
+    int32_t reserved[3];
+    void*   stream;       /* hipStream_t; NULL = null stream                         */
+} fm_config;
+
+/* Adam hyper-parameters of utils/local_training.py:636-637 (torch.optim.Adam,
+ * coupled L2 weight decay). */
+typedef struct fm_adam {
+    float lr, beta1, beta2, eps, weight_decay;
+} fm_adam;
+
+const char* fm_last_error(void);
+const char* fm_version(void);
+
+/* ---- lifetime ---------------------------------------------------------- */
+int fm_create(const fm_config* cfg, fm_engine** out);
+int fm_destroy(fm_engine* e);
+int fm_sync(fm_engine* e);
+
+/* ---- state: net.state_dict() / load_state_dict()  (main.py:196, 222) ----- */
+/* Sizes of the state_dict-order buffers (fp32 elements, int64 counters). */
+int fm_state_sizes(fm_engine* e, int64_t* n_f32, int64_t* n_i64);
+int fm_set_state(fm_engine* e, const float* host_f32, const int64_t* host_i64);
+int fm_get_state(fm_engine* e, float* host_f32, int64_t* host_i64);
+/* The engine-layout device buffer holding every fp32 state entry (parameters
+ * then BN running statistics).  FedAvg (utils/FedAvg.py:7-14) is element-wise,
+ * so the RCCL all-reduce of main.py:218's aggregation runs on this buffer in
+ * place; *numel is its length.  Valid until fm_destroy. */
+int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel);
+/* state *= w  (the n_i / sum(n) pre-scale before the all-reduce SUM). */
+int fm_state_scale(fm_engine* e, float w);
+/* glob_model = deepcopy(net) at round start (utils/local_training.py:909, 1017):
+ * snapshot the current state as the frozen eval-mode teacher. */
+int fm_teacher_snapshot(fm_engine* e);
+/* A fresh torch.optim.Adam every round (utils/local_training.py:912-913):
+ * zero both moments and the step count. */
+int fm_adam_reset(fm_engine* e, const fm_adam* hp);
+
+/* ---- net(x) in eval mode: -> (feature[B,D], logits[B,C]) ----------------- */
+/* utils/local_training.py:983, 1030, 1227 (student) / :944-947 (teacher).
+ * use_teacher != 0 runs the snapshot taken by fm_teacher_snapshot. */
+int fm_forward_eval(fm_engine* e, const float* x_dev, int32_t B, int32_t use_teacher,
+                    float* feat_dev, float* logits_dev);
+
+/* ---- training steps: forward + loss + backward + Adam.step --------------- */
+/* Every step writes its scalar loss to *loss_dev (a device float the caller
+ * reads back once per round instead of loss.item() every step) and bumps the
+ * BN counters like a train-mode forward does.  bs_norm is args.batch_size: the
+ * reference normalises by it, not by the actual batch length B. */
+
+/* LocalUpdate.train (utils/local_training.py:628-703):
+ * sum(BCEWithLogits(pos_weight)(z, y)) / (bs_norm * C). pos_weight: host[C]. */
+int fm_step_bce(fm_engine* e, const float* x_dev, const float* y_dev, int32_t B,
+                const float* pos_weight_host, int32_t bs_norm, float* loss_dev);
+
+/* train_FedMLP stage 1 (utils/local_training.py:920-967): two views, frozen
+ * teacher, BCE on the active classes + MSE-to-teacher on the missing classes.
+ * active_mask: host[C] of 0/1 (1 = class annotated by this client). */
+int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const float* y_dev,
+                   int32_t B, const float* active_mask_host, int32_t annotation_num,
+                   int32_t bs_norm, float* loss_dev);
+
+/* train_FedMLP stage 2 (utils/local_training.py:1171-1192): masked BCE,
+ * sup_cls = 1 - distill_cls (device [B,C]).  The reference's teacher forward
+ * there is dead code and is not executed. */
+int fm_step_stage2(fm_engine* e, const float* x_dev, const float* y_dev,
+                   const float* distill_dev, int32_t B, float* loss_dev);
+
+/* train_FixMatch (utils/local_training.py:789-818): weak/strong consistency.
+ * pos_weight / pos_weight_unknown: host[C]. */
+int fm_step_fixmatch(fm_engine* e, const float* xw_dev, const float* xs_dev, const float* y_dev,
+                     int32_t B, const float* pos_weight_host, const float* pos_weight_unk_host,
+                     const float* active_mask_host, int32_t annotation_num, int32_t bs_norm,
+                     float* loss_dev);
+
+/* ---- prototype + t pass (utils/local_training.py:971-1002, 1208-1250) ---- */
+/* Accumulators live in the engine: proto sums [2C,D], counts [2C], t counts [C]. */
+int fm_proto_reset(fm_engine* e);
+/* One eval batch: feature[B,D], logits[B,C], labels[B,C] on device.
+ * active_mask / negative_mask: host[C] 0/1 (classes for prototypes / for t). */
+int fm_proto_accumulate(fm_engine* e, const float* feat_dev, const float* logits_dev,
+                        const float* labels_dev, int32_t B, const float* active_mask_host,
+                        const float* negative_mask_host, float L, float U);
+/* proto rows /= counts (zero_guard: leave a row with count 0 as is, the stage-2
+ * variant :1240-1248; otherwise 0/0 = NaN like :997-999), t = counts / n_local.
+ * Outputs on host: proto[2C*D] fp32, t[C] f64. */
+int fm_proto_finalize(fm_engine* e, int32_t zero_guard, int64_t n_local,
+                      const float* active_mask_host, float* proto_host, double* t_host);
+
+/* ---- cosine tagging (CosineSimilarityFast, utils/local_training.py:1417-1435,
+ *      call site :1052-1057) ------------------------------------------------ */
+/* sim[k][n] = cos(f[n], P[2c_k]) - cos(f[n], P[2c_k+1]) for the n_cls classes
+ * listed in classes_host.  feat_dev [N,D], proto_dev [2C,D], sim_dev [n_cls,N]. */
+int fm_cos_tag(fm_engine* e, const float* feat_dev, int64_t N, const float* proto_dev,
+               const int32_t* classes_host, int32_t n_cls, float* sim_dev);
+/* Stable top-/bottom-k positions of one similarity row (utils/utils.py:24-35 via
+ * utils/local_training.py:1061-1075): n_clean = #(sim>=0), n_noise = #(sim<0),
+ * k_top = (int)(clean_thr*n_clean), k_bot = (int)(noise_thr*n_noise); writes the
+ * positions of the k_top largest (descending, first position wins ties) and the
+ * k_bot smallest (ascending) values to host arrays of capacity cap. */
+int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_thr,
+                   double noise_thr, int32_t cap, int32_t* top_host, int32_t* n_top,
+                   int32_t* bot_host, int32_t* n_bot);
+
+/* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
+/* When enabled, HIP events bracket every convolution GEMM launch on the
+ * engine's stream; fm_profile_read drains them (synchronises) and returns, per
+ * kernel family (0 = conv fwd/dgrad implicit GEMM, 1 = conv wgrad GEMM,
+ * 2 = everything else timed as whole-step remainder is not reported), the
+ * launch count, total milliseconds and algorithmic FLOPs since the last read. */
+int fm_profile_enable(fm_engine* e, int32_t on);
+int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops);
+
+/* ---- kernel-level test hooks (tests/ only; not part of the drop-in surface) -- */
+/* info[0..11] = cin, cout, k, stride, pad, hin, win, hout, wout, cin_p (padded
+ * input channels of the NHWC operand), Kw (row length of the engine-layout
+ * weight matrix [cout][Kw] = [cout][k][kw_p][cin_p]), kw_p. */
+int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info12);
+int fm_debug_num_convs(fm_engine* e);
+/* op 0: raw forward  x[imgs,hin,win,cin_p] -> out[imgs,hout,wout,cout]; if stats_dev
+ *       != NULL also the per-group per-channel (sum, sumsq) [groups][2][cout]
+ * op 1: data gradient dy[imgs,hout,wout,cout] -> out[imgs,hin,win,cin]
+ * op 2: weight gradient (x, dy) -> out[cout][Kw] (engine layout)
+ * All tensors NHWC fp32 on device; weights are the engine's current state. */
+int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, const float* dy_dev,
+                  float* out_dev, int32_t imgs, int32_t groups, float* stats_dev);
+
+/* Gradients of the last step in state_dict order (running-stat slots are 0). */
+int fm_debug_get_grads(fm_engine* e, float* host_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEDMLP_HIP_H */

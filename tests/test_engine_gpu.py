@@ -1,0 +1,183 @@
+"""Engine-level parity on a real MI355X through the C ABI: eval forward, and one
+training step of each variant (loss, gradients, post-Adam state) against the CPU
+oracle on the same seeded inputs."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from fedmlp_amd import spec
+from oracle import steps_ref as R
+from tests.helpers import oracle_net
+
+pytestmark = pytest.mark.gpu
+
+C_, HW = 5, 64
+LR = 3e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fedmlp_amd.engine import Engine
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    yield e
+    e.close()
+
+
+def _load(e, seed=1037):
+    flat, cnt = spec.init_state("Resnet18", C_, seed)
+    e.set_state(flat, cnt)
+    e.adam_reset(LR)
+    return oracle_net(C_, seed)
+
+
+def _data(B, seed, views=1):
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn((B, 3, HW, HW), generator=g) for _ in range(views)]
+    y = (torch.rand((B, C_), generator=g) < 0.3).float()
+    return xs, y
+
+
+def _grads_sd(e):
+    flat = e.debug_get_grads()
+    return spec.flat_to_state_dict("Resnet18", C_, flat, np.zeros(e.ni, np.int64))
+
+
+def _cmp_grads(e, net, rtol=2e-3):
+    gsd = _grads_sd(e)
+    for k, p in net.named_parameters():
+        want = p.grad.numpy()
+        got = gsd[k]
+        scale = np.abs(want).max() + 1e-12
+        err = np.abs(got - want).max() / scale
+        assert err < rtol, f"grad {k}: rel-to-max err {err:.3e}"
+
+
+def _cmp_state(e, net, atol_w):
+    flat, cnt = e.get_state()
+    sd = spec.flat_to_state_dict("Resnet18", C_, flat, cnt)
+    for k, v in net.state_dict().items():
+        want = v.numpy()
+        if "num_batches" in k:
+            assert int(sd[k]) == int(want), k
+            continue
+        tol = atol_w if ("running" not in k) else 1e-5 * (np.abs(want).max() + 1.0)
+        np.testing.assert_allclose(sd[k], want, rtol=1e-4, atol=tol, err_msg=k)
+
+
+def test_forward_eval(eng):
+    net = _load(eng)
+    (x,), _ = _data(5, 1)
+    net.eval()
+    with torch.no_grad():
+        f, z = net(x)
+    fe, ze = eng.forward_eval(x.cuda())
+    np.testing.assert_allclose(fe.cpu().numpy(), f.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ze.cpu().numpy(), z.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_step_bce(eng):
+    net = _load(eng)
+    (x,), y = _data(6, 2)
+    pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x)
+    loss = R.loss_train(z, y, pw, 8, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
+    assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+    _cmp_state(eng, net, atol_w=2.5 * LR)
+
+
+def test_step_stage1(eng):
+    net = _load(eng)
+    (x1, x2), y = _data(6, 3, views=2)
+    act, neg = [1], [0, 2, 3, 4]
+    glob = copy.deepcopy(net).eval()
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z1 = net(x1); _, z2 = net(x2)
+    with torch.no_grad():
+        _, g1 = glob(x1); _, g2 = glob(x2)
+    loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
+    opt.zero_grad(); loss.backward(); opt.step()
+    eng.teacher_snapshot()
+    lo = torch.zeros(1, device="cuda")
+    mask = [1.0 if c in act else 0.0 for c in range(C_)]
+    eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+    assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+    _cmp_state(eng, net, atol_w=2.5 * LR)
+
+
+def test_step_stage2(eng):
+    net = _load(eng)
+    (x,), y = _data(7, 4)
+    g = torch.Generator().manual_seed(44)
+    dist = (torch.rand((7, C_), generator=g) < 0.4).float()
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x)
+    loss = R.loss_stage2(z, y, dist)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.step_stage2(x.cuda(), y.cuda(), dist.cuda(), lo)
+    assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+    _cmp_state(eng, net, atol_w=2.5 * LR)
+
+
+def test_step_fixmatch(eng):
+    flat, cnt = spec.init_state("Resnet18", C_, 1037)
+    sd = spec.flat_to_state_dict("Resnet18", C_, flat, cnt)
+    sd["fc.weight"] = sd["fc.weight"] * 40.0        # saturate some probabilities -> confident rows
+    flat, cnt = spec.state_dict_to_flat("Resnet18", C_, sd)
+    eng.set_state(flat, cnt)
+    eng.adam_reset(LR)
+    net = oracle_net(C_, 1037)
+    with torch.no_grad():
+        net.fc.weight.mul_(40.0)
+    (xw, xs), y = _data(8, 5, views=2)
+    act, neg = [0], [1, 2, 3, 4]
+    pw, pwu = [3.0, 1.5, 4.0, 2.0, 2.5], [3.3, 1, 1, 1, 1]
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, zw = net(xw); _, zs = net(xs)
+    assert len(R.fixmatch_mask(zw, neg, 8)) > 0, "test needs at least one confident row"
+    loss = R.loss_fixmatch(zw, zs, y, pw, pwu, act, neg, 8, 1, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    mask = [1.0 if c in act else 0.0 for c in range(C_)]
+    eng.step_fixmatch(xw.cuda(), xs.cuda(), y.cuda(), pw, pwu, mask, 1, 8, lo)
+    assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+
+
+def test_multi_step_trajectory(eng):
+    """10 Adam steps of the plain BCE loop: loss curve and weight norms vs the oracle."""
+    net = _load(eng)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+    lo = torch.zeros(10, device="cuda")
+    want = []
+    for s in range(10):
+        (x,), y = _data(8, 100 + s)
+        _, z = net(x)
+        loss = R.loss_train(z, y, pw, 8, C_)
+        opt.zero_grad(); loss.backward(); opt.step()
+        want.append(loss.item())
+        eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo[s:s + 1])
+    np.testing.assert_allclose(lo.cpu().numpy(), np.array(want), rtol=1e-4)
+    flat, cnt = eng.get_state()
+    sd = spec.flat_to_state_dict("Resnet18", C_, flat, cnt)
+    for k, v in net.state_dict().items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v)
+            continue
+        a, b = np.linalg.norm(sd[k].astype(np.float64)), float(torch.linalg.vector_norm(v.double()))
+        assert abs(a - b) <= 1e-3 * b + 1e-7, (k, a, b)

@@ -1,0 +1,127 @@
+"""Kernel-level parity on a real MI355X: each HIP convolution GEMM (forward,
+data gradient, weight gradient, BN-statistics epilogue) against torch CPU fp32
+ops on the same seeded inputs, called through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fedmlp_amd import spec
+
+pytestmark = pytest.mark.gpu
+
+
+def conv_names():
+    names = ["conv1"]
+    cin = 64
+    for li, w in enumerate((64, 128, 256, 512), start=1):
+        for b in range(2):
+            p = f"layer{li}.{b}"
+            stride = 2 if (li > 1 and b == 0) else 1
+            names += [p + ".conv1", p + ".conv2"]
+            if stride != 1 or cin != w:
+                names.append(p + ".downsample.0")
+            cin = w
+    return names
+
+
+@pytest.fixture(scope="module")
+def eng64():
+    from fedmlp_amd.engine import Engine
+    e = Engine("Resnet18", 5, 64, 64, 8)
+    flat, cnt = spec.init_state("Resnet18", 5, 1037)
+    e.set_state(flat, cnt)
+    yield e, spec.flat_to_state_dict("Resnet18", 5, flat, cnt)
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng224():
+    from fedmlp_amd.engine import Engine
+    e = Engine("Resnet18", 5, 224, 224, 4)
+    flat, cnt = spec.init_state("Resnet18", 5, 7)
+    e.set_state(flat, cnt)
+    yield e, spec.flat_to_state_dict("Resnet18", 5, flat, cnt)
+    e.close()
+
+
+def _nhwc(x_nchw, cpad):
+    x = x_nchw.permute(0, 2, 3, 1).contiguous()
+    if cpad > x.shape[3]:
+        x = F.pad(x, (0, cpad - x.shape[3]))
+    return x.contiguous()
+
+
+def _check_conv(e, sd, ci, imgs, groups, seed):
+    info = e.debug_conv_info(ci)
+    name = conv_names()[ci]
+    w = torch.from_numpy(sd[name + ".weight"])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((imgs, info["cin"], info["hin"], info["win"]), generator=g)
+    dy = torch.randn((imgs, info["cout"], info["hout"], info["wout"]), generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, info["stride"], info["pad"])
+    y.backward(dy)
+    dev = e.device
+    x_d = _nhwc(x, info["cin_p"]).to(dev)
+    dy_d = _nhwc(dy, info["cout"]).to(dev)
+    # forward + BN partial statistics
+    out = torch.empty((imgs, info["hout"], info["wout"], info["cout"]), device=dev)
+    stats = torch.empty((groups, 2, info["cout"]), device=dev)
+    e.debug_conv(0, ci, x_d, None, out, imgs, groups, stats)
+    got = out.cpu().permute(0, 3, 1, 2)
+    scale = y.detach().abs().max().item()
+    np.testing.assert_allclose(got.numpy(), y.detach().numpy(), rtol=1e-4, atol=2e-5 * scale,
+                               err_msg=f"fwd {name}")
+    yg = y.detach().reshape(groups, imgs // groups, info["cout"], -1)
+    s1 = yg.sum(dim=(1, 3)); s2 = (yg * yg).sum(dim=(1, 3))
+    st = stats.cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), s1.numpy(), rtol=1e-3, atol=1e-3 * s2.sqrt().max().item())
+    np.testing.assert_allclose(st[:, 1].numpy(), s2.numpy(), rtol=1e-4)
+    # weight gradient (engine layout [cout][k][kw_p][cin_p])
+    dw = torch.empty((info["cout"], info["Kw"]), device=dev)
+    e.debug_conv(2, ci, x_d, dy_d, dw, imgs)
+    want = wr.grad.permute(0, 2, 3, 1)                               # O,H,W,I
+    want = F.pad(want, (0, info["cin_p"] - info["cin"], 0, info["kw_p"] - info["k"]))
+    want = want.reshape(info["cout"], -1)
+    scale = want.abs().max().item()
+    np.testing.assert_allclose(dw.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5 * scale,
+                               err_msg=f"wgrad {name}")
+    # data gradient (not needed for the stem)
+    if ci > 0:
+        dx = torch.full((imgs, info["hin"], info["win"], info["cin"]), float("nan"), device=dev)
+        e.debug_conv(1, ci, None, dy_d, dx, imgs)
+        got = dx.cpu().permute(0, 3, 1, 2)
+        want = xr.grad
+        if info["k"] == 1 and info["stride"] == 2:
+            # only parity class (0,0) is written by the 1x1 stride-2 dgrad; the block's 3x3
+            # conv writes the rest (engine.hip backward_and_step)
+            got, want = got[:, :, ::2, ::2], want[:, :, ::2, ::2]
+        scale = want.abs().max().item()
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * scale,
+                                   err_msg=f"dgrad {name}")
+
+
+@pytest.mark.parametrize("ci", list(range(20)))
+def test_conv_all_layers_64(eng64, ci):
+    e, sd = eng64
+    _check_conv(e, sd, ci, imgs=6, groups=2, seed=100 + ci)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 5, 7, 10, 12, 15, 17, 19])
+def test_conv_layers_224(eng224, ci):
+    e, sd = eng224
+    _check_conv(e, sd, ci, imgs=3, groups=1, seed=200 + ci)
+
+
+def test_state_roundtrip(eng64):
+    e, sd = eng64
+    flat, cnt = spec.init_state("Resnet18", 5, 99)
+    cnt[:] = np.arange(len(cnt))
+    e.set_state(flat, cnt)
+    f2, c2 = e.get_state()
+    np.testing.assert_array_equal(f2, flat)
+    np.testing.assert_array_equal(c2, cnt)
+    flat0, cnt0 = spec.init_state("Resnet18", 5, 1037)
+    e.set_state(flat0, cnt0)
