@@ -39,6 +39,7 @@ SYMBOLS = {
     "fm_set_state": (C.c_int, [_P, _P, _P]),
     "fm_get_state": (C.c_int, [_P, _P, _P]),
     "fm_state_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "fm_counters": (C.c_int, [_P, _P, _I32]),
     "fm_state_scale": (C.c_int, [_P, C.c_float]),
     "fm_teacher_snapshot": (C.c_int, [_P]),
     "fm_adam_reset": (C.c_int, [_P, C.POINTER(FmAdam)]),

@@ -126,8 +126,8 @@ struct fm_engine {
     bool prof = false;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ev_free;
-    double prof_ms[2] = {0, 0}, prof_flops[2] = {0, 0};
-    int64_t prof_n[2] = {0, 0};
+    double prof_ms[4] = {0, 0, 0, 0}, prof_flops[4] = {0, 0, 0, 0};
+    int64_t prof_n[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
 };
 
@@ -366,7 +366,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     const int bn = igemm_tile_n(c.cout);
     p.tilesN = (p.imgs_per_group * c.hout * c.wout + bn - 1) / bn;
     p.relu = relu;
-    ProfScope ps(e, 0, 2.0 * c.macs_per_img * imgs);
+    ProfScope ps(e, c.cout >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs);
     launch_igemm(p, groups, e->st);
 }
 
@@ -401,7 +401,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         const int bn = igemm_tile_n(c.cin);
         p.tilesN = (imgs * p.Hg * p.Wg + bn - 1) / bn;
         p.relu = 0;
-        ProfScope ps(e, 0, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
+        ProfScope ps(e, c.cin >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
         launch_igemm(p, 1, e->st);
     }
 }
@@ -425,7 +425,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     p.pix_per_split = (((p.npix + splits - 1) / splits) + 31) & ~31;
     splits = (p.npix + p.pix_per_split - 1) / p.pix_per_split;
     {
-        ProfScope ps(e, 1, 2.0 * c.macs_per_img * imgs);
+        ProfScope ps(e, c.cout >= 128 ? 2 : 3, 2.0 * c.macs_per_img * imgs);
         launch_wgrad(p, splits, e->st);
     }
     k_reduce_slabs(e->ws_slab, e->grad + c.w_off, splits, (int64_t)c.w_numel, e->st);
@@ -687,6 +687,19 @@ int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel)
     return FM_OK;
 }
 
+int fm_counters(fm_engine* e, int64_t* host_i64, int32_t set)
+{
+    ARGCHK(e && host_i64, "null");
+    int ic = 0;
+    for (auto& en : e->entries)
+        if (en.kind == 2) {
+            if (set) e->counters[en.bn] = host_i64[ic];
+            else host_i64[ic] = e->counters[en.bn];
+            ++ic;
+        }
+    return FM_OK;
+}
+
 int fm_state_scale(fm_engine* e, float w)
 {
     ARGCHK(e, "null engine");
@@ -885,7 +898,7 @@ int fm_profile_enable(fm_engine* e, int32_t on)
 
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops)
 {
-    ARGCHK(e && family >= 0 && family < 2, "family");
+    ARGCHK(e && family >= 0 && family < 4, "family");
     HIPCHK(hipStreamSynchronize(e->st));
     for (auto& p : e->evs) {
         float t = 0.f;

@@ -77,6 +77,11 @@ class Engine:
         _lib.check(self.lib.fm_state_device(self.h, C.byref(p), C.byref(n)))
         return _device_view(p.value, n.value, self.device)
 
+    def counters(self, new=None):
+        c = np.zeros(self.ni, np.int64) if new is None else np.ascontiguousarray(new, dtype=np.int64)
+        _lib.check(self.lib.fm_counters(self.h, c.ctypes.data_as(C.c_void_p), int(new is not None)))
+        return c
+
     def state_scale(self, w):
         _lib.check(self.lib.fm_state_scale(self.h, C.c_float(w)))
 

@@ -1,0 +1,132 @@
+"""Aggregation: the reference's utils/FedAvg.py surface + its RCCL form.
+
+Two forms of the same arithmetic:
+  * FedAvg / FedAvg_tao / FedAvg_proto -- drop-ins with the reference signatures
+    (utils/FedAvg.py:7-14, 51-70, 72-93) for a single-process driver that holds
+    every client's state_dict on the host, as main.py:216-234 does.  Host glue:
+    left-to-right weighted mean, same order as the reference.
+  * fedavg_allreduce / tao_allreduce / proto_allreduce -- one client per GPU:
+    each rank pre-scales its device-resident state by n_i/sum(n) (HIP kernel) and
+    the sum is an RCCL all-reduce over xGMI (torch.distributed backend "nccl");
+    on CPU test rigs the same code runs over gloo tensors.
+"""
+import copy
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+
+def FedAvg(w, dict_len):
+    """utils/FedAvg.py:7-14: sample-count weighted mean of EVERY state_dict entry,
+    accumulated left to right in the entry's dtype; the int64 counter becomes
+    float through the true division (and is truncated again on load)."""
+    out = OrderedDict()
+    for k in w[0].keys():
+        acc = _np(w[0][k]) * dict_len[0]
+        for i in range(1, len(w)):
+            acc = acc + _np(w[i][k]) * dict_len[i]
+        if np.issubdtype(acc.dtype, np.integer):
+            acc = (acc / float(sum(dict_len))).astype(np.float32)
+        else:
+            acc = (acc / np.float32(sum(dict_len))).astype(np.float32)
+        out[k] = torch.from_numpy(np.ascontiguousarray(acc))
+    return out
+
+
+def FedAvg_tao(t, weight, class_active_client_list=None):
+    """utils/FedAvg.py:51-70."""
+    C = len(t[0])
+    out = np.array([0.] * C)
+    if class_active_client_list is None:
+        for i, tao in enumerate(t):
+            out += np.asarray(tao) * float(weight[i])
+        return out / float(sum(weight))
+    for cls, clients in enumerate(class_active_client_list):
+        if len(clients) == 0:
+            out[cls] = 1.
+            continue
+        wsum = 0.
+        for i, tao in enumerate(t):
+            if i in clients:
+                out[cls] += tao[cls] * float(weight[i])
+                wsum += float(weight[i])
+        out[cls] = out[cls] / wsum
+    return out
+
+
+def FedAvg_proto(Prototypes, weight, class_active_client_list):
+    """utils/FedAvg.py:72-93 (a class with no active client yields NaN rows)."""
+    P = [torch.as_tensor(_np(p)) for p in Prototypes]
+    out = torch.zeros((len(P[0]), len(P[0][0])))
+    for cls, clients in enumerate(class_active_client_list):
+        a0 = torch.zeros_like(P[0][0])
+        a1 = torch.zeros_like(P[0][0])
+        for cid in clients:
+            a0 = P[cid][2 * cls] * weight[cid] + a0
+            a1 = P[cid][2 * cls + 1] * weight[cid] + a1
+        den = np.sum(np.array(weight)[clients])
+        out[2 * cls] = a0 / den
+        out[2 * cls + 1] = a1 / den
+    return out
+
+
+# ---- one client per GPU: RCCL --------------------------------------------------------
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def allreduce_weighted_(tensor, w):
+    """tensor <- sum_ranks(w_rank * tensor_rank), in place (tensor on any device)."""
+    tensor.mul_(w)
+    d = _dist()
+    if d is not None and d.get_world_size() > 1:
+        d.all_reduce(tensor, op=d.ReduceOp.SUM)
+    return tensor
+
+
+def fedavg_allreduce(engine, w):
+    """FedAvg of the device-resident model over all ranks: state <- sum_i w_i state_i with
+    w_i = n_i / sum(n).  The pre-scale is the engine's HIP kernel, the sum is RCCL."""
+    d = _dist()
+    engine.state_scale(float(w))
+    st = engine.state_tensor()
+    if d is not None and d.get_world_size() > 1:
+        d.all_reduce(st, op=d.ReduceOp.SUM)
+        cnt = torch.from_numpy(engine.counters().astype(np.float64) * float(w)).to(st.device)
+        d.all_reduce(cnt, op=d.ReduceOp.SUM)
+        engine.counters(np.trunc(cnt.cpu().numpy() + 1e-9).astype(np.int64))
+    return st
+
+
+def tao_allreduce(t, n_i, is_negative_client_mask, device="cpu"):
+    """FedAvg_tao over ranks: t[C] local, mask[c] = 1 if this client has class c missing
+    (it is in class_negative_client_list[c], main.py:206-210, 223)."""
+    m = np.asarray(is_negative_client_mask, dtype=np.float64)
+    buf = torch.from_numpy(np.concatenate([np.asarray(t, np.float64) * n_i * m, n_i * m])).to(device)
+    d = _dist()
+    if d is not None and d.get_world_size() > 1:
+        d.all_reduce(buf, op=d.ReduceOp.SUM)
+    buf = buf.cpu().numpy()
+    C = len(m)
+    num, den = buf[:C], buf[C:]
+    return np.where(den == 0, 1.0, num / np.where(den == 0, 1.0, den))
+
+
+def proto_allreduce(proto, n_i, is_active_client_mask, device="cpu"):
+    """FedAvg_proto over ranks: proto[2C,D] local, mask[c] = 1 if this client annotates c."""
+    m = np.repeat(np.asarray(is_active_client_mask, dtype=np.float32), 2)[:, None]
+    P = np.asarray(_np(proto), dtype=np.float32) * np.float32(n_i)     # NaN rows of an active class propagate
+    num = torch.from_numpy(np.where(m > 0, P, 0.0).astype(np.float32)).to(device)
+    den = torch.from_numpy((np.float32(n_i) * m[:, 0]).astype(np.float32)).to(device)
+    d = _dist()
+    if d is not None and d.get_world_size() > 1:
+        d.all_reduce(num, op=d.ReduceOp.SUM)
+        d.all_reduce(den, op=d.ReduceOp.SUM)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return torch.from_numpy(num.cpu().numpy() / den.cpu().numpy()[:, None])   # 0/0 -> NaN

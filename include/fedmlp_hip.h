@@ -75,6 +75,10 @@ int fm_get_state(fm_engine* e, float* host_f32, int64_t* host_i64);
  * so the RCCL all-reduce of main.py:218's aggregation runs on this buffer in
  * place; *numel is its length.  Valid until fm_destroy. */
 int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel);
+/* num_batches_tracked counters (state_dict order): read (set == 0) or overwrite.
+ * They never enter the arithmetic (momentum is fixed at 0.1) but FedAvg
+ * averages them like every other entry (utils/FedAvg.py:9-13). */
+int fm_counters(fm_engine* e, int64_t* host_i64, int32_t set);
 /* state *= w  (the n_i / sum(n) pre-scale before the all-reduce SUM). */
 int fm_state_scale(fm_engine* e, float w);
 /* glob_model = deepcopy(net) at round start (utils/local_training.py:909, 1017):
@@ -153,9 +157,9 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the
  * engine's stream; fm_profile_read drains them (synchronises) and returns, per
- * kernel family (0 = conv fwd/dgrad implicit GEMM, 1 = conv wgrad GEMM,
- * 2 = everything else timed as whole-step remainder is not reported), the
- * launch count, total milliseconds and algorithmic FLOPs since the last read. */
+ * kernel (family 0 = igemm_kernel<128,128,2>, 1 = igemm_kernel<64,256,4>: conv
+ * forward + data gradient; 2 = wgrad_kernel<128,128,2>, 3 = wgrad_kernel<64,256,4>),
+ * the launch count, total milliseconds and algorithmic FLOPs since the last read. */
 int fm_profile_enable(fm_engine* e, int32_t on);
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops);
 
