@@ -75,6 +75,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension is not built and fedmlp_amd has no CPU "
             "fallback. Build it with `make` (or __graft_entry__.build()).")
+    # torch bundles its own ROCm runtime; it must be the first HIP runtime in the process
+    # (loading ours first leaves two runtimes and hipMalloc reports "no ROCm-capable device")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
