@@ -9,17 +9,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Implicit-GEMM convolution (forward and data-gradient), fp32 MFMA.
 //   D[m][n] = sum_k Wp[m][k] * Xg[n][k]
 //   m: output channel, n: output pixel (per BN-statistics group), k: (tap, ci)
-// The K axis is cut in steps of 32 floats = 8 chunks of 16 B; `tab` gives, per
-// (step, chunk), where that chunk's 4 input channels come from relative to the
-// output pixel: {dh, dw, ci0, valid}.  The kernel itself knows nothing about
-// taps, strides or padding, so forward convs, the 7x7 stem (kw folded into K)
-// and the per-parity-class data gradients all run through it.
+// The K axis is (tap, channel): `ntaps` taps of `Ci` gathered channels each, cut
+// in steps of 32 floats = 8 chunks of 16 B.  Tap t reads the input pixel at
+// offset (dh[t], dw[t]) from the output pixel's base position; the tap arrays
+// sit in the kernel arguments, so the per-step tap lookup is scalar work and the
+// main loop has no dependent global load.  The kernel knows nothing else about
+// strides or padding, so forward convs and the per-parity-class data gradients
+// all run through it.  stem_kw > 0 selects the 7x7-stem form (Ci = 4): one step
+// = one kernel row, chunk j = kernel column j (valid while j < stem_kw).
 // ---------------------------------------------------------------------------
 struct IgemmParams {
     const float* W;       // packed weights [M][nsteps*32]
     const float* X;       // input activations NHWC [imgs][Hi][Wi][Ci]
     float* Y;             // output NHWC [imgs][Ho][Wo][Co]
-    const int4* tab;      // [nsteps][8]
+    int dh[9], dw[9];     // per-tap input offsets
+    int stem_kw, stem_pad;
+    const float* zeros;   // >= 16 B of zeros (source of padded / out-of-range chunks)
     const float* res;     // optional residual, indexed like Y (may alias Y)
     const float* scale;   // optional per-m affine (eval-mode BN folded), else null
     const float* shift;
@@ -40,6 +45,7 @@ struct WgradParams {
     const float* X;       // [imgs][Hi][Wi][Ci]
     float* slab;          // [splits][M][Nw]
     const int4* tab;      // [Nw/4]: {dh, dw, ci0, valid} per 4-column chunk
+    const float* zeros;   // >= 16 B of zeros
     int M, Nw;
     int Ho, Wo, Hi, Wi, Ci, stride;
     int npix;             // imgs*Ho*Wo

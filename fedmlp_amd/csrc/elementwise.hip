@@ -126,11 +126,41 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
         __syncthreads();
     }
 }
+// stage A of the statistics reduction: [groups][tiles][2C] -> [groups][32][2C], one block per
+// (chunk of tiles, group); fixed summation order, so the result is run-to-run deterministic.
+__global__ void bn_fold_tiles_kernel(const float* __restrict__ stats, float* __restrict__ out, int tiles, int C2)
+{
+    const int g = blockIdx.y, nch = gridDim.x;
+    const int per = (tiles + nch - 1) / nch;
+    const int t0 = blockIdx.x * per, t1 = min(tiles, t0 + per);
+    const float* st = stats + (size_t)g * tiles * C2;
+    for (int c = threadIdx.x; c < C2; c += blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int t = t0;
+        for (; t + 3 < t1; t += 4) {
+            a0 += st[(size_t)t * C2 + c];
+            a1 += st[(size_t)(t + 1) * C2 + c];
+            a2 += st[(size_t)(t + 2) * C2 + c];
+            a3 += st[(size_t)(t + 3) * C2 + c];
+        }
+        for (; t < t1; ++t) a0 += st[(size_t)t * C2 + c];
+        out[((size_t)g * nch + blockIdx.x) * C2 + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 void k_bn_finalize(const float* stats, int groups, int tiles, int C, int count, const float* gamma,
                    const float* beta, float* run_mean, float* run_var, float* mean, float* istd, float* scale,
                    float* shift, float eps, float momentum, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, s, stats, groups, tiles, C, count, gamma,
+    const float* src = stats;
+    if (tiles > 64) {
+        // the folded partials live right behind the per-tile partials in the same workspace
+        float* folded = const_cast<float*>(stats) + (size_t)groups * tiles * 2 * C;
+        hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3(32, groups), dim3(256), 0, s, stats, folded, tiles, 2 * C);
+        src = folded;
+        tiles = 32;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, s, src, groups, tiles, C, count, gamma,
                        beta, run_mean, run_var, mean, istd, scale, shift, eps, momentum);
 }
 
@@ -293,7 +323,7 @@ void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* i
 }
 
 // ------------------------------------------------------------ BN backward ------
-int bn_bwd_blocks(int pix_per_group) { return max(1, min(512, cdiv(pix_per_group, 64))); }
+int bn_bwd_blocks(int pix_per_group) { return max(1, min(256, cdiv(pix_per_group, 64))); }
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                      const float* __restrict__ y, const float* __restrict__ mean,
@@ -461,17 +491,33 @@ void k_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, f
                        eps, wd, bc1, bc2_sqrt);
 }
 
+// out[i] = sum_s slab[s][i]; block = 64 float4 columns x 16 split lanes, lanes combined through
+// LDS in a fixed order (deterministic), so a long split axis does not serialise on one thread.
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, int64_t n4)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 a = reinterpret_cast<const f32x4*>(slab)[i];
-        for (int s = 1; s < splits; ++s) a += reinterpret_cast<const f32x4*>(slab)[(int64_t)s * n4 + i];
-        reinterpret_cast<f32x4*>(out)[i] = a;
+    __shared__ f32x4 red[16][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int s = sl;
+        for (; s + 16 < splits; s += 32) {
+            a += reinterpret_cast<const f32x4*>(slab)[(int64_t)s * n4 + i];
+            b += reinterpret_cast<const f32x4*>(slab)[(int64_t)(s + 16) * n4 + i];
+        }
+        if (s < splits) a += reinterpret_cast<const f32x4*>(slab)[(int64_t)s * n4 + i];
+    }
+    red[sl][col] = a + b;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+        f32x4 r = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) r += red[k][col];
+        reinterpret_cast<f32x4*>(out)[i] = r;
     }
 }
 void k_reduce_slabs(const float* slab, float* out, int splits, int64_t n, hipStream_t s)
 {
     const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(min(2048, cdiv(n4, 256))), dim3(256), 0, s, slab, out, splits, n4);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(cdiv(n4, 64)), dim3(1024), 0, s, slab, out, splits, n4);
 }

@@ -46,7 +46,6 @@ struct DgradClass {
     int dh[9], dw[9];
     int ph, pw;
     int nsteps;
-    int4* tab = nullptr;
     float* wpack = nullptr;
 };
 
@@ -120,6 +119,7 @@ struct fm_engine {
     // prototypes
     float* psum = nullptr;
     int64_t *pcnt = nullptr, *tcnt = nullptr;
+    float* zeros = nullptr;
     int *sel_counts = nullptr, *sel_top = nullptr, *sel_bot = nullptr, *cls_dev = nullptr;
     int sel_cap = 0;
     // profiling
@@ -208,13 +208,6 @@ int build_tables(fm_engine* e)
                 if (d.taps.n == 0) continue;
                 const int K = d.taps.n * c.cout;
                 d.nsteps = K / 32;
-                std::vector<int4> dt(K / 4);
-                for (int q = 0; q < K / 4; ++q) {
-                    const int kk = 4 * q, j = kk / c.cout, co0 = kk % c.cout;
-                    dt[q] = make_int4(d.dh[j], d.dw[j], co0, 1);
-                }
-                rc = upload_tab(e, dt, &d.tab);
-                if (rc) return rc;
                 DALLOC(d.wpack, (size_t)c.cin * K);
                 c.cls[c.ncls++] = d;
             }
@@ -302,7 +295,7 @@ int alloc_workspaces(fm_engine* e)
     for (auto& c : e->convs) {
         DALLOC(c.y, B * c.hout * c.wout * c.cout);
         const size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout) - 1) / igemm_tile_n(c.cout) + 2;
-        max_stats = std::max(max_stats, tiles * 2 * c.cout);
+        max_stats = std::max(max_stats, (tiles + 2 * 32) * 2 * c.cout);   // + folded partials
         max_slab = std::max(max_slab, c.w_numel);
     }
     for (auto& b : e->bns) {
@@ -319,7 +312,7 @@ int alloc_workspaces(fm_engine* e)
     }
     DALLOC(e->GA, pooled); DALLOC(e->GB, pooled); DALLOC(e->GC, pooled); DALLOC(e->GD, pooled); DALLOC(e->GE, pooled);
     DALLOC(e->ws_stats, max_stats);
-    DALLOC(e->ws_part, (size_t)2 * 512 * 2 * 512);
+    DALLOC(e->ws_part, (size_t)2 * 256 * 2 * 512);
     e->slab_floats = std::max<size_t>(max_slab * 8, (size_t)48 << 20);   // >= 192 MB of partial slabs
     DALLOC(e->ws_slab, e->slab_floats);
     DALLOC(e->ca, 2 * 512); DALLOC(e->cb, 2 * 512); DALLOC(e->cc, 2 * 512);
@@ -327,6 +320,8 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->logits, B * e->C); DALLOC(e->tlogits, B * e->C); DALLOC(e->dlogits, B * e->C);
     DALLOC(e->psum, (size_t)2 * e->C * 512); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
     DALLOC(e->sel_counts, 2); DALLOC(e->cls_dev, FM_MAX_CLASSES);
+    DALLOC(e->zeros, 64);
+    HIPCHK(hipMemset(e->zeros, 0, 64 * 4));
     return FM_OK;
 }
 
@@ -354,7 +349,10 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
 {
     const Conv& c = e->convs[ci];
     IgemmParams p{};
-    p.W = S + c.w_off; p.X = x; p.Y = y; p.tab = c.tab;
+    p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros;
+    if (c.cin == 3) { p.stem_kw = c.k; p.stem_pad = c.pad; }
+    else
+        for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
     p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
     p.M = c.cout; p.nsteps = c.nsteps;
     p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
@@ -387,7 +385,8 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         DgradClass& d = c.cls[k];
         k_pack_dgrad(S + c.w_off, d.wpack, c.cout, c.k * c.k, c.cin, d.taps, e->st);
         IgemmParams p{};
-        p.W = d.wpack; p.X = dy; p.Y = dx; p.tab = d.tab;
+        p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros;
+        for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
         p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
         p.M = c.cin; p.nsteps = d.nsteps;
         p.Hi = c.hout; p.Wi = c.wout; p.Ci = c.cout;
@@ -410,7 +409,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
 {
     const Conv& c = e->convs[ci];
     WgradParams p{};
-    p.dY = dy; p.X = x; p.slab = e->ws_slab; p.tab = c.tab;
+    p.dY = dy; p.X = x; p.slab = e->ws_slab; p.tab = c.tab; p.zeros = e->zeros;
     p.M = c.cout; p.Nw = c.Kw;
     p.Ho = c.hout; p.Wo = c.wout; p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p; p.stride = c.stride;
     p.npix = imgs * c.hout * c.wout;

@@ -79,14 +79,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
         for (int q = 0; q < RA; ++q)
             ra[q] = *reinterpret_cast<const f32x4*>(wrow + (size_t)q * 32 * Ktot + s * 32);
-        const int4 e = p.tab[s * 8 + lc];
+        // where this step's chunk comes from: scalar tap lookup (kernel arguments), or for
+        // the stem one kernel row per step and one kernel column per chunk
+        int dh, dw, c0;
+        bool cv = true;
+        if (p.stem_kw) {
+            dh = s - p.stem_pad; dw = lc - p.stem_pad; c0 = 0; cv = lc < p.stem_kw;
+        } else {
+            const int k0 = s * 32;
+            const int t = k0 / p.Ci;
+            dh = p.dh[t]; dw = p.dw[t]; c0 = k0 - t * p.Ci + lc * 4;
+        }
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
-            const int ih = ih0[q] + e.x, iw = iw0[q] + e.y;
-            const bool ok = rv[q] && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(xb[q] + (ih * p.Wi + iw) * p.Ci + e.z));
-            rb[q] = v;
+            const int ih = ih0[q] + dh, iw = iw0[q] + dw;
+            const bool ok = rv[q] && cv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            // branch-free padding: out-of-image taps read a 16-B block of zeros, so no select
+            // ever touches the loaded data (a select would drag the vmcnt wait ahead of the MFMAs)
+            const float* src = ok ? p.X + (size_t)(xb[q] + (ih * p.Wi + iw) * p.Ci + c0) : p.zeros;
+            rb[q] = *reinterpret_cast<const f32x4*>(src);
         }
     };
     auto lstore = [&](int buf) {

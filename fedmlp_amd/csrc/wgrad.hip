@@ -49,30 +49,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
     if (gc < (p.Nw >> 2)) e = p.tab[gc];
 
     f32x4 ra[NA], rb[NB];
+    // Pixel -> (image, oh, ow) of every B row this thread stages: decoded once by division,
+    // then advanced by 32 pixels per step with carries only (32 = d_img*HWo + dq*Wo + dr).
+    int r_img[NB], r_oh[NB], r_ow[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int pix = pbeg + rb0 + RPB * q;
+        r_img[q] = pix / HWo;
+        const int rem = pix - r_img[q] * HWo;
+        r_oh[q] = rem / p.Wo;
+        r_ow[q] = rem - r_oh[q] * p.Wo;
+    }
+    const int d_img = 32 / HWo, rem32 = 32 - d_img * HWo;
+    const int dq = rem32 / p.Wo, dr = rem32 - dq * p.Wo;
+    // Out-of-range pixels / padded taps read a 16-B block of zeros: no select on loaded data.
+    // gload(s) must be called for s = 0, 1, 2, ... in order (it advances the row state).
     auto gload = [&](int s) {
         const int pb = pbeg + s * 32;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int pix = pb + ra0 + RPA * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pix < pend) v = *reinterpret_cast<const f32x4*>(p.dY + (size_t)pix * p.M + m0 + 4 * ca);
-            ra[q] = v;
+            const float* src = pix < pend ? p.dY + (size_t)pix * p.M + m0 + 4 * ca : p.zeros;
+            ra[q] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int pix = pb + rb0 + RPB * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pix < pend && e.w) {
-                const int img = pix / HWo;
-                const int rem = pix - img * HWo;
-                const int oh = rem / p.Wo;
-                const int ow = rem - oh * p.Wo;
-                const int ih = oh * p.stride + e.x, iw = ow * p.stride + e.y;
-                if ((unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-                    v = *reinterpret_cast<const f32x4*>(
-                        p.X + ((size_t)(img * p.Hi + ih) * p.Wi + iw) * p.Ci + e.z);
-            }
-            rb[q] = v;
+            const int ih = r_oh[q] * p.stride + e.x, iw = r_ow[q] * p.stride + e.y;
+            const bool ok = pix < pend && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            const float* src = ok ? p.X + ((size_t)(r_img[q] * p.Hi + ih) * p.Wi + iw) * p.Ci + e.z : p.zeros;
+            rb[q] = *reinterpret_cast<const f32x4*>(src);
+            int ow = r_ow[q] + dr, oh = r_oh[q] + dq, im = r_img[q] + d_img;
+            if (ow >= p.Wo) { ow -= p.Wo; ++oh; }
+            if (oh >= p.Ho) { oh -= p.Ho; ++im; }
+            r_ow[q] = ow; r_oh[q] = oh; r_img[q] = im;
         }
     };
     auto lstore = [&](int buf) {

@@ -1,0 +1,283 @@
+"""LocalUpdate drop-in: the reference's per-client trainer surface
+(utils/local_training.py:26-55 ctor, :628-703 train, :771-825 train_FixMatch,
+:904-1256 train_FedMLP) driven through the HIP engine.
+
+Same constructor and method signatures, same return tuples (positions 3-4 are
+the reference's junk `_` placeholders -> None), same persistent per-client
+state (traindata_idx, idxss, class_num_list, loss_w, iter_num, epoch).  What
+changes is where the arithmetic runs: every forward/backward/optimiser step,
+the prototype pass, cosine tagging and top-k selection are engine calls
+(include/fedmlp_hip.h); this file only orders batches and keeps label masks.
+
+Data: `dataset` follows dataset/all_dataset.py:64-83 -- `.targets` float32
+[N,C] and `dataset[i]` -> dict with "image" or "image_aug_1"/"image_aug_2",
+"target", "index".  If the dataset exposes `device_views()` -> dict of CUDA
+tensors [N,3,H,W] (the HBM-resident cache of SURVEY 8f), batches are gathered
+on the GPU instead of being collated on the host.
+
+Batch order: the reference's DataLoader(shuffle=True) draws from the global
+torch RNG (:47-48, 1166-1167).  Here `torch.randperm` does, unless explicit
+orders are queued in `self.order_queue` (parity tests).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .model import HipNet
+
+
+def _batches(order, bs):
+    return [order[i:i + bs] for i in range(0, len(order), bs)]
+
+
+class LocalUpdate(object):
+    def __init__(self, args, client_id, dataset, idxs, class_pos_idx, class_neg_idx,
+                 active_class_list=None, student=None, teacher_neg=None, teacher_act=None,
+                 dataset_test=None):
+        self.args = args
+        self.client_id = client_id
+        self.dataset = dataset
+        self.dataset_test = dataset_test
+        self.idxs = [int(i) for i in idxs]
+        self.student, self.teacher_neg, self.teacher_act = student, teacher_neg, teacher_act
+        self.class_pos_idx, self.class_neg_idx = class_pos_idx, class_neg_idx
+        C = args.n_classes
+        if active_class_list is None:       # DatasetSplit.__init__ :1338-1341
+            import random
+            active_class_list = random.sample(list(range(C)), args.annotation_num)
+        self.active_class_list = list(active_class_list)
+        targets = np.asarray(dataset.targets, dtype=np.float32)
+        loc = targets[self.idxs]                                   # unmasked local labels
+        # get_num_of_each_class :1358-1362 (float64 sums of the UNMASKED labels), loss_w :40-42
+        self.class_num_list = loc.astype(np.float64).sum(axis=0).tolist()
+        n = len(self.idxs)
+        self.loss_w = [n / i for i in self.class_num_list]
+        self.loss_w_unknown = [1] * C
+        self.loss_w_unknown[client_id] = n / self.class_num_list[client_id]
+        logging.info(f"---> Client{client_id}, each class num: {self.class_num_list}, total num: {n}")
+        # DatasetSplit.__getitem__ :1347-1356: zero positives of non-active classes listed in class_neg_idx
+        y = loc.copy()
+        ids = np.asarray(self.idxs)
+        for c in range(C):
+            if c not in self.active_class_list:
+                hit = np.isin(ids, np.asarray(list(class_neg_idx[c]), dtype=np.int64))
+                y[hit, c] = 0.0
+        self._targets_local = loc
+        self._y_masked = y
+        self.negative_class_list = [c for c in range(C) if c not in self.active_class_list]
+        self.epoch = 0
+        self.iter_num = 0
+        self.lr = args.base_lr
+        self.traindata_idx = []
+        self.idxss = []
+        self.order_queue = []
+        self._dev = {}
+
+    # ---- data plumbing -------------------------------------------------------------------
+    def _order(self, n):
+        if self.order_queue:
+            o = list(self.order_queue.pop(0))
+            assert len(o) == n
+            return o
+        return torch.randperm(n).tolist()
+
+    def _views(self, eng):
+        if "views" not in self._dev:
+            v = None
+            if hasattr(self.dataset, "device_views"):
+                v = self.dataset.device_views(eng.device)
+            self._dev["views"] = v
+        return self._dev["views"]
+
+    def _images(self, eng, key, pos):
+        ds_idx = [self.idxs[p] for p in pos]
+        v = self._views(eng)
+        if v is not None and key in v:
+            sel = torch.as_tensor(ds_idx, device=eng.device, dtype=torch.long)
+            return v[key].index_select(0, sel).contiguous()
+        x = torch.stack([torch.as_tensor(self.dataset[i][key], dtype=torch.float32) for i in ds_idx])
+        return x.to(eng.device).contiguous()
+
+    def _labels_dev(self, eng, arr, name):
+        t = self._dev.get(name)
+        if t is None or t[0] is not arr:
+            self._dev[name] = (arr, torch.from_numpy(np.ascontiguousarray(arr)).to(eng.device))
+        return self._dev[name][1]
+
+    def _rows(self, t, pos, eng):
+        sel = torch.as_tensor(list(pos), device=eng.device, dtype=torch.long)
+        return t.index_select(0, sel).contiguous()
+
+    def _bind(self, net, key):
+        assert isinstance(net, HipNet), "net must come from fedmlp_amd.model.build_model"
+        sample = self.dataset[self.idxs[0]][key]
+        h, w = int(sample.shape[-2]), int(sample.shape[-1])
+        return net.bind(h, w, 4 * self.args.batch_size)
+
+    def _mask(self, classes):
+        return [1.0 if c in classes else 0.0 for c in range(self.args.n_classes)]
+
+    # ---- LocalUpdate.train (:628-703) ----------------------------------------------------------
+    def train(self, rnd, net, writer1=None):
+        a = self.args
+        eng = self._bind(net, "image")
+        eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+        y = self._labels_dev(eng, self._y_masked, "y_masked")
+        n = len(self.idxs)
+        epoch_loss = []
+        for _ in range(a.local_ep):
+            batches = _batches(self._order(n), a.batch_size)
+            losses = torch.zeros(len(batches), device=eng.device)
+            for k, pos in enumerate(batches):
+                eng.step_bce(self._images(eng, "image", pos), self._rows(y, pos, eng), self.loss_w,
+                             a.batch_size, losses[k:k + 1])
+                self.iter_num += 1
+            self.epoch += 1
+            epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+        net.mark_trained()
+        return net.state_dict(), np.array(epoch_loss).mean(), None, None, \
+            list(self.negative_class_list), list(self.active_class_list)
+
+    # ---- LocalUpdate.train_FixMatch (:771-825) ---------------------------------------------------
+    def train_FixMatch(self, rnd, net):
+        a = self.args
+        eng = self._bind(net, "image_aug_1")
+        eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+        y = self._labels_dev(eng, self._y_masked, "y_masked")
+        n = len(self.idxs)
+        act = self._mask(self.active_class_list)
+        epoch_loss = []
+        for _ in range(a.local_ep):
+            batches = _batches(self._order(n), a.batch_size)
+            losses = torch.zeros(len(batches), device=eng.device)
+            for k, pos in enumerate(batches):
+                eng.step_fixmatch(self._images(eng, "image_aug_1", pos), self._images(eng, "image_aug_2", pos),
+                                  self._rows(y, pos, eng), self.loss_w, self.loss_w_unknown, act,
+                                  a.annotation_num, a.batch_size, losses[k:k + 1])
+                self.iter_num += 1
+            self.epoch += 1
+            epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+        net.mark_trained()
+        return net.state_dict(), np.array(epoch_loss).mean(), None, None, \
+            list(self.negative_class_list), list(self.active_class_list)
+
+    # ---- prototype + t pass (:971-1002 unguarded, :1208-1250 zero-guarded) ----------------------------
+    def _proto_pass(self, eng, negative_list, zero_guard):
+        a = self.args
+        n = len(self.idxs)
+        y = self._labels_dev(eng, self._y_masked, "y_masked")
+        act, neg = self._mask(self.active_class_list), self._mask(negative_list)
+        eng.proto_reset()
+        for pos in _batches(list(range(n)), a.batch_size * 4):
+            f, z = eng.forward_eval(self._images(eng, "image_aug_1", pos))
+            eng.proto_accumulate(f, z, self._rows(y, pos, eng), act, neg, a.L, a.U)
+        t, proto = eng.proto_finalize(zero_guard, n, act)
+        return t, torch.from_numpy(proto)
+
+    # ---- LocalUpdate.train_FedMLP (:904-1256) --------------------------------------------------------
+    def train_FedMLP(self, rnd, tao, Prototype, writer1, negetive_class_list, active_class_list_client_i, net):
+        a = self.args
+        eng = self._bind(net, "image_aug_1")
+        n = len(self.idxs)
+        if rnd < a.rounds_FedMLP_stage1:                                   # ---- stage 1
+            eng.teacher_snapshot()                                         # glob_model = deepcopy(net) :909
+            eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+            y = self._labels_dev(eng, self._y_masked, "y_masked")
+            act = self._mask(self.active_class_list)
+            epoch_loss = []
+            for _ in range(a.local_ep):
+                batches = _batches(self._order(n), a.batch_size)
+                losses = torch.zeros(len(batches), device=eng.device)
+                for k, pos in enumerate(batches):
+                    eng.step_stage1(self._images(eng, "image_aug_1", pos), self._images(eng, "image_aug_2", pos),
+                                    self._rows(y, pos, eng), act, a.annotation_num, a.batch_size,
+                                    losses[k:k + 1])
+                    self.iter_num += 1
+                self.epoch += 1
+                epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+            for c in self.negative_class_list:                             # :932 "try noro"
+                self.class_num_list[c] = 0
+            net.mark_trained()
+            ret = (net.state_dict(), np.array(epoch_loss).mean(), None, None,
+                   list(self.negative_class_list), list(self.active_class_list))
+            if rnd == a.rounds_FedMLP_stage1 - 1:                          # first tao and proto :971
+                t, proto = self._proto_pass(eng, negetive_class_list, zero_guard=False)
+                ret = ret + (t, proto)
+            return ret
+
+        # ---------------------------------------------------------------------- stage 2
+        first = (rnd == a.rounds_FedMLP_stage1)
+        if first:
+            self.traindata_idx = []
+        # (a) eval-mode feature pass over the shuffled local loader (:1023-1049)
+        feat_order = self._order(n)
+        D = eng.feature_dim
+        f = torch.empty((n, D), device=eng.device)
+        row = 0
+        for pos in _batches(feat_order, a.batch_size):
+            fb, _ = eng.forward_eval(self._images(eng, "image_aug_1", pos))
+            f[row:row + len(pos)] = fb
+            row += len(pos)
+        ds_idx = [self.idxs[p] for p in feat_order]                        # `class_idx`, loader order
+        proto_dev = torch.as_tensor(np.asarray(Prototype, dtype=np.float32)).to(eng.device).contiguous()
+        # (b)+(c) cosine tagging and stable top-/bottom-k selection per missing class (:1052-1112)
+        where = {v: j for j, v in enumerate(ds_idx)}
+        for k, cls in enumerate(negetive_class_list):
+            if first:
+                pool_f, pool_idx = f, ds_idx
+            else:
+                rows = [where[v] for v in self.idxss[k]]                   # find_indices_in_a :901-902
+                pool_idx = [ds_idx[r] for r in rows]
+                pool_f = f.index_select(0, torch.as_tensor(rows, device=eng.device, dtype=torch.long)) \
+                    if rows else f[:0]
+            if len(pool_idx):
+                sim = eng.cos_tag(pool_f.contiguous(), proto_dev, [cls])
+                top, bot = eng.select_topk(sim[0], a.clean_threshold, a.noise_threshold)
+            else:
+                top, bot = [], []
+            clean = [int(pool_idx[j]) for j in top]
+            noise = [int(pool_idx[j]) for j in bot]
+            if first:
+                self.traindata_idx += [clean, noise]
+            else:
+                self.traindata_idx[2 * k].extend(clean)
+                self.traindata_idx[2 * k + 1].extend(noise)
+        for k, cls in enumerate(negetive_class_list):                      # :1117-1120
+            self.class_num_list[cls] = len(self.traindata_idx[2 * k + 1])
+        # (d) training on pseudo-labelled targets (DatasetSplit_pseudo :1456-1477; loop :1164-1196)
+        ids = np.asarray(self.idxs)
+        yp = self._targets_local.copy()
+        dist = np.zeros_like(yp)
+        for c in range(a.n_classes):
+            if c not in active_class_list_client_i:
+                yp[:, c] = 0.0
+        for k, cls in enumerate(negetive_class_list):
+            clean = np.asarray(self.traindata_idx[2 * k], dtype=np.int64)
+            noise = np.asarray(self.traindata_idx[2 * k + 1], dtype=np.int64)
+            in_noise = np.isin(ids, noise)
+            in_any = in_noise | np.isin(ids, clean)
+            yp[in_noise, cls] = 1.0
+            dist[~in_any, cls] = 1.0
+        yp_d = torch.from_numpy(yp).to(eng.device)
+        dist_d = torch.from_numpy(dist).to(eng.device)
+        eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+        epoch_loss = []
+        for _ in range(a.local_ep):
+            batches = _batches(self._order(n), a.batch_size)
+            losses = torch.zeros(len(batches), device=eng.device)
+            for kb, pos in enumerate(batches):
+                eng.step_stage2(self._images(eng, "image_aug_1", pos), self._rows(yp_d, pos, eng),
+                                self._rows(dist_d, pos, eng), losses[kb:kb + 1])
+                self.iter_num += 1
+            self.epoch += 1
+            epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+        net.mark_trained()
+        self.idxss = []
+        for k in range(len(self.traindata_idx) // 2):                      # :1197-1204
+            sel = self.traindata_idx[2 * k] + self.traindata_idx[2 * k + 1]
+            self.idxss.append(list(set(self.idxs) - set(sel)))
+        # (e) prototype + t pass, zero-count guarded (:1208-1250)
+        t, proto = self._proto_pass(eng, negetive_class_list, zero_guard=True)
+        return net.state_dict(), np.array(epoch_loss).mean(), None, None, \
+            negetive_class_list, list(self.active_class_list), t, proto
