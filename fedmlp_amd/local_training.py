@@ -31,6 +31,40 @@ def _batches(order, bs):
     return [order[i:i + bs] for i in range(0, len(order), bs)]
 
 
+def mask_targets(targets, idxs, active_class_list, class_neg_idx):
+    """DatasetSplit.__getitem__ label masking (utils/local_training.py:1347-1356) for the
+    whole local set at once: for every NON-active class c, the label of samples listed in
+    class_neg_idx[c] is zeroed.  Returns (unmasked local labels, masked copy), float32 [N,C]."""
+    loc = np.asarray(targets, dtype=np.float32)[[int(i) for i in idxs]]
+    y = loc.copy()
+    ids = np.asarray([int(i) for i in idxs])
+    for c in range(loc.shape[1]):
+        if c not in active_class_list:
+            y[np.isin(ids, np.asarray(list(class_neg_idx[c]), dtype=np.int64)), c] = 0.0
+    return loc, y
+
+
+def pseudo_targets(local_targets, idxs, active_class_list, negative_class_list, traindata_idx):
+    """DatasetSplit_pseudo.__getitem__ (utils/local_training.py:1456-1477) for the whole local
+    set: non-active labels zeroed; for the k-th missing class, samples selected as clean or
+    noise are supervised (label 1 iff noise), all others get distill_cls = 1.
+    Returns (y[N,C], distill_cls[N,C]) float32."""
+    ids = np.asarray([int(i) for i in idxs])
+    yp = np.array(local_targets, dtype=np.float32, copy=True)
+    dist = np.zeros_like(yp)
+    for c in range(yp.shape[1]):
+        if c not in active_class_list:
+            yp[:, c] = 0.0
+    for k, cls in enumerate(negative_class_list):
+        clean = np.asarray(traindata_idx[2 * k], dtype=np.int64)
+        noise = np.asarray(traindata_idx[2 * k + 1], dtype=np.int64)
+        in_noise = np.isin(ids, noise)
+        in_any = in_noise | np.isin(ids, clean)
+        yp[in_noise, cls] = 1.0
+        dist[~in_any, cls] = 1.0
+    return yp, dist
+
+
 class LocalUpdate(object):
     def __init__(self, args, client_id, dataset, idxs, class_pos_idx, class_neg_idx,
                  active_class_list=None, student=None, teacher_neg=None, teacher_act=None,
@@ -47,8 +81,8 @@ class LocalUpdate(object):
             import random
             active_class_list = random.sample(list(range(C)), args.annotation_num)
         self.active_class_list = list(active_class_list)
-        targets = np.asarray(dataset.targets, dtype=np.float32)
-        loc = targets[self.idxs]                                   # unmasked local labels
+        # DatasetSplit.__getitem__ :1347-1356: zero positives of non-active classes listed in class_neg_idx
+        loc, y = mask_targets(dataset.targets, self.idxs, self.active_class_list, class_neg_idx)
         # get_num_of_each_class :1358-1362 (float64 sums of the UNMASKED labels), loss_w :40-42
         self.class_num_list = loc.astype(np.float64).sum(axis=0).tolist()
         n = len(self.idxs)
@@ -56,13 +90,6 @@ class LocalUpdate(object):
         self.loss_w_unknown = [1] * C
         self.loss_w_unknown[client_id] = n / self.class_num_list[client_id]
         logging.info(f"---> Client{client_id}, each class num: {self.class_num_list}, total num: {n}")
-        # DatasetSplit.__getitem__ :1347-1356: zero positives of non-active classes listed in class_neg_idx
-        y = loc.copy()
-        ids = np.asarray(self.idxs)
-        for c in range(C):
-            if c not in self.active_class_list:
-                hit = np.isin(ids, np.asarray(list(class_neg_idx[c]), dtype=np.int64))
-                y[hit, c] = 0.0
         self._targets_local = loc
         self._y_masked = y
         self.negative_class_list = [c for c in range(C) if c not in self.active_class_list]
@@ -246,19 +273,8 @@ class LocalUpdate(object):
         for k, cls in enumerate(negetive_class_list):                      # :1117-1120
             self.class_num_list[cls] = len(self.traindata_idx[2 * k + 1])
         # (d) training on pseudo-labelled targets (DatasetSplit_pseudo :1456-1477; loop :1164-1196)
-        ids = np.asarray(self.idxs)
-        yp = self._targets_local.copy()
-        dist = np.zeros_like(yp)
-        for c in range(a.n_classes):
-            if c not in active_class_list_client_i:
-                yp[:, c] = 0.0
-        for k, cls in enumerate(negetive_class_list):
-            clean = np.asarray(self.traindata_idx[2 * k], dtype=np.int64)
-            noise = np.asarray(self.traindata_idx[2 * k + 1], dtype=np.int64)
-            in_noise = np.isin(ids, noise)
-            in_any = in_noise | np.isin(ids, clean)
-            yp[in_noise, cls] = 1.0
-            dist[~in_any, cls] = 1.0
+        yp, dist = pseudo_targets(self._targets_local, self.idxs, active_class_list_client_i,
+                                  negetive_class_list, self.traindata_idx)
         yp_d = torch.from_numpy(yp).to(eng.device)
         dist_d = torch.from_numpy(dist).to(eng.device)
         eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)

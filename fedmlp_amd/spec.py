@@ -127,7 +127,7 @@ def state_dict_to_flat(model, n_classes, sd):
             v = v.detach().cpu().numpy()
         v = np.asarray(v)
         if dt == "i64":
-            cnt.append(int(np.trunc(float(v))))
+            cnt.append(int(np.trunc(float(np.asarray(v).reshape(-1)[0]))))
         else:
             assert tuple(v.shape) == tuple(shape), (key, v.shape, shape)
             fl.append(v.astype(np.float32).reshape(-1))

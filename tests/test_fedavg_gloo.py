@@ -1,0 +1,86 @@
+"""The N>1 path on CPU: world_size-2 `gloo` process groups run the same all-reduce
+forms the 8-GPU job runs over RCCL (fedmlp_amd/fedavg.py) and are checked against
+the single-process reference-surface FedAvg / FedAvg_tao / FedAvg_proto."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from fedmlp_amd.fedavg import (FedAvg, FedAvg_tao, FedAvg_proto, fedavg_allreduce, tao_allreduce,
+                               proto_allreduce)
+
+WORLD = 2
+N_LOCAL = [300, 500]
+C, D, NSTATE = 4, 16, 1000
+
+
+class FakeEngine:
+    """CPU stand-in with the three engine methods fedavg_allreduce touches."""
+
+    def __init__(self, state, counters):
+        self.state, self.cnt = state, counters
+
+    def state_scale(self, w):
+        self.state.mul_(w)
+
+    def state_tensor(self):
+        return self.state
+
+    def counters(self, new=None):
+        if new is not None:
+            self.cnt = np.asarray(new, dtype=np.int64)
+        return self.cnt
+
+
+def _inputs(rank):
+    rs = np.random.RandomState(100 + rank)
+    state = torch.from_numpy(rs.standard_normal(NSTATE).astype(np.float32))
+    cnt = np.array([40 + 7 * rank, 41 + 7 * rank], dtype=np.int64)
+    t = rs.uniform(size=C)
+    proto = torch.from_numpy(rs.standard_normal((2 * C, D)).astype(np.float32))
+    return state, cnt, t, proto
+
+
+# client r annotates class r; class 2 has no active client at all, class 3 is missing everywhere
+ACT = [[0], [1]]
+CLASS_ACTIVE = [[0], [1], [], []]
+CLASS_NEG = [[1], [0], [0, 1], [0, 1]]
+
+
+def _worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    state, cnt, t, proto = _inputs(rank)
+    w = N_LOCAL[rank] / float(sum(N_LOCAL))
+    eng = FakeEngine(state.clone(), cnt.copy())
+    fedavg_allreduce(eng, w)
+    neg_mask = [0.0 if c in ACT[rank] else 1.0 for c in range(C)]
+    act_mask = [1.0 if c in ACT[rank] else 0.0 for c in range(C)]
+    tao = tao_allreduce(t, N_LOCAL[rank], neg_mask)
+    pr = proto_allreduce(proto, N_LOCAL[rank], act_mask)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), state=eng.state.numpy(), cnt=eng.cnt, tao=tao,
+             proto=pr.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_forms_match_reference_surface(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    ins = [_inputs(r) for r in range(WORLD)]
+    # single-process reference surface on the same inputs
+    sds = [{"w": ins[r][0], "bn.num_batches_tracked": torch.tensor(ins[r][1][0])} for r in range(WORLD)]
+    want = FedAvg(sds, N_LOCAL)
+    want_tao = FedAvg_tao([ins[r][2] for r in range(WORLD)], N_LOCAL, CLASS_NEG)
+    want_proto = FedAvg_proto([ins[r][3] for r in range(WORLD)], N_LOCAL, CLASS_ACTIVE).numpy()
+    for r in range(WORLD):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        np.testing.assert_allclose(got["state"], want["w"].numpy(), rtol=2e-6, atol=1e-7)
+        assert got["cnt"][0] == int(np.trunc(float(want["bn.num_batches_tracked"])))
+        np.testing.assert_allclose(got["tao"], want_tao, rtol=1e-12)
+        np.testing.assert_allclose(got["proto"], want_proto, rtol=2e-6, atol=1e-7, equal_nan=True)
+        assert np.isnan(got["proto"][4:]).all()          # classes without an active client

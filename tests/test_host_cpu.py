@@ -1,0 +1,123 @@
+"""CPU-only checks of the host side: state layout, the reference-surface helpers
+(label masking, pseudo targets, FedAvg* drop-ins) against the reference's golden
+vectors, and that the C-ABI library loads and exports every declared symbol."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fedmlp_amd import spec
+from tests.helpers import load_golden, make_args
+from tests.synth import synth_arrays, class_lists
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spec_matches_reference_layout():
+    nf, ni = spec.sizes("Resnet18", 5)
+    assert (nf + ni, ni) == (11188697, 20)            # 122 keys, 11 188 697 elements
+    ent = spec.entries("Resnet18", 5)
+    assert len(ent) == 122
+    from oracle.resnet18_ref import ResNet18Ref
+    ref = ResNet18Ref(5).state_dict()
+    assert [k for k, _, _ in ent] == list(ref.keys())
+    for k, shape, _ in ent:
+        assert tuple(ref[k].shape) == tuple(shape), k
+
+
+def test_state_flat_roundtrip():
+    flat, cnt = spec.init_state("Resnet18", 8, 3)
+    sd = spec.flat_to_state_dict("Resnet18", 8, flat, cnt)
+    f2, c2 = spec.state_dict_to_flat("Resnet18", 8, sd)
+    np.testing.assert_array_equal(flat, f2)
+    np.testing.assert_array_equal(cnt, c2)
+    flat_b, _ = spec.init_state("Resnet18", 8, 3)
+    np.testing.assert_array_equal(flat, flat_b)       # deterministic
+
+
+def test_label_masking_and_pseudo_targets_golden():
+    from fedmlp_amd.local_training import mask_targets, pseudo_targets
+    g = load_golden("kat.json")["dataset_split"]
+    t = np.array(g["targets"], dtype=np.float32)
+    loc, ym = mask_targets(t, g["idxs"], g["active"], g["class_neg_idx"])
+    np.testing.assert_array_equal(ym, np.array(g["masked"], dtype=np.float32))
+    assert loc.astype(np.float64).sum(axis=0).tolist() == g["counts"]
+    y, d = pseudo_targets(loc, g["idxs"], g["active"], g["negative"], g["traindata_idx"])
+    np.testing.assert_array_equal(y, np.array(g["pseudo_y"], dtype=np.float32))
+    np.testing.assert_array_equal(d, np.array(g["pseudo_distill"], dtype=np.float32))
+
+
+def test_localupdate_ctor_state_golden():
+    """LocalUpdate.__init__ (utils/local_training.py:26-55): class counts and pos_weight from
+    the UNMASKED labels, checked against the reference-run golden."""
+    from fedmlp_amd.local_training import LocalUpdate
+    g = load_golden("traj_train.json")
+    C, n_cl, N = g["C"], g["n_clients"], g["N"]
+
+    class DS:
+        pass
+    ds = DS()
+    ds.targets, _, _ = synth_arrays(n_cl * N, C, 4, g["data_seed"], False)
+    # synth_arrays draws targets first, so any hw regenerates the same labels
+    t224, _, _ = synth_arrays(n_cl * N, C, g["hw"], g["data_seed"], False)
+    np.testing.assert_array_equal(ds.targets, t224)
+    pos, neg = class_lists(ds.targets, C)
+    args = make_args(n_classes=C, n_clients=n_cl)
+    for i in range(n_cl):
+        loc = LocalUpdate(args, i, ds, g["users"][i], pos, neg, active_class_list=[i])
+        np.testing.assert_allclose(loc.loss_w, g["loss_w"][i], rtol=0)
+        assert loc.negative_class_list == g["rounds"][0]["neg"][i]
+
+
+def test_fedavg_dropins_golden():
+    from fedmlp_amd.fedavg import FedAvg, FedAvg_tao, FedAvg_proto
+    kat = load_golden("kat.json")
+    g = kat["fedavg"]
+    w = [{k: torch.tensor(v, dtype=torch.int64 if "num_batches" in k else torch.float32)
+          for k, v in wi.items()} for wi in g["w"]]
+    out = FedAvg(w, g["lens"])
+    for k, v in g["out"].items():
+        assert str(out[k].dtype) == g["out_dtype"][k]
+        np.testing.assert_array_equal(out[k].numpy(), np.array(v, dtype=np.float32))
+    g = kat["fedavg_tao"]
+    np.testing.assert_array_equal(FedAvg_tao([np.array(v) for v in g["t"]], g["weight"], g["clients"]),
+                                  np.array(g["out"]))
+    g = kat["fedavg_proto"]
+    out = FedAvg_proto([torch.tensor(p) for p in g["P"]], g["weight"], g["clients"]).numpy()
+    want = np.array([[np.nan if x is None else x for x in r] for r in g["out"]], dtype=np.float32)
+    np.testing.assert_array_equal(out, want)
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """The built .so must load (no GPU needed) and export every function the header declares;
+    the ctypes table must cover the header one-to-one."""
+    from fedmlp_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "fedmlp_hip.h")).read()
+    declared = set(re.findall(r"\b(fm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fm_engine", "fm_config", "fm_adam"}
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libfedmlp_hip.so not built (run `make`)")
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.fm_version()
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must never route through the oracle (tests/bench only)."""
+    pkg = os.path.join(ROOT, "fedmlp_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), fn
+
+
+def test_engine_requires_gpu_and_library():
+    from fedmlp_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        Engine("Resnet18", 5, 64, 64, 4)

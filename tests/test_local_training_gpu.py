@@ -55,15 +55,18 @@ def _norms(sd):
     return {k: float(torch.linalg.vector_norm(v.double())) for k, v in sd.items()}
 
 
-def _cmp_norms(got, want, rtol, what, report):
+def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6):
+    """atol = a quarter of ONE Adam update (lr 3e-5) on the tensor norm: zero-initialised BN
+    biases (norm ~1e-3 after a round) move by +-lr per step, and a channel whose gradient
+    is ~0 can take one step in the other direction (2*lr on one of 64 channels)."""
     worst = 0.0
     for k, w in want.items():
         if "num_batches" in k:
             assert abs(got[k] - w) < 0.5, (what, k, got[k], w)
             continue
-        rel = abs(got[k] - w) / (abs(w) + 1e-12)
-        worst = max(worst, rel)
-        assert rel <= rtol, f"{what} {k}: got {got[k]} want {w} rel {rel:.2e}"
+        err = abs(got[k] - w)
+        worst = max(worst, err / (abs(w) + 1e-12))
+        assert err <= rtol * abs(w) + atol, f"{what} {k}: got {got[k]} want {w} rel {err / (abs(w) + 1e-12):.2e}"
     report[what + " max norm rel err"] = worst
 
 
