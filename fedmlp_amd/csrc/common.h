@@ -29,6 +29,10 @@ struct IgemmParams {
     const float* scale;   // optional per-m affine (eval-mode BN folded), else null
     const float* shift;
     float* stats;         // optional BN partials [group][tilesN][2][M]
+    float* slab;          // stream-K partial tiles [blocks][2][BM*BN]
+    int* counters;        // stream-K arrival counters [tiles], zero between launches
+    long long total_steps;   // tiles * nsteps (set by launch_igemm)
+    int steps_per_block;     // range length per persistent block (set by launch_igemm)
     int M, nsteps;
     int Hi, Wi, Ci;
     int Hg, Wg, sg;       // virtual output grid per image and its stride into the input
@@ -53,7 +57,8 @@ struct WgradParams {
     int tilesM, tilesN;
 };
 
-void launch_igemm(const IgemmParams& p, int groups, hipStream_t s);
+void launch_igemm(IgemmParams p, int groups, hipStream_t s);
+int igemm_max_blocks();
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s);
 int igemm_tile_n(int M);   // pixel-tile width the igemm uses for this M
 int igemm_tile_m(int M);

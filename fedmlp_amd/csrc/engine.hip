@@ -120,6 +120,8 @@ struct fm_engine {
     float* psum = nullptr;
     int64_t *pcnt = nullptr, *tcnt = nullptr;
     float* zeros = nullptr;
+    float* sk_slab = nullptr;
+    int* sk_counters = nullptr;
     int *sel_counts = nullptr, *sel_top = nullptr, *sel_bot = nullptr, *cls_dev = nullptr;
     int sel_cap = 0;
     // profiling
@@ -321,6 +323,9 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->psum, (size_t)2 * e->C * 512); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
     DALLOC(e->sel_counts, 2); DALLOC(e->cls_dev, FM_MAX_CLASSES);
     DALLOC(e->zeros, 64);
+    DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);
+    DALLOC(e->sk_counters, (size_t)1 << 20);
+    HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
     HIPCHK(hipMemset(e->zeros, 0, 64 * 4));
     return FM_OK;
 }
@@ -349,7 +354,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
 {
     const Conv& c = e->convs[ci];
     IgemmParams p{};
-    p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros;
+    p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
     if (c.cin == 3) { p.stem_kw = c.k; p.stem_pad = c.pad; }
     else
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
@@ -385,7 +390,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         DgradClass& d = c.cls[k];
         k_pack_dgrad(S + c.w_off, d.wpack, c.cout, c.k * c.k, c.cin, d.taps, e->st);
         IgemmParams p{};
-        p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros;
+        p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
         for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
         p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
         p.M = c.cin; p.nsteps = d.nsteps;
@@ -417,7 +422,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     p.tilesM = c.cout / bm;
     p.tilesN = (c.Kw + bn - 1) / bn;
     const int tiles = p.tilesM * p.tilesN;
-    int splits = (1024 + tiles - 1) / tiles;
+    int splits = std::max(1, 1024 / tiles);           // tiles*splits <= 1024 = 2 full rounds of 512 block slots
     const int max_by_pix = std::max(1, p.npix / 256);
     const int max_by_mem = (int)std::max<size_t>(1, e->slab_floats / c.w_numel);
     splits = std::max(1, std::min(splits, std::min(max_by_pix, max_by_mem)));

@@ -115,6 +115,23 @@ def test_conv_layers_224(eng224, ci):
     _check_conv(e, sd, ci, imgs=3, groups=1, seed=200 + ci)
 
 
+def test_conv_streamk_forced_splits():
+    """Stream-K fix-up paths (partial tiles summed by the last arriver) on small shapes: the
+    persistent grid is forced to odd block counts in a child process (the grid override is
+    read once per process) and every conv layer is re-checked."""
+    import os, subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, '.');"
+        "import tests.test_kernels_gpu as T; from fedmlp_amd.engine import Engine; from fedmlp_amd import spec;"
+        "e = Engine('Resnet18', 5, 64, 64, 8); flat, cnt = spec.init_state('Resnet18', 5, 1037);"
+        "e.set_state(flat, cnt); sd = spec.flat_to_state_dict('Resnet18', 5, flat, cnt);"
+        "[T._check_conv(e, sd, ci, 6, 2, 300 + ci) for ci in range(20)]; e.close(); print('ok')")
+    for nb in ("7", "61", "509"):
+        env = dict(os.environ, FM_IGEMM_BLOCKS=nb)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, f"FM_IGEMM_BLOCKS={nb}: {r.stdout[-2000:]} {r.stderr[-3000:]}"
+
+
 def test_state_roundtrip(eng64):
     e, sd = eng64
     flat, cnt = spec.init_state("Resnet18", 5, 99)
