@@ -24,8 +24,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KERNEL_NAMES = {0: "igemm_kernel<128,128,2>", 1: "igemm_kernel<64,256,4>",
-                2: "wgrad_kernel<128,128,2>", 3: "wgrad_kernel<64,256,4>"}
+KERNEL_NAMES = {0: "igemm_kernel<128,128,2,false>", 1: "igemm_kernel<64,256,4,false>",
+                2: "igemm_kernel<64,256,4,true>", 3: "wgrad_kernel<128,128,2>", 4: "wgrad_kernel<64,256,4>"}
+NFAM = len(KERNEL_NAMES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
@@ -148,7 +149,7 @@ def main():
         dist.barrier()
     if not args.no_profile:
         eng.profile_enable(True)
-        for f in range(4):
+        for f in range(NFAM):
             eng.profile_read(f)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -168,9 +169,9 @@ def main():
 
     roof = None
     if not args.no_profile:
-        fams = [eng.profile_read(f) for f in range(4)]
+        fams = [eng.profile_read(f) for f in range(NFAM)]
         eng.profile_enable(False)
-        dom = max(range(4), key=lambda f: fams[f][1])
+        dom = max(range(NFAM), key=lambda f: fams[f][1])
         n, ms, fl = fams[dom]
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -178,7 +179,7 @@ def main():
                 "kernel": KERNEL_NAMES[dom], "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
                 "all_kernels": {KERNEL_NAMES[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
                                                   "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
-                                for f in range(4)}}
+                                for f in range(NFAM)}}
     lv = losses.cpu().numpy()
     assert np.isfinite(lv).all(), "non-finite loss in the benchmark"
 

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfedmlp_hip.so")
+# FEDMLP_HIP_LIB selects another build of the same library (timing probes under tools/)
+LIB_PATH = os.environ.get("FEDMLP_HIP_LIB") or os.path.join(_HERE, "libfedmlp_hip.so")
 
 FM_MAX_CLASSES = 32
 

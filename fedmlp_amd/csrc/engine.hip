@@ -56,7 +56,7 @@ struct Conv {
     size_t w_off;             // offset into the state arena
     size_t w_numel;           // cout*k*kw_p*cin_p
     int Kw;                   // k*kw_p*cin_p  (GEMM K of fwd, N of wgrad)
-    int nsteps;               // Kw/32
+    int nsteps;               // Kw/16 (igemm K steps)
     int4* tab = nullptr;      // [Kw/4]
     int ncls = 0;
     DgradClass cls[4];
@@ -128,8 +128,8 @@ struct fm_engine {
     bool prof = false;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ev_free;
-    double prof_ms[4] = {0, 0, 0, 0}, prof_flops[4] = {0, 0, 0, 0};
-    int64_t prof_n[4] = {0, 0, 0, 0};
+    double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
+    int64_t prof_n[5] = {0, 0, 0, 0, 0};
     std::vector<void*> allocs;
 };
 
@@ -168,7 +168,7 @@ int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hi
     c.hout = (hin + 2 * pad - k) / stride + 1;
     c.wout = (win + 2 * pad - k) / stride + 1;
     c.Kw = k * c.kw_p * c.cin_p;
-    c.nsteps = c.Kw / 32;
+    c.nsteps = c.Kw / 16;
     c.w_numel = (size_t)cout * c.Kw;
     c.w_off = off;
     off += c.w_numel;
@@ -209,7 +209,7 @@ int build_tables(fm_engine* e)
                     }
                 if (d.taps.n == 0) continue;
                 const int K = d.taps.n * c.cout;
-                d.nsteps = K / 32;
+                d.nsteps = K / 16;
                 DALLOC(d.wpack, (size_t)c.cin * K);
                 c.cls[c.ncls++] = d;
             }
@@ -323,7 +323,7 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->psum, (size_t)2 * e->C * 512); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
     DALLOC(e->sel_counts, 2); DALLOC(e->cls_dev, FM_MAX_CLASSES);
     DALLOC(e->zeros, 64);
-    DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);
+    DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);   // [blocks][2][BM*BN]
     DALLOC(e->sk_counters, (size_t)1 << 20);
     HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
     HIPCHK(hipMemset(e->zeros, 0, 64 * 4));
@@ -369,7 +369,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     const int bn = igemm_tile_n(c.cout);
     p.tilesN = (p.imgs_per_group * c.hout * c.wout + bn - 1) / bn;
     p.relu = relu;
-    ProfScope ps(e, c.cout >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs);
+    ProfScope ps(e, c.cout >= 128 ? 0 : (c.cin == 3 ? 2 : 1), 2.0 * c.macs_per_img * imgs);
     launch_igemm(p, groups, e->st);
 }
 
@@ -429,7 +429,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     p.pix_per_split = (((p.npix + splits - 1) / splits) + 31) & ~31;
     splits = (p.npix + p.pix_per_split - 1) / p.pix_per_split;
     {
-        ProfScope ps(e, c.cout >= 128 ? 2 : 3, 2.0 * c.macs_per_img * imgs);
+        ProfScope ps(e, c.cout >= 128 ? 3 : 4, 2.0 * c.macs_per_img * imgs);
         launch_wgrad(p, splits, e->st);
     }
     k_reduce_slabs(e->ws_slab, e->grad + c.w_off, splits, (int64_t)c.w_numel, e->st);
@@ -902,7 +902,7 @@ int fm_profile_enable(fm_engine* e, int32_t on)
 
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops)
 {
-    ARGCHK(e && family >= 0 && family < 4, "family");
+    ARGCHK(e && family >= 0 && family < 5, "family");
     HIPCHK(hipStreamSynchronize(e->st));
     for (auto& p : e->evs) {
         float t = 0.f;

@@ -9,26 +9,29 @@
 //  * D = Wp * Xg^T with output CHANNELS on the MFMA row axis, so each lane ends
 //    up with 4 consecutive channels of one pixel -> one 16-B NHWC store.
 //  * 256 threads = 4 waves, each wave owns a 64x64 sub-tile (4x4 MFMA tiles,
-//    64 accumulator VGPRs); block tile 128x128 (M>=128) or 64x256 (M==64).
-//  * K advances 32 floats per step through double-buffered LDS; both operand
-//    tiles are k-contiguous rows of 128 B whose 16-B chunks are XOR-swizzled by
-//    (row & 7): conflict-free ds_read_b128 / ds_write_b128 on the 64-bank LDS.
+//    64 accumulator VGPRs); block tile 128x128 (M>=128) or 64x256 (M==64); two
+//    blocks per CU.  (The template also builds one-block-per-CU 256x128 /
+//    128x256 / 64x512 tiles with 128x64 wave tiles; measured slower, see the
+//    table above launch_igemm.)
+//  * Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR
+//    staging, no ds_write.  LDS is a ring of 4 stages of 16 k; a step's DMA is
+//    issued three steps ahead of its use (counted s_waitcnt vmcnt + raw
+//    s_barrier), so L2 misses do not stall the MFMA stream.  The LDS image is
+//    lane-linear (DMA destination = base + lane*16 B); the bank swizzle
+//    slot = chunk ^ ((row>>1)&3) is applied on the SOURCE address and on the
+//    read (conflict-free ds_read_b128 on 64-B rows, brute-force checked).
 //  * K order inside a step is permuted (lane group g reads k = 4g..4g+3 with
 //    ONE ds_read_b128 and feeds 4 MFMAs); legal because A and B use the same
-//    permutation.
-//  * Global->LDS goes through registers (next step's loads are issued before
-//    the current step's MFMAs) because the pixel operand is a bounds-checked
-//    gather; padding reads a zero page, tap offsets are scalar kernel arguments,
-//    so nothing in the loop waits on a dependent load.
+//    permutation.  Tap offsets are scalar kernel arguments; padding and tail
+//    rows read a 16-B zero page.
 //  * STREAM-K scheduling: ResNet's pixel counts are 49*2^k, so a one-tile-per-
-//    block grid leaves the last round of the 256 CUs ~23 % empty (392 / 784 /
-//    1568 tiles on 512 block slots).  Instead the launch is persistent: the
-//    (tile, K-step) space is cut into equal contiguous ranges, one per block.
-//    A block whose range ends inside a tile stores its partial accumulators to a
-//    slab, releases them at agent scope and bumps the tile's arrival counter; the
-//    LAST arriver re-reads every partial of the tile in segment order (so the
-//    sum does not depend on arrival order: deterministic) and runs the epilogue.
-//    Nobody waits on anybody, so no residency assumption and no deadlock.
+//    block grid leaves the last round of the 256 CUs partly empty.  The launch
+//    is persistent: the (tile, K-step) space is cut into equal contiguous
+//    ranges, one per block.  A block whose range ends inside a tile stores its
+//    partial accumulators to a slab, releases them at agent scope and bumps the
+//    tile's arrival counter; the LAST arriver re-reads every partial of the tile
+//    in segment order (the sum does not depend on arrival order: deterministic)
+//    and runs the epilogue.  Nobody waits on anybody: no residency assumption.
 //  * Epilogue variants (runtime-uniform): raw store + per-channel sum/sumsq
 //    partials (train-mode BN statistics, fixed reduction order), or folded
 //    eval-BN affine + residual + ReLU, or plain residual add (dgrad).
@@ -40,29 +43,32 @@
 
 #include "common.h"
 
-template <int BM, int BN, int WN>
+template <int BM, int BN, int WN, bool STEM>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
+#if __HIP_DEVICE_COMPILE__     // the host pass only needs the launch stub (the body uses gfx950-only builtins)
     constexpr int WM = 4 / WN;
-    static_assert(BM == WM * 64 && BN == WN * 64, "wave tile is 64x64");
-    constexpr int RA = BM / 32;
-    constexpr int RB = BN / 32;
+    constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
+    static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
+    constexpr int NS = 4;                       // LDS ring: 4 stages of 16 k
+    constexpr int STG_A = BM * 16, STG_B = BN * 16;   // floats per stage
+    constexpr int GA = BM / 64, GB = BN / 64;   // 16-row groups each wave stages per step
+    constexpr int PER = GA + GB;                // LDS-DMA instructions per wave per step
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [2][BM][32]
-    float* Bs = smem + 2 * BM * 32;   // [2][BN][32]
+    float* As = smem;                 // [NS][BM][16]
+    float* Bs = smem + NS * STG_A;    // [NS][BN][16]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
-    const int lc = tid & 7, lr = tid >> 3;         // loader: chunk, row
-    const int sc4 = (lc ^ (lr & 7)) << 2;          // swizzled float offset inside the row
-    const int sw = li & 7;
-    const int aoff = (wm * 64 + li) * 32;
-    const int boff = (wn * 64 + li) * 32;
+    const int drow = lane >> 2, dpos = lane & 3;           // LDS-DMA: row inside a 16-row group, 16-B slot
+    // fragment reads: row 16r+i, k-chunk g lives in slot g ^ ((row>>1)&3)  (conflict-free ds_read_b128)
+    const int aoff = (wm * (16 * FR) + li) * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
+    const int boff = (wn * (16 * FC) + li) * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
 
-    const int nsteps = p.nsteps;
-    const int Ktot = nsteps * 32;
+    const int nsteps = p.nsteps;                // steps of 16 k
+    const int Ktot = nsteps * 16;
     const int HWg = p.Hg * p.Wg;
     const int npix = p.imgs_per_group * HWg;
     const int tiles_pg = p.tilesM * p.tilesN;
@@ -86,12 +92,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         const int tm = tl % p.tilesM, tn = tl / p.tilesM;
         const int m0 = tm * BM, n0 = tn * BN;
 
-        // ---- loader state: thread -> (row lr + 32q, chunk lc) ----------------
-        int ih0[RB], iw0[RB], xb[RB];
-        bool rv[RB];
+        // ---- LDS-DMA source state: this lane stages row 16*(wave*G+q)+drow of each operand -------
+        const int csrc = (dpos ^ ((drow >> 1) & 3)) << 2;          // floats; same for every group (16 | group base)
+        const float* asrc[GA];
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
-            const int n = n0 + lr + 32 * q;
+        for (int q = 0; q < GA; ++q)
+            asrc[q] = p.W + (size_t)(m0 + 16 * (wave * GA + q) + drow) * Ktot + csrc;
+        int ih0[GB], iw0[GB], xb[GB];
+        bool rv[GB];
+#pragma unroll
+        for (int q = 0; q < GB; ++q) {
+            const int n = n0 + 16 * (wave * GB + q) + drow;
             rv[q] = n < npix;
             const int nn = rv[q] ? n : 0;
             const int img = nn / HWg;
@@ -102,86 +113,79 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             iw0[q] = wg * p.sg;
             xb[q] = (grp * p.imgs_per_group + img) * (p.Hi * p.Wi * p.Ci);
         }
-        const float* wrow = p.W + (size_t)(m0 + lr) * Ktot + lc * 4;
-
-        f32x4 ra[RA], rb[RB];
-        auto gload = [&](int s) {
+        // Issue the LDS-DMA of K-step s into ring slot (s - k0) & 3.
+        auto issue = [&](int s) {
+            const int slot = (s - k0) & (NS - 1);
+            typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll
-            for (int q = 0; q < RA; ++q)
-                ra[q] = *reinterpret_cast<const f32x4*>(wrow + (size_t)q * 32 * Ktot + s * 32);
-            // where this step's chunk comes from: scalar tap lookup (kernel arguments), or for
-            // the stem one kernel row per step and one kernel column per chunk
+            for (int q = 0; q < GA; ++q)
+                __builtin_amdgcn_global_load_lds(asrc[q] + s * 16,
+                                                 (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
             int dh, dw, c0;
             bool cv = true;
-            if (p.stem_kw) {
-                dh = s - p.stem_pad; dw = lc - p.stem_pad; c0 = 0; cv = lc < p.stem_kw;
+            if constexpr (STEM) {
+                // stem: K = (kh, kw padded to 8, ci padded to 4); step = half a kernel row, chunk = kw
+                const int kw = ((s & 1) << 2) + (csrc >> 2);
+                dh = (s >> 1) - p.stem_pad; dw = kw - p.stem_pad; c0 = 0; cv = kw < p.stem_kw;
             } else {
-                const int kk = s * 32;
+                const int kk = s * 16;
                 const int t = kk / p.Ci;
-                dh = p.dh[t]; dw = p.dw[t]; c0 = kk - t * p.Ci + lc * 4;
+                dh = p.dh[t]; dw = p.dw[t]; c0 = kk - t * p.Ci + csrc;
             }
 #pragma unroll
-            for (int q = 0; q < RB; ++q) {
+            for (int q = 0; q < GB; ++q) {
                 const int ih = ih0[q] + dh, iw = iw0[q] + dw;
                 const bool ok = rv[q] && cv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-                // branch-free padding: out-of-image taps read a 16-B block of zeros, so no select
-                // ever touches the loaded data (a select would drag the vmcnt wait ahead of the MFMAs)
                 const float* src = ok ? p.X + (size_t)(xb[q] + (ih * p.Wi + iw) * p.Ci + c0) : p.zeros;
-                rb[q] = *reinterpret_cast<const f32x4*>(src);
+                __builtin_amdgcn_global_load_lds(src, (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
             }
         };
-        auto lstore = [&](int buf) {
-            float* a = As + buf * BM * 32 + lr * 32 + sc4;
-            float* b = Bs + buf * BN * 32 + lr * 32 + sc4;
-#pragma unroll
-            for (int q = 0; q < RA; ++q) *reinterpret_cast<f32x4*>(a + q * 32 * 32) = ra[q];
-#pragma unroll
-            for (int q = 0; q < RB; ++q) *reinterpret_cast<f32x4*>(b + q * 32 * 32) = rb[q];
-        };
 
-        f32x4 acc[4][4];
+        f32x4 acc[FR][FC];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < FR; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        gload(k0);
-        lstore(0);
-        __syncthreads();
+        issue(k0);
+        if (k0 + 1 < k1) issue(k0 + 1);
+        if (k0 + 2 < k1) issue(k0 + 2);
         for (int s = k0; s < k1; ++s) {
-            const int buf = (s - k0) & 1;
-            if (s + 1 < k1) gload(s + 1);
-            const float* A = As + buf * BM * 32 + aoff;
-            const float* B = Bs + buf * BN * 32 + boff;
+            // my DMA of step s has landed once at most the younger steps' instructions are outstanding
+            const int younger = min(2, k1 - 1 - s);
+            if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // everyone's step-s data landed; everyone finished reading step s-1
+            asm volatile("" ::: "memory");
+            if (s + 3 < k1) issue(s + 3);      // refill the slot step s-1 just vacated
+            const int slot = (s - k0) & (NS - 1);
+            const float* A = As + slot * STG_A + aoff;
+            const float* B = Bs + slot * STG_B + boff;
+            f32x4 a[FR], b[FC];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int ch = ((4 * s2 + lg) ^ sw) << 2;
-                f32x4 a[4], b[4];
+            for (int r = 0; r < FR; ++r) a[r] = *reinterpret_cast<const f32x4*>(A + r * 256);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const f32x4*>(A + r * 16 * 32 + ch);
+            for (int c = 0; c < FC; ++c) b[c] = *reinterpret_cast<const f32x4*>(B + c * 256);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const f32x4*>(B + c * 16 * 32 + ch);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < FR; ++r)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
-            }
-            if (s + 1 < k1) lstore(buf ^ 1);
-            __syncthreads();
+                    for (int c = 0; c < FC; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
         }
+        __syncthreads();       // all LDS reads done before the fix-up / epilogue reuse the LDS
 
         // ---- stream-K fix-up: partial tiles meet in the slab ------------------------
         if (k0 != 0 || k1 != nsteps) {
             // slot 0: the block's first segment, slot 1: its last one (middle ones are whole tiles)
-            float* mine = p.slab + ((size_t)(rbk * 2 + (seg_first_of_block ? 0 : 1)) * 16) * 1024;
+            float* mine = p.slab + (size_t)(rbk * 2 + (seg_first_of_block ? 0 : 1)) * (BM * BN);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < FR; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<f32x4*>(mine + ((r * 4 + c) * 256 + tid) * 4) = acc[r][c];
+                for (int c = 0; c < FC; ++c)
+                    *reinterpret_cast<f32x4*>(mine + ((r * FC + c) * 256 + tid) * 4) = acc[r][c];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
             __syncthreads();
             const long long t0 = (long long)tile * nsteps;
@@ -207,30 +211,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             // last arriver: sum every segment of this tile in segment order (incl. its own, from the
             // slab) -> the result is independent of which block arrived last
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < FR; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int bb = b_first; bb <= b_last; ++bb) {
                 const long long sstart = max(t0, (long long)bb * S);
-                const float* src = p.slab + ((size_t)(bb * 2 + (sstart == (long long)bb * S ? 0 : 1)) * 16) * 1024;
+                const float* src = p.slab + (size_t)(bb * 2 + (sstart == (long long)bb * S ? 0 : 1)) * (BM * BN);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < FR; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * 4 + c) * 256 + tid) * 4);
+                    for (int c = 0; c < FC; ++c)
+                        acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * FC + c) * 256 + tid) * 4);
             }
         }
 
         // ---- epilogue -------------------------------------------------------------
-        // acc[r][c][q] = D[m = m0 + wm*64 + 16r + 4*lg + q][n = n0 + wn*64 + 16c + li]
-        const int mbase = m0 + wm * 64 + 4 * lg;
+        // acc[r][c][q] = D[m = m0 + wm*16FR + 16r + 4*lg + q][n = n0 + wn*16FC + 16c + li]
+        const int mbase = m0 + wm * (16 * FR) + 4 * lg;
         if (p.stats) {
             float* red = smem;            // [WN][BM][2]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < FR; ++r) {
                 f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < FC; ++c) {
                     s1 += acc[r][c];
                     s2 += acc[r][c] * acc[r][c];
                 }
@@ -243,28 +247,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                         v += __shfl_xor(v, d);
                     }
                     if (li == 0) {
-                        const int ml = wm * 64 + 16 * r + 4 * lg + q;
+                        const int ml = wm * (16 * FR) + 16 * r + 4 * lg + q;
                         red[(wn * BM + ml) * 2 + 0] = u;
                         red[(wn * BM + ml) * 2 + 1] = v;
                     }
                 }
             }
             __syncthreads();
-            if (tid < BM) {
+            for (int ch = tid; ch < BM; ch += 256) {
                 float u = 0.f, v = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < WN; ++ww) {
-                    u += red[(ww * BM + tid) * 2 + 0];
-                    v += red[(ww * BM + tid) * 2 + 1];
+                    u += red[(ww * BM + ch) * 2 + 0];
+                    v += red[(ww * BM + ch) * 2 + 1];
                 }
                 float* st = p.stats + (size_t)(grp * p.tilesN + tn) * 2 * p.M;
-                st[m0 + tid] = u;
-                st[p.M + m0 + tid] = v;
+                st[m0 + ch] = u;
+                st[p.M + m0 + ch] = v;
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int n = n0 + wn * 64 + 16 * c + li;
+        for (int c = 0; c < FC; ++c) {
+            const int n = n0 + wn * (16 * FC) + 16 * c + li;
             if (n >= npix) continue;
             const int img = n / HWg;
             const int rem = n - img * HWg;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             const size_t o = ((size_t)((grp * p.imgs_per_group + img) * p.Ho + hg * p.os + p.oh0) * p.Wo
                               + (wg * p.os + p.ow0)) * p.Co;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < FR; ++r) {
                 const int m = mbase + 16 * r;
                 f32x4 v = acc[r][c];
                 if (p.scale) {
@@ -291,37 +295,46 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         }
         __syncthreads();       // LDS (stats scratch) is re-staged by the next segment
     }
+#endif
 }
 
+// Tile configuration.  Measured on MI355X (conv 3x3, 256 images, tools/probe_conv.py):
+//   two 4-wave blocks per CU, 128x128 / 64x256 tiles (this build) : 100 / 116 / 117 / 118 TFLOP/s
+//   one block per CU, 256x128 / 128x256 / 64x512 tiles (128x64 wave tiles):  90 / 107 / 116 / 115
+// for layer1 / layer2 / layer3 / layer4; the kernel template supports both.
 int igemm_tile_m(int M) { return M >= 128 ? 128 : 64; }
 int igemm_tile_n(int M) { return M >= 128 ? 128 : 256; }
-int igemm_max_blocks() { return 512; }    // 2 blocks per CU x 256 CUs (64-80 KB LDS, <=256 VGPRs)
+int igemm_max_blocks() { return 512; }    // 2 blocks per CU x 256 CUs (64-80 KB LDS each)
 
 void launch_igemm(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
-    constexpr int LDS_L = 2 * (128 + 128) * 32 * 4;
-    constexpr int LDS_S = 2 * (64 + 256) * 32 * 4;
+    constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
+    constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
         attr_done = true;
     }
     const long long T = (long long)p.tilesM * p.tilesN * groups;
     p.total_steps = T * p.nsteps;
-    // persistent grid: all 512 block slots whenever there are >= 2 steps for each of them,
-    // otherwise one tile per block.  FM_IGEMM_BLOCKS overrides the grid (tests force odd
-    // splits so that every fix-up path runs on small shapes).
+    // persistent grid: every block slot whenever there are >= 4 K-steps for each of them, otherwise
+    // one tile per block.  FM_IGEMM_BLOCKS overrides the grid (tests force odd splits so that every
+    // fix-up path runs on small shapes).
     static const int forced = getenv("FM_IGEMM_BLOCKS") ? atoi(getenv("FM_IGEMM_BLOCKS")) : 0;
-    int nblk = p.total_steps >= 2LL * igemm_max_blocks() ? igemm_max_blocks()
+    int nblk = p.total_steps >= 4LL * igemm_max_blocks() ? igemm_max_blocks()
                                                          : (int)std::min<long long>(igemm_max_blocks(), T);
     if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, igemm_max_blocks()), p.total_steps);
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
     dim3 grid(nblk);
-    if (p.M >= 128)
-        hipLaunchKernelGGL((igemm_kernel<128, 128, 2>), grid, dim3(256), LDS_L, s, p);
+    if (p.stem_kw)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, true>), grid, dim3(256), LDS_S, s, p);
+    else if (p.M >= 128)
+        hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false>), grid, dim3(256), LDS_L, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4>), grid, dim3(256), LDS_S, s, p);
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, false>), grid, dim3(256), LDS_S, s, p);
 }
