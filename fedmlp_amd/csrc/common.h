@@ -23,6 +23,8 @@ struct IgemmParams {
     const float* X;       // input activations NHWC [imgs][Hi][Wi][Ci]
     float* Y;             // output NHWC [imgs][Ho][Wo][Co]
     int dh[9], dw[9];     // per-tap input offsets
+    int ntaps;
+    int tap_minor;        // K walked chunk-major / tap-minor (L2 reuse) instead of tap-major
     int stem_kw, stem_pad;
     const float* zeros;   // >= 16 B of zeros (source of padded / out-of-range chunks)
     const float* res;     // optional residual, indexed like Y (may alias Y)

@@ -7,6 +7,7 @@
 // eps 1e-5; eval: folded affine), F.relu, residual add, nn.MaxPool2d(3,2,1),
 // torch.optim.Adam (coupled L2 weight decay).  Roofline: HBM bandwidth; every
 // kernel moves 16 B per lane, NHWC so that the channel axis is contiguous.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -415,7 +416,14 @@ void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count
                        const float* mean, const float* istd, float* ca, float* cb, float* cc, float* dgamma,
                        float* dbeta, hipStream_t s)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 64), dim3(256), 0, s, part, groups, nblk, C, count, gamma,
+    const float* src = part;
+    if (nblk > 64 && !getenv("FM_NO_BWD_FOLD")) {      // fold the per-block partials with many blocks first (same kernel as the forward statistics)
+        float* folded = const_cast<float*>(part) + (size_t)groups * nblk * 2 * C;
+        hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3(32, groups), dim3(256), 0, s, part, folded, nblk, 2 * C);
+        src = folded;
+        nblk = 32;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 64), dim3(256), 0, s, src, groups, nblk, C, count, gamma,
                        mean, istd, ca, cb, cc, dgamma, dbeta);
 }
 

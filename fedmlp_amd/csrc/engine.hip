@@ -314,7 +314,7 @@ int alloc_workspaces(fm_engine* e)
     }
     DALLOC(e->GA, pooled); DALLOC(e->GB, pooled); DALLOC(e->GC, pooled); DALLOC(e->GD, pooled); DALLOC(e->GE, pooled);
     DALLOC(e->ws_stats, max_stats);
-    DALLOC(e->ws_part, (size_t)2 * 256 * 2 * 512);
+    DALLOC(e->ws_part, (size_t)2 * (256 + 32) * 2 * 512);   // per-block partials + folded partials
     e->slab_floats = std::max<size_t>(max_slab * 8, (size_t)48 << 20);   // >= 192 MB of partial slabs
     DALLOC(e->ws_slab, e->slab_floats);
     DALLOC(e->ca, 2 * 512); DALLOC(e->cb, 2 * 512); DALLOC(e->cc, 2 * 512);
@@ -357,7 +357,10 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
     if (c.cin == 3) { p.stem_kw = c.k; p.stem_pad = c.pad; }
     else
+    {
+        p.ntaps = c.k * c.k;
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
+    }
     p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
     p.M = c.cout; p.nsteps = c.nsteps;
     p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
@@ -391,6 +394,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         k_pack_dgrad(S + c.w_off, d.wpack, c.cout, c.k * c.k, c.cin, d.taps, e->st);
         IgemmParams p{};
         p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+        p.ntaps = d.taps.n;
         for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
         p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
         p.M = c.cin; p.nsteps = d.nsteps;

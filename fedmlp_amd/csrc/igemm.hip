@@ -117,21 +117,33 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         auto issue = [&](int s) {
             const int slot = (s - k0) & (NS - 1);
             typedef __attribute__((address_space(3))) void lds_void;
-#pragma unroll
-            for (int q = 0; q < GA; ++q)
-                __builtin_amdgcn_global_load_lds(asrc[q] + s * 16,
-                                                 (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
-            int dh, dw, c0;
+            // K is walked channel-chunk-major, tap-minor: the taps of one 16-channel chunk are
+            // consecutive steps, so the shifted re-reads of an input pixel hit L1/L2 instead of
+            // coming back from MALL/HBM after the other channels have streamed through.
+            int dh, dw, c0, koff;
             bool cv = true;
             if constexpr (STEM) {
                 // stem: K = (kh, kw padded to 8, ci padded to 4); step = half a kernel row, chunk = kw
                 const int kw = ((s & 1) << 2) + (csrc >> 2);
                 dh = (s >> 1) - p.stem_pad; dw = kw - p.stem_pad; c0 = 0; cv = kw < p.stem_kw;
+                koff = s * 16;
             } else {
-                const int kk = s * 16;
-                const int t = kk / p.Ci;
-                dh = p.dh[t]; dw = p.dw[t]; c0 = kk - t * p.Ci + csrc;
+                if (p.tap_minor) {
+                    const int cc = s / p.ntaps;
+                    const int t = s - cc * p.ntaps;
+                    dh = p.dh[t]; dw = p.dw[t]; c0 = cc * 16 + csrc;
+                    koff = t * p.Ci + cc * 16;
+                } else {
+                    const int kk = s * 16;
+                    const int t = kk / p.Ci;
+                    dh = p.dh[t]; dw = p.dw[t]; c0 = kk - t * p.Ci + csrc;
+                    koff = kk;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < GA; ++q)
+                __builtin_amdgcn_global_load_lds(asrc[q] + koff,
+                                                 (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
 #pragma unroll
             for (int q = 0; q < GB; ++q) {
                 const int ih = ih0[q] + dh, iw = iw0[q] + dw;
@@ -322,6 +334,8 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     }
     const long long T = (long long)p.tilesM * p.tilesN * groups;
     p.total_steps = T * p.nsteps;
+    static const int tap_major = getenv("FM_TAP_MAJOR") ? 1 : 0;
+    p.tap_minor = !tap_major;
     // persistent grid: every block slot whenever there are >= 4 K-steps for each of them, otherwise
     // one tile per block.  FM_IGEMM_BLOCKS overrides the grid (tests force odd splits so that every
     // fix-up path runs on small shapes).
