@@ -142,6 +142,11 @@ class LocalUpdate(object):
         h, w = int(sample.shape[-2]), int(sample.shape[-1])
         return net.bind(h, w, 4 * self.args.batch_size)
 
+    @staticmethod
+    def _sd(net):
+        # a resident net (one client per GPU) keeps its state in HBM: no per-round D2H copy
+        return None if getattr(net, "resident", False) else net.state_dict()
+
     def _mask(self, classes):
         return [1.0 if c in classes else 0.0 for c in range(self.args.n_classes)]
 
@@ -163,7 +168,7 @@ class LocalUpdate(object):
             self.epoch += 1
             epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
         net.mark_trained()
-        return net.state_dict(), np.array(epoch_loss).mean(), None, None, \
+        return self._sd(net), np.array(epoch_loss).mean(), None, None, \
             list(self.negative_class_list), list(self.active_class_list)
 
     # ---- LocalUpdate.train_FixMatch (:771-825) ---------------------------------------------------
@@ -186,7 +191,7 @@ class LocalUpdate(object):
             self.epoch += 1
             epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
         net.mark_trained()
-        return net.state_dict(), np.array(epoch_loss).mean(), None, None, \
+        return self._sd(net), np.array(epoch_loss).mean(), None, None, \
             list(self.negative_class_list), list(self.active_class_list)
 
     # ---- prototype + t pass (:971-1002 unguarded, :1208-1250 zero-guarded) ----------------------------
@@ -226,7 +231,7 @@ class LocalUpdate(object):
             for c in self.negative_class_list:                             # :932 "try noro"
                 self.class_num_list[c] = 0
             net.mark_trained()
-            ret = (net.state_dict(), np.array(epoch_loss).mean(), None, None,
+            ret = (self._sd(net), np.array(epoch_loss).mean(), None, None,
                    list(self.negative_class_list), list(self.active_class_list))
             if rnd == a.rounds_FedMLP_stage1 - 1:                          # first tao and proto :971
                 t, proto = self._proto_pass(eng, negetive_class_list, zero_guard=False)
@@ -295,5 +300,5 @@ class LocalUpdate(object):
             self.idxss.append(list(set(self.idxs) - set(sel)))
         # (e) prototype + t pass, zero-count guarded (:1208-1250)
         t, proto = self._proto_pass(eng, negetive_class_list, zero_guard=True)
-        return net.state_dict(), np.array(epoch_loss).mean(), None, None, \
+        return self._sd(net), np.array(epoch_loss).mean(), None, None, \
             negetive_class_list, list(self.active_class_list), t, proto

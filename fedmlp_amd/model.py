@@ -129,6 +129,40 @@ class HipNet:
             self._engine._dirty = True
 
 
+class ResidentNet(HipNet):
+    """A net whose state already lives in an engine (one client per GPU: the model never
+    leaves HBM between rounds; FedAvg is an in-place RCCL all-reduce of the engine state).
+    bind() hands back that engine without any upload; state_dict() still works (D2H copy)."""
+
+    def __init__(self, engine):
+        self.model, self.n_classes = engine.model, engine.n_classes
+        self.training = True
+        self._version = 0
+        self._engine = engine
+        self.default_max_images = engine.max_images
+        self.resident = True
+
+    def bind(self, in_h, in_w, max_images, device="cuda:0"):
+        eng = self._engine
+        assert (in_h, in_w) == (eng.in_h, eng.in_w) and max_images <= eng.max_images, \
+            "resident engine was created for another input size / batch"
+        return eng
+
+    def _pull(self):
+        self.flat, self.counters = self._engine.get_state()
+
+    def mark_trained(self):
+        pass
+
+    def load_state_dict(self, sd, strict=True):
+        flat, cnt = spec.state_dict_to_flat(self.model, self.n_classes, sd)
+        self._engine.set_state(flat, cnt)
+        return self
+
+    def __deepcopy__(self, memo):
+        return self          # "deepcopy(netglob)" of a resident net is the resident net
+
+
 def build_model(args):
     """model/build_model.py:5-10.  Reads args.model, args.n_classes, args.pretrained.
     ImageNet weights (args.pretrained, utils/options.py:26) cannot be downloaded
