@@ -361,11 +361,43 @@ def g_step224(out):
     json.dump(rec, open(os.path.join(out, "step224.json"), "w"), indent=1)
 
 
+# ---- G3: evaluation metrics (utils/evaluations.py globaltest) ----------------------------------
+def g_eval(out):
+    """globaltest of the reference on a synthetic test set with the oracle net (probabilities,
+    sklearn AP / ROC-AUC and the multilabel_metrixs numbers), plus a metrics-only KAT with ties."""
+    import utils.evaluations as EV
+    EV.DataLoader = FixedLoader
+    C, N, hw = 5, 64, 32
+    args = make_args(n_classes=C, batch_size=8)
+    ds = SynthDataset(N, C, hw, 51, False)
+    net = build_net(C, 1037)
+    res = EV.globaltest(net, ds, args)
+    rec = {"C": C, "N": N, "hw": hw, "data_seed": 51, "init_seed": 1037, "bs": 8,
+           "metrics": {k: float(v) for k, v in res.items()}}
+    # metrics-only KAT (ties in the scores, a class that is never predicted)
+    rs = np.random.RandomState(5)
+    y = (rs.uniform(size=(40, 4)) < 0.3).astype(np.float32)
+    y[0] = 1; y[1] = 0
+    p = np.round(rs.uniform(size=(40, 4)), 1).astype(np.float32)      # many ties
+    p[:, 3] = np.minimum(p[:, 3], 0.4)                                 # class 3 never predicted
+    from sklearn.metrics import average_precision_score, roc_curve, auc
+    from utils.multilabel_metrixs import Recall, Hamming_Loss, F1Measure, Precision, BACC
+    pred = p > 0.5
+    rec["kat"] = {"y": y.tolist(), "p": p.tolist(),
+                  "AP": [float(average_precision_score(y[:, c], p[:, c])) for c in range(4)],
+                  "AUC": [float(auc(*roc_curve(y[:, c], p[:, c], pos_label=1)[:2])) for c in range(4)],
+                  "BACC": float(BACC(y, pred)), "R": float(Recall(y, pred)), "F1": float(F1Measure(y, pred)),
+                  "P": float(Precision(y, pred)), "hamming_loss": float(Hamming_Loss(y, pred))}
+    json.dump(rec, open(os.path.join(out, "eval_metrics.json"), "w"), indent=1)
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224"]
+    which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224", "eval"]
     fns = {"kat": g_kat, "train": g_train_traj, "fedmlp": g_fedmlp_traj,
-           "fixmatch": g_fixmatch_traj, "step224": g_step224}
+           "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval}
     for w in which:
         print("==> golden:", w, flush=True)
         fns[w](HERE)
     assert not ORDERS, "unconsumed loader orders"
+

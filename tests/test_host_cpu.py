@@ -121,3 +121,38 @@ def test_engine_requires_gpu_and_library():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         Engine("Resnet18", 5, 64, 64, 4)
+
+
+def test_eval_metrics_golden():
+    """numpy AP / ROC-AUC / multilabel metrics vs sklearn + the reference's multilabel_metrixs
+    (tests/golden/eval_metrics.json, made by importing utils/evaluations.py)."""
+    from fedmlp_amd.evaluations import average_precision, roc_auc, multilabel_metrics
+    g = load_golden("eval_metrics.json")["kat"]
+    y, p = np.array(g["y"], dtype=np.float32), np.array(g["p"], dtype=np.float32)
+    for c in range(4):
+        assert abs(average_precision(y[:, c], p[:, c]) - g["AP"][c]) < 1e-12
+        assert abs(roc_auc(y[:, c], p[:, c]) - g["AUC"][c]) < 1e-12
+    m = multilabel_metrics(y, p)
+    for k in ("BACC", "R", "F1", "P", "hamming_loss"):
+        assert abs(m[k] - g[k]) < 1e-12, k
+    assert abs(float(m["mAP"]) - np.mean(g["AP"])) < 1e-6
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """main.py:237/361 saves torch.save(netglob.state_dict()); a HipNet must write and read that
+    file format (122 torchvision keys, OIHW, int64 counters) and an nn.Module must accept it."""
+    from fedmlp_amd.model import HipNet
+    from oracle.resnet18_ref import ResNet18Ref
+    flat, cnt = spec.init_state("Resnet18", 5, 11)
+    cnt[:] = 7
+    net = HipNet("Resnet18", 5, flat, cnt)
+    path = tmp_path / "model_9.pth"
+    torch.save(net.state_dict(), path)
+    sd = torch.load(path)
+    ref = ResNet18Ref(5)
+    ref.load_state_dict(sd)                              # strict: same keys, shapes, dtypes
+    assert ref.bn1.num_batches_tracked.item() == 7
+    net2 = HipNet("Resnet18", 5, np.zeros_like(flat), np.zeros_like(cnt))
+    net2.load_state_dict(torch.load(path))
+    np.testing.assert_array_equal(net2.flat, flat)
+    np.testing.assert_array_equal(net2.counters, cnt)
