@@ -55,6 +55,7 @@ SYMBOLS = {
     "fm_cos_tag": (C.c_int, [_P, _P, _I64, _P, C.POINTER(_I32), _I32, _P]),
     "fm_select_topk": (C.c_int, [_P, _P, _I64, C.c_double, C.c_double, _I32, C.POINTER(_I32),
                                  C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "fm_augment": (C.c_int, [_P, _P, _P, _P, _I32, _F, _F, _P]),
     "fm_profile_enable": (C.c_int, [_P, _I32]),
     "fm_profile_read": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),

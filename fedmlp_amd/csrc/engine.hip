@@ -897,6 +897,15 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
     return FM_OK;
 }
 
+int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const float* params_dev, int32_t B,
+               const float* mean_host, const float* std_host, float* out_dev)
+{
+    ARGCHK(e && cache_dev && idx_dev && params_dev && mean_host && std_host && out_dev && B >= 1, "null");
+    k_augment(cache_dev, idx_dev, params_dev, out_dev, B, e->H, e->W, mean_host[0], mean_host[1], mean_host[2],
+              std_host[0], std_host[1], std_host[2], e->st);
+    return FM_OK;
+}
+
 int fm_profile_enable(fm_engine* e, int32_t on)
 {
     ARGCHK(e, "null engine");

@@ -18,6 +18,12 @@ void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, in
 void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList taps, hipStream_t s);
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
 
+// ---- input pipeline: uint8 HBM cache -> augmented, normalised fp32 NCHW batch.
+// params[b] = {m0..m5 (inverse affine, PIL AFFINE convention), flip, unused}; nearest sampling,
+// fill 0, then horizontal flip, /255, (v-mean)/std   (dataset/dataset.py:40-53 pipeline)
+void k_augment(const uint8_t* cache, const int* idx, const float* params, float* out, int B, int H, int W,
+               float m0, float m1, float m2, float s0, float s1, float s2, hipStream_t s);
+
 // ---- batch norm ---------------------------------------------------------------
 // stats: [groups][tiles][2][C] partial (sum, sumsq) from the conv epilogue.
 // Writes mean/istd/scale/shift [groups][C]; updates running stats group by group

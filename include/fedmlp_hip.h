@@ -154,6 +154,16 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
                    double noise_thr, int32_t cap, int32_t* top_host, int32_t* n_top,
                    int32_t* bot_host, int32_t* n_bot);
 
+/* ---- HBM-resident input pipeline --------------------------- */
+/* Train transform of dataset/dataset.py:40-53 on a uint8 cache of already-resized images
+ * [N,3,H,W] kept in HBM: RandomAffine(10 deg, translate 2 %) with NEAREST sampling and fill 0,
+ * RandomHorizontalFlip, ToTensor (/255), Normalize(mean, std).  The random draws are the
+ * caller's: params_dev[b] = {m0..m5 = inverse affine matrix in PIL's AFFINE convention
+ * (source = M * (x+0.5, y+0.5, 1)), flip (0/1), unused}.  idx_dev[b] = sample index in the cache.
+ * out_dev: fp32 NCHW [B,3,H,W], i.e. what fm_step_* consume.  mean/std: host[3]. */
+int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const float* params_dev,
+               int32_t B, const float* mean_host, const float* std_host, float* out_dev);
+
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the
  * engine's stream; fm_profile_read drains them (synchronises) and returns, per
