@@ -56,6 +56,8 @@ SYMBOLS = {
     "fm_select_topk": (C.c_int, [_P, _P, _I64, C.c_double, C.c_double, _I32, C.POINTER(_I32),
                                  C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "fm_augment": (C.c_int, [_P, _P, _P, _P, _I32, _F, _F, _P]),
+    "fm_set_stochastic": (C.c_int, [_P, _P, _P]),
+    "fm_feature_dim": (C.c_int, [_P]),
     "fm_profile_enable": (C.c_int, [_P, _I32]),
     "fm_profile_read": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),

@@ -1,0 +1,507 @@
+// HBM-bound kernels of the EfficientNet-B0 path (BASELINE configs 4-5), gfx950.
+//
+// Reference ops replaced: what efficientnet-pytorch 0.7.1's MBConvBlock does around its 1x1
+// convolutions (the 1x1 convs themselves are GEMMs and run through igemm.hip / wgrad.hip):
+// depthwise k3/k5 s1/s2 convolution with TF-"same" padding, BatchNorm(eps 1e-3, momentum 0.01)
+// + Swish forward/backward, squeeze-and-excite (global pool -> 1x1 reduce + Swish -> 1x1 expand
+// + sigmoid -> channel gate), drop-connect on the residual branch, dropout before `_fc`
+// (model/efficientnet.py:28-33 builds the net; the trainer calls it at
+// utils/local_training.py:657, 937-947, 983, 1030, 1178).  The model is HBM-bound on MI355X
+// (10.4 FLOP/B in fp32): every kernel here moves 16 B per lane on NHWC tensors whose
+// channel counts are padded to multiples of 16 (24->32, 40->48; padded channels are exactly 0).
+#include "common.h"
+#include "kernels.h"
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ f32x4 act_fwd(f32x4 v, int act)
+{
+    if (act == 1) { for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f); }
+    else if (act == 2) { for (int k = 0; k < 4; ++k) v[k] = v[k] * sigm(v[k]); }
+    return v;
+}
+// d act(v) / dv for act = swish
+__device__ __forceinline__ float swish_grad(float v)
+{
+    const float s = sigm(v);
+    return s * (1.f + v * (1.f - s));
+}
+
+// ------------------------------------------------------------ BN(+act) apply ---
+// out = act(y*scale+shift) * rowscale[img] + res      (per group scale/shift, any C % 4 == 0)
+__global__ void bnact_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const float* __restrict__ res,
+                                   const float* __restrict__ rowscale, float* __restrict__ out, int pix_per_group,
+                                   int HW, int C, int act)
+{
+    const int g = blockIdx.y;
+    const int Q = C >> 2;
+    const int64_t n4 = (int64_t)pix_per_group * Q;
+    const size_t base = (size_t)g * pix_per_group * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int cq = (int)(i % Q);
+        const int64_t pix = i / Q;
+        const size_t o = base + (size_t)i * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + o) * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
+                  *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+        v = act_fwd(v, act);
+        if (rowscale) v = v * rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
+        if (res) v += *reinterpret_cast<const f32x4*>(res + o);
+        *reinterpret_cast<f32x4*>(out + o) = v;
+    }
+}
+void k_bnact_apply(const float* y, const float* scale, const float* shift, const float* res, const float* rowscale,
+                   float* out, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s)
+{
+    const int64_t n4 = (int64_t)pix_per_group * (C / 4);
+    hipLaunchKernelGGL(bnact_apply_kernel, dim3(std::min(2048, cdiv(n4, 256)), groups), dim3(256), 0, s, y, scale,
+                       shift, res, rowscale, out, pix_per_group, HW, C, act);
+}
+
+// ------------------------------------------------------------ channel reductions
+// mode 0: (sum y, sum y^2)                        -> forward BN statistics
+// mode 1: (sum dyh, sum dyh*xhat), dyh = dz * act'(v) * rowscale   -> BN backward sums
+// part layout [groups][nblk][2][C] (what bn_finalize / bn_bwd_finalize consume)
+__global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y,
+                                   const float* __restrict__ mean, const float* __restrict__ istd,
+                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ rowscale, float* __restrict__ part, int pix_per_group,
+                                   int HW, int C, int mode, int act)
+{
+    __shared__ f32x4 red[2][256];
+    const int g = blockIdx.y, nblk = gridDim.x;
+    const int Q = C >> 2;
+    const int QT = Q < 256 ? Q : 256;          // quads handled concurrently
+    const int P = 256 / QT;                    // pixel lanes
+    const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
+    const bool active = pl < P;
+    const int chunk = (pix_per_group + nblk - 1) / nblk;
+    const int pb = blockIdx.x * chunk, pe = min(pix_per_group, pb + chunk);
+    const size_t base = (size_t)g * pix_per_group * C;
+    for (int cq = cq0; cq < Q; cq += QT) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+            if (mode == 1) {
+                mu = *reinterpret_cast<const f32x4*>(mean + g * C + cq * 4);
+                is = *reinterpret_cast<const f32x4*>(istd + g * C + cq * 4);
+                if (act == 2) {
+                    sc = *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4);
+                    sh = *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+                }
+            }
+            for (int p = pb + pl; p < pe; p += P) {
+                const size_t o = base + (size_t)p * C + cq * 4;
+                if (mode == 0) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+                    s1 += v;
+                    s2 += v * v;
+                } else {
+                    f32x4 d = *reinterpret_cast<const f32x4*>(a + o);
+                    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+                    if (act == 2) {
+                        const f32x4 v = yy * sc + sh;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] *= swish_grad(v[k]);
+                    }
+                    if (rowscale) d = d * rowscale[(size_t)g * (pix_per_group / HW) + p / HW];
+                    s1 += d;
+                    s2 += d * ((yy - mu) * is);
+                }
+            }
+        }
+        __syncthreads();
+        if (active) { red[0][pl * QT + cq0] = s1; red[1][pl * QT + cq0] = s2; }
+        __syncthreads();
+        if (pl == 0) {
+            for (int k = 1; k < P; ++k) { s1 += red[0][k * QT + cq0]; s2 += red[1][k * QT + cq0]; }
+            float* o = part + ((size_t)(g * nblk + blockIdx.x) * 2) * C + cq * 4;
+            *reinterpret_cast<f32x4*>(o) = s1;
+            *reinterpret_cast<f32x4*>(o + C) = s2;
+        }
+    }
+}
+void k_chan_reduce(const float* a, const float* y, const float* mean, const float* istd, const float* scale,
+                   const float* shift, const float* rowscale, float* part, int groups, int pix_per_group, int HW,
+                   int C, int mode, int act, hipStream_t s)
+{
+    hipLaunchKernelGGL(chan_reduce_kernel, dim3(bn_bwd_blocks(pix_per_group), groups), dim3(256), 0, s, a, y, mean,
+                       istd, scale, shift, rowscale, part, pix_per_group, HW, C, mode, act);
+}
+
+// dy = ca*dyh + cb*y + cc with dyh = dz * act'(v) * rowscale
+__global__ void bnact_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                       const float* __restrict__ ca, const float* __restrict__ cb,
+                                       const float* __restrict__ cc, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const float* __restrict__ rowscale,
+                                       float* __restrict__ dy, int pix_per_group, int HW, int C, int act)
+{
+    const int g = blockIdx.y;
+    const int Q = C >> 2;
+    const int64_t n4 = (int64_t)pix_per_group * Q;
+    const size_t base = (size_t)g * pix_per_group * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int cq = (int)(i % Q);
+        const int64_t pix = i / Q;
+        const size_t o = base + (size_t)i * 4;
+        f32x4 d = *reinterpret_cast<const f32x4*>(dz + o);
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+        if (act == 2) {
+            const f32x4 v = yy * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
+                            *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] *= swish_grad(v[k]);
+        }
+        if (rowscale) d = d * rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
+        *reinterpret_cast<f32x4*>(dy + o) = *reinterpret_cast<const f32x4*>(ca + g * C + cq * 4) * d +
+                                            *reinterpret_cast<const f32x4*>(cb + g * C + cq * 4) * yy +
+                                            *reinterpret_cast<const f32x4*>(cc + g * C + cq * 4);
+    }
+}
+void k_bnact_bwd_apply(const float* dz, const float* y, const float* ca, const float* cb, const float* cc,
+                       const float* scale, const float* shift, const float* rowscale, float* dy, int groups,
+                       int pix_per_group, int HW, int C, int act, hipStream_t s)
+{
+    const int64_t n4 = (int64_t)pix_per_group * (C / 4);
+    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(std::min(2048, cdiv(n4, 256)), groups), dim3(256), 0, s, dz, y,
+                       ca, cb, cc, scale, shift, rowscale, dy, pix_per_group, HW, C, act);
+}
+
+// ------------------------------------------------------------ depthwise conv ---
+// x [imgs][Hi][Wi][C], w [K*K][C], y [imgs][Ho][Wo][C]; pad_t/pad_l = TF-same top/left padding.
+// Optional fused eval epilogue: y = act(y*scale+shift).
+template <int K>
+__global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                              const float* __restrict__ scale, const float* __restrict__ shift, int imgs, int Hi,
+                              int Wi, int Ho, int Wo, int C, int stride, int pad_t, int pad_l, int act)
+{
+    const int Q = C >> 2;
+    const int64_t n = (int64_t)imgs * Ho * Wo * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int img = (int)(t / Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int ih = oh * stride + kh - pad_t;
+        if ((unsigned)ih >= (unsigned)Hi) continue;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int iw = ow * stride + kw - pad_l;
+            if ((unsigned)iw >= (unsigned)Wi) continue;
+            acc += *reinterpret_cast<const f32x4*>(x + ((size_t)(img * Hi + ih) * Wi + iw) * C + cq * 4) *
+                   *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+        }
+    }
+    if (scale) {
+        acc = acc * *reinterpret_cast<const f32x4*>(scale + cq * 4) + *reinterpret_cast<const f32x4*>(shift + cq * 4);
+        acc = act_fwd(acc, act);
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = acc;
+}
+void k_dw_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift, int imgs, int Hi,
+              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
+{
+    const int64_t n = (int64_t)imgs * Ho * Wo * (C / 4);
+    if (K == 3)
+        hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi,
+                           Ho, Wo, C, stride, pad_t, pad_l, act);
+    else
+        hipLaunchKernelGGL(dw_fwd_kernel<5>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi,
+                           Ho, Wo, C, stride, pad_t, pad_l, act);
+}
+
+template <int K>
+__global__ void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                int imgs, int Hi, int Wi, int Ho, int Wo, int C, int stride, int pad_t, int pad_l)
+{
+    const int Q = C >> 2;
+    const int64_t n = (int64_t)imgs * Hi * Wi * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int iw = (int)(t % Wi); t /= Wi;
+    const int ih = (int)(t % Hi);
+    const int img = (int)(t / Hi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int a = ih + pad_t - kh;
+        if (a < 0 || a % stride) continue;
+        const int oh = a / stride;
+        if (oh >= Ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+            const int b = iw + pad_l - kw;
+            if (b < 0 || b % stride) continue;
+            const int ow = b / stride;
+            if (ow >= Wo) continue;
+            acc += *reinterpret_cast<const f32x4*>(dy + ((size_t)(img * Ho + oh) * Wo + ow) * C + cq * 4) *
+                   *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+        }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+}
+void k_dw_dgrad(const float* dy, const float* w, float* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                int stride, int pad_t, int pad_l, hipStream_t s)
+{
+    const int64_t n = (int64_t)imgs * Hi * Wi * (C / 4);
+    if (K == 3)
+        hipLaunchKernelGGL(dw_dgrad_kernel<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C,
+                           stride, pad_t, pad_l);
+    else
+        hipLaunchKernelGGL(dw_dgrad_kernel<5>, dim3(cdiv(n, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C,
+                           stride, pad_t, pad_l);
+}
+
+// dw[kh][kw][c] = sum over output pixels of dy * x(shifted): each block owns a chunk of output
+// pixels and one tile of 64 channel-quads x 4 pixel lanes; partial [nblk][K*K][C], summed later
+// in a fixed order (reduce_slabs).
+template <int K>
+__global__ void dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                int imgs, int Hi, int Wi, int Ho, int Wo, int C, int stride, int pad_t, int pad_l)
+{
+    __shared__ f32x4 red[4][64];
+    const int Q = C >> 2;
+    const int cq = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    const int npix = imgs * Ho * Wo, nblk = gridDim.x;
+    const int chunk = (npix + nblk - 1) / nblk;
+    const int pb = blockIdx.x * chunk, pe = min(npix, pb + chunk);
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (cq < Q) {
+        for (int p = pb + pl; p < pe; p += 4) {
+            const int img = p / (Ho * Wo);
+            const int rem = p - img * Ho * Wo;
+            const int oh = rem / Wo, ow = rem - oh * Wo;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * C + cq * 4);
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int ih = oh * stride + kh - pad_t;
+                if ((unsigned)ih >= (unsigned)Hi) continue;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const int iw = ow * stride + kw - pad_l;
+                    if ((unsigned)iw >= (unsigned)Wi) continue;
+                    acc[kh * K + kw] += d * *reinterpret_cast<const f32x4*>(x + ((size_t)(img * Hi + ih) * Wi + iw) * C + cq * 4);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        __syncthreads();
+        red[pl][threadIdx.x & 63] = acc[t];
+        __syncthreads();
+        if (pl == 0 && cq < Q) {
+            const f32x4 v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
+        }
+    }
+}
+int dw_wgrad_blocks(int npix) { return std::max(1, std::min(256, npix / 256)); }
+void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                int stride, int pad_t, int pad_l, hipStream_t s)
+{
+    dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), cdiv(C / 4, 64));
+    if (K == 3)
+        hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t,
+                           pad_l);
+    else
+        hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t,
+                           pad_l);
+}
+
+// ------------------------------------------------------------ squeeze-excite ---
+// one block per image: s = mean_hw(a); r_pre = W1 s + b1; g = sigmoid(W2 swish(r_pre) + b2)
+// W1 [Cs][C], W2 [C][Cs].  Stores s [imgs][C], r_pre [imgs][Cs], g [imgs][C].
+__global__ void se_fwd_kernel(const float* __restrict__ a, const float* __restrict__ W1, const float* __restrict__ b1,
+                              const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ sq,
+                              float* __restrict__ rpre, float* __restrict__ gate, int HW, int C, int Cs)
+{
+    extern __shared__ float sm[];            // s[C] then r[Cs]
+    float* s_ = sm;
+    float* r_ = sm + C;
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv = 1.f / (float)HW;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int p = 0; p < HW; ++p) t += a[((size_t)img * HW + p) * C + c];
+        t *= inv;
+        s_[c] = t;
+        sq[(size_t)img * C + c] = t;
+    }
+    __syncthreads();
+    for (int j = wave; j < Cs; j += 4) {
+        float t = 0.f;
+        for (int c = lane; c < C; c += 64) t += W1[(size_t)j * C + c] * s_[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+        if (lane == 0) {
+            t += b1[j];
+            rpre[(size_t)img * Cs + j] = t;
+            r_[j] = t * sigm(t);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = b2[c];
+        for (int j = 0; j < Cs; ++j) t += W2[(size_t)c * Cs + j] * r_[j];
+        gate[(size_t)img * C + c] = sigm(t);
+    }
+}
+void k_se_fwd(const float* a, const float* W1, const float* b1, const float* W2, const float* b2, float* sq,
+              float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s)
+{
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, a, W1, b1, W2, b2, sq, rpre,
+                       gate, HW, C, Cs);
+}
+
+// out = a * gate[img][c]   (+ optional second output: dsum[img][c] left to se_bwd)
+__global__ void se_scale_kernel(const float* __restrict__ a, const float* __restrict__ gate, float* __restrict__ out,
+                                int64_t n4, int HW, int C)
+{
+    const int Q = C >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int cq = (int)(i % Q);
+        const int64_t img = i / Q / HW;
+        *reinterpret_cast<f32x4*>(out + i * 4) =
+            *reinterpret_cast<const f32x4*>(a + i * 4) * *reinterpret_cast<const f32x4*>(gate + img * C + cq * 4);
+    }
+}
+void k_se_scale(const float* a, const float* gate, float* out, int imgs, int HW, int C, hipStream_t s)
+{
+    const int64_t n4 = (int64_t)imgs * HW * (C / 4);
+    hipLaunchKernelGGL(se_scale_kernel, dim3(std::min(4096, cdiv(n4, 256))), dim3(256), 0, s, a, gate, out, n4, HW, C);
+}
+
+// backward, one block per image:  dgs[c] = sum_hw dout*a ; dgp = dgs*g(1-g) ; dr = W2^T dgp ;
+// drp = dr*swish'(r_pre) ; ds = W1^T drp.  Stores dgp [imgs][C], drp [imgs][Cs], ds [imgs][C].
+__global__ void se_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                              const float* __restrict__ gate, const float* __restrict__ rpre,
+                              const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ dgp,
+                              float* __restrict__ drp, float* __restrict__ ds, int HW, int C, int Cs)
+{
+    extern __shared__ float sm[];            // dgp[C] then drp[Cs]
+    float* g_ = sm;
+    float* r_ = sm + C;
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            const size_t o = ((size_t)img * HW + p) * C + c;
+            t += dout[o] * a[o];
+        }
+        const float g = gate[(size_t)img * C + c];
+        t *= g * (1.f - g);
+        g_[c] = t;
+        dgp[(size_t)img * C + c] = t;
+    }
+    __syncthreads();
+    for (int j = wave; j < Cs; j += 4) {
+        float t = 0.f;
+        for (int c = lane; c < C; c += 64) t += W2[(size_t)c * Cs + j] * g_[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+        if (lane == 0) {
+            t *= swish_grad(rpre[(size_t)img * Cs + j]);
+            r_[j] = t;
+            drp[(size_t)img * Cs + j] = t;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int j = 0; j < Cs; ++j) t += W1[(size_t)j * C + c] * r_[j];
+        ds[(size_t)img * C + c] = t;
+    }
+}
+void k_se_bwd(const float* dout, const float* a, const float* gate, const float* rpre, const float* W1,
+              const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs, hipStream_t s)
+{
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, dout, a, gate, rpre, W1, W2,
+                       dgp, drp, ds, HW, C, Cs);
+}
+
+// dW2[c][j] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]
+__global__ void se_wgrad_kernel(const float* __restrict__ dgp, const float* __restrict__ drp,
+                                const float* __restrict__ rpre, const float* __restrict__ sq, float* __restrict__ dW1,
+                                float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2, int imgs,
+                                int C, int Cs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * Cs) return;
+    const int c = i / Cs, j = i - c * Cs;
+    float w2 = 0.f, w1 = 0.f, bb2 = 0.f, bb1 = 0.f;
+    for (int m = 0; m < imgs; ++m) {
+        const float g = dgp[(size_t)m * C + c], rp = rpre[(size_t)m * Cs + j], d = drp[(size_t)m * Cs + j];
+        w2 += g * (rp * sigm(rp));
+        w1 += d * sq[(size_t)m * C + c];
+        bb2 += g;
+        bb1 += d;
+    }
+    dW2[(size_t)c * Cs + j] = w2;
+    dW1[(size_t)j * C + c] = w1;
+    if (j == 0) db2[c] = bb2;
+    if (c == 0) db1[j] = bb1;
+}
+void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
+                float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s)
+{
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv((int64_t)C * Cs, 256)), dim3(256), 0, s, dgp, drp, rpre, sq, dW1, db1,
+                       dW2, db2, imgs, C, Cs);
+}
+
+// d_a = dout*gate + ds/HW
+__global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ gate,
+                                    const float* __restrict__ ds, float* __restrict__ da, int64_t n4, int HW, int C)
+{
+    const int Q = C >> 2;
+    const float inv = 1.f / (float)HW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int cq = (int)(i % Q);
+        const int64_t img = i / Q / HW;
+        *reinterpret_cast<f32x4*>(da + i * 4) =
+            *reinterpret_cast<const f32x4*>(dout + i * 4) * *reinterpret_cast<const f32x4*>(gate + img * C + cq * 4) +
+            *reinterpret_cast<const f32x4*>(ds + img * C + cq * 4) * inv;
+    }
+}
+void k_se_bwd_apply(const float* dout, const float* gate, const float* ds, float* da, int imgs, int HW, int C,
+                    hipStream_t s)
+{
+    const int64_t n4 = (int64_t)imgs * HW * (C / 4);
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(std::min(4096, cdiv(n4, 256))), dim3(256), 0, s, dout, gate, ds, da, n4,
+                       HW, C);
+}
+
+// y = a * b, y += a (elementwise helpers: dropout on the feature, residual-gradient accumulation)
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a[i] * b[i];
+}
+void k_mul(const float* a, const float* b, float* y, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(mul_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, y, n);
+}
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ a, int64_t n4)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<f32x4*>(y)[i] += reinterpret_cast<const f32x4*>(a)[i];
+}
+void k_add_inplace(float* y, const float* a, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(std::min(4096, cdiv(n / 4, 256))), dim3(256), 0, s, y, a, n / 4);
+}

@@ -130,7 +130,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
 {
     __shared__ double red[2][4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int ch = blockIdx.x * 64 + cl;
+    const bool chv = blockIdx.x * 64 + cl < C;             // C need not be a multiple of 64
+    const int ch = chv ? blockIdx.x * 64 + cl : C - 1;
     for (int g = 0; g < groups; ++g) {
         double s1 = 0.0, s2 = 0.0;
         const float* st = stats + (size_t)g * tiles * 2 * C;
@@ -141,7 +142,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
         red[0][sl][cl] = s1;
         red[1][sl][cl] = s2;
         __syncthreads();
-        if (sl == 0) {
+        if (sl == 0 && chv) {
             s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
             s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
             const double n = (double)count;
@@ -196,7 +197,7 @@ void k_bn_finalize(const float* stats, int groups, int tiles, int C, int count, 
         src = folded;
         tiles = 32;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 64), dim3(256), 0, s, src, groups, tiles, C, count, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, src, groups, tiles, C, count, gamma,
                        beta, run_mean, run_var, mean, istd, scale, shift, eps, momentum);
 }
 
@@ -416,7 +417,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int group
 {
     __shared__ double red[2][4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int ch = blockIdx.x * 64 + cl;
+    const bool chv = blockIdx.x * 64 + cl < C;
+    const int ch = chv ? blockIdx.x * 64 + cl : C - 1;
     double dg = 0.0, db = 0.0;
     for (int g = 0; g < groups; ++g) {
         double s1 = 0.0, s2 = 0.0;
@@ -428,7 +430,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int group
         red[0][sl][cl] = s1;
         red[1][sl][cl] = s2;
         __syncthreads();
-        if (sl == 0) {
+        if (sl == 0 && chv) {
             s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
             s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
             const float is = istd[g * C + ch], mu = mean[g * C + ch];
@@ -442,7 +444,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int group
         }
         __syncthreads();
     }
-    if (sl == 0) {
+    if (sl == 0 && chv) {
         dgamma[ch] = (float)dg;
         dbeta[ch] = (float)db;
     }
@@ -458,7 +460,7 @@ void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count
         src = folded;
         nblk = 32;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 64), dim3(256), 0, s, src, groups, nblk, C, count, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, src, groups, nblk, C, count, gamma,
                        mean, istd, ca, cb, cc, dgamma, dbeta);
 }
 

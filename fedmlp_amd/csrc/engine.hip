@@ -1,6 +1,6 @@
-// FedMLP engine: ResNet-18 training/eval graph over the HIP kernels + the C ABI
-// of include/fedmlp_hip.h.  Host code only (kernels live in igemm/wgrad/
-// elementwise/heads.hip).  One engine per process/GPU.
+// FedMLP engine: ResNet-18 and EfficientNet-B0 training/eval graphs over the HIP kernels + the
+// C ABI of include/fedmlp_hip.h.  Host code only (kernels live in igemm/wgrad/elementwise/
+// heads/effnet.hip).  One engine per process/GPU.
 //
 // Data layout in HBM (all fp32):
 //   state   : [conv weights OHWI (stem padded to [64][7][8][4])][fc.W][fc.b][pad]
@@ -9,6 +9,9 @@
 //   activations NHWC; train-mode forward keeps per conv the raw output y, per block
 //   the post-BN/ReLU z1 and the block output; the two views of a FedMLP step are
 //   one batch of 2B images with per-view ("group") BN statistics.
+//   EfficientNet-B0 (model 1): channel counts are padded to multiples of 16 inside the engine
+//   (24->32, 40->48; padded weights/gamma/beta are 0 and stay 0 under Adam, so padded channels
+//   carry exact zeros); depthwise weights are [k*k][C]; squeeze-excite W1 [Cs][C], W2 [C][Cs].
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -52,9 +55,10 @@ struct DgradClass {
 struct Conv {
     int cin, cout, k, stride, pad;
     int cin_p, kw_p;          // padded input channels / kernel width of the engine layout
+    int cout_p;               // rows of the engine weight matrix (= cout for ResNet, padded to 16 for EfficientNet)
     int hin, win, hout, wout;
     size_t w_off;             // offset into the state arena
-    size_t w_numel;           // cout*k*kw_p*cin_p
+    size_t w_numel;           // cout_p*k*kw_p*cin_p
     int Kw;                   // k*kw_p*cin_p  (GEMM K of fwd, N of wgrad)
     int nsteps;               // Kw/16 (igemm K steps)
     int4* tab = nullptr;      // [Kw/4]
@@ -66,7 +70,8 @@ struct Conv {
 };
 
 struct Bn {
-    int C;
+    int C;                    // engine channels (padded)
+    int C_real;               // state_dict channels
     int ch_off;               // channel offset inside the all-BN vectors
     float *mean, *istd, *scale, *shift;   // [2][C] train-mode per-group
 };
@@ -77,12 +82,24 @@ struct Block {
     float* out = nullptr;
 };
 
+struct MBConv {               // EfficientNet block (efficientnet-pytorch MBConvBlock)
+    int k, s, expand, cin, cout, cin_p, ce, ce_p, cout_p, cs;
+    int hin, win, hout, wout, pad_t, pad_l;
+    bool skip;
+    int c_exp = -1, c_proj = -1;          // 1x1 conv indices
+    int bn0 = -1, bn1 = -1, bn2 = -1;
+    size_t dw_off, w1_off, b1_off, w2_off, b2_off;
+    float *a_e = nullptr, *y_d = nullptr, *a_d = nullptr, *a_s = nullptr, *out = nullptr;
+    float *sq = nullptr, *rpre = nullptr, *gate = nullptr;
+};
+
 struct StateEntry {           // one state_dict entry, in reference key order
-    int kind;                 // 0 conv weight, 1 float vector, 2 int64 counter
-    int conv;                 // conv index (kind 0)
-    size_t eng_off;           // engine arena offset (kind 1)
+    int kind;                 // 0 OIHW weight (re-laid out to O,H,W(pad),I(pad)), 1 float vector, 2 int64 counter
+    int conv;                 // conv index (kind 0, -1 for depthwise / squeeze-excite weights)
+    size_t eng_off;           // engine arena offset
     size_t n;                 // elements in state_dict form
     int bn;                   // counter's BN index (kind 2)
+    int O = 0, I = 0, KH = 0, KW = 0, Wpad = 0, Ipad = 0;   // kind 0 geometry
 };
 
 struct EvPair { hipEvent_t a, b; int family; double flops; };
@@ -96,6 +113,14 @@ struct fm_engine {
     std::vector<Conv> convs;
     std::vector<Bn> bns;
     std::vector<Block> blocks;
+    std::vector<MBConv> mbs;
+    int model = 0, c_stem = 0, c_head = -1, bn_stem = 0, bn_head = -1;
+    float bn_eps = 1e-5f, bn_mom = 0.1f;
+    int maxC = 512;                   // widest BN (sizes ca/cb/cc and the partial-sum workspace)
+    float *a0 = nullptr;              // EfficientNet: swish(bn(stem))
+    float *T_small = nullptr, *T_mid = nullptr, *T_big = nullptr;
+    float *se_dgp = nullptr, *se_drp = nullptr, *se_ds = nullptr, *hfeat = nullptr;
+    const float *dc_dev = nullptr, *drop_dev = nullptr;   // caller-owned stochastic multipliers (or null)
     std::vector<StateEntry> entries;
     int n_bn_ch = 0;
     size_t NP = 0, NS = 0;            // trainable floats (padded to 4), whole state floats
@@ -162,14 +187,21 @@ int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hi
 {
     Conv c{};
     c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = pad;
-    c.cin_p = (cin == 3) ? 4 : cin;
+    const bool eff = e->model == 1;
+    c.cin_p = (cin == 3) ? 4 : (eff ? (cin + 15) / 16 * 16 : cin);
+    c.cout_p = eff ? (cout + 15) / 16 * 16 : cout;
     c.kw_p = (cin == 3) ? 8 : k;
     c.hin = hin; c.win = win;
-    c.hout = (hin + 2 * pad - k) / stride + 1;
-    c.wout = (win + 2 * pad - k) / stride + 1;
+    if (eff) {                       // TF-"same": out = ceil(in/stride); pad here = top/left padding
+        c.hout = (hin + stride - 1) / stride;
+        c.wout = (win + stride - 1) / stride;
+    } else {
+        c.hout = (hin + 2 * pad - k) / stride + 1;
+        c.wout = (win + 2 * pad - k) / stride + 1;
+    }
     c.Kw = k * c.kw_p * c.cin_p;
     c.nsteps = c.Kw / 16;
-    c.w_numel = (size_t)cout * c.Kw;
+    c.w_numel = (size_t)c.cout_p * c.Kw;
     c.w_off = off;
     off += c.w_numel;
     c.macs_per_img = (double)c.hout * c.wout * cout * cin * k * k;
@@ -181,7 +213,7 @@ int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hi
 int build_tables(fm_engine* e)
 {
     for (auto& c : e->convs) {
-        if (c.Kw % 32 != 0) { g_err = "conv K not a multiple of 32"; return FM_ERR_ARG; }
+        if (c.Kw % 16 != 0) { g_err = "conv K not a multiple of 16"; return FM_ERR_ARG; }
         // forward / wgrad table: chunk q -> (kh, kw, ci0)
         std::vector<int4> t(c.Kw / 4);
         for (int q = 0; q < c.Kw / 4; ++q) {
@@ -208,9 +240,9 @@ int build_tables(fm_engine* e)
                         d.dw[j] = (pw + c.pad - kw) / s;
                     }
                 if (d.taps.n == 0) continue;
-                const int K = d.taps.n * c.cout;
+                const int K = d.taps.n * c.cout_p;
                 d.nsteps = K / 16;
-                DALLOC(d.wpack, (size_t)c.cin * K);
+                DALLOC(d.wpack, (size_t)c.cin_p * K);
                 c.cls[c.ncls++] = d;
             }
     }
@@ -244,7 +276,7 @@ int build_resnet18(fm_engine* e)
     int ch = 0;
     for (auto& c : e->convs) {
         Bn b{};
-        b.C = c.cout; b.ch_off = ch; ch += c.cout;
+        b.C = c.cout; b.C_real = c.cout; b.ch_off = ch; ch += c.cout;
         e->bns.push_back(b);
     }
     e->n_bn_ch = ch;
@@ -257,7 +289,8 @@ int build_resnet18(fm_engine* e)
     // state_dict entry table (torchvision key order)
     auto push_conv = [&](int ci) {
         const Conv& c = e->convs[ci];
-        e->entries.push_back({0, ci, 0, (size_t)c.cout * c.cin * c.k * c.k, -1});
+        e->entries.push_back({0, ci, c.w_off, (size_t)c.cout * c.cin * c.k * c.k, -1, c.cout, c.cin, c.k, c.k, c.kw_p,
+                              c.cin_p});
     };
     auto push_bn = [&](int bi) {
         const Bn& b = e->bns[bi];
@@ -281,6 +314,115 @@ int build_resnet18(fm_engine* e)
     return FM_OK;
 }
 
+// EfficientNet-B0 (efficientnet-pytorch 0.7.1 'efficientnet-b0', width/depth 1.0): stem 3x3 s2 ->
+// 16 MBConv blocks -> head 1x1 -> pool -> dropout -> fc.  State entries follow the package's
+// state_dict order (fedmlp_amd/spec.py:efficientnet_b0_entries is the host-side mirror).
+int build_effnet_b0(fm_engine* e)
+{
+    static const int stages[7][6] = {{1, 3, 1, 1, 32, 16},  {2, 3, 2, 6, 16, 24},  {2, 5, 2, 6, 24, 40},
+                                     {3, 3, 2, 6, 40, 80},  {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192},
+                                     {1, 3, 1, 6, 192, 320}};
+    e->bn_eps = 1e-3f; e->bn_mom = 0.01f; e->D = 1280;
+    auto r16 = [](int c) { return (c + 15) / 16 * 16; };
+    size_t off = 0;
+    int ch = 0;
+    auto add_bn = [&](int c_real) {
+        Bn b{};
+        b.C = r16(c_real); b.C_real = c_real; b.ch_off = ch; ch += b.C;
+        e->bns.push_back(b);
+        return (int)e->bns.size() - 1;
+    };
+    auto same_pad = [](int size, int k, int s) {
+        const int o = (size + s - 1) / s;
+        const int p = std::max((o - 1) * s + k - size, 0);
+        return p / 2;
+    };
+    int h = e->H, w = e->W;
+    e->c_stem = add_conv(e, 3, 32, 3, 2, same_pad(h, 3, 2), h, w, off);
+    e->bn_stem = add_bn(32);
+    e->convs[e->c_stem].bn = e->bn_stem;
+    h = e->convs[e->c_stem].hout; w = e->convs[e->c_stem].wout;
+    for (int st = 0; st < 7; ++st)
+        for (int r = 0; r < stages[st][0]; ++r) {
+            MBConv m{};
+            m.k = stages[st][1];
+            m.s = r == 0 ? stages[st][2] : 1;
+            m.expand = stages[st][3];
+            m.cin = r == 0 ? stages[st][4] : stages[st][5];
+            m.cout = stages[st][5];
+            m.cin_p = r16(m.cin); m.ce = m.cin * m.expand; m.ce_p = r16(m.ce); m.cout_p = r16(m.cout);
+            m.cs = std::max(1, m.cin / 4);
+            m.hin = h; m.win = w;
+            m.hout = (h + m.s - 1) / m.s; m.wout = (w + m.s - 1) / m.s;
+            m.pad_t = same_pad(h, m.k, m.s); m.pad_l = same_pad(w, m.k, m.s);
+            m.skip = m.s == 1 && m.cin == m.cout;
+            if (m.expand != 1) {
+                m.c_exp = add_conv(e, m.cin, m.ce, 1, 1, 0, h, w, off);
+                m.bn0 = add_bn(m.ce);
+                e->convs[m.c_exp].bn = m.bn0;
+            }
+            m.dw_off = off; off += (size_t)m.k * m.k * m.ce_p;
+            m.bn1 = add_bn(m.ce);
+            m.w1_off = off; off += (size_t)m.cs * m.ce_p;
+            m.b1_off = off; off += (size_t)(m.cs + 3) / 4 * 4;
+            m.w2_off = off; off += (size_t)m.ce_p * m.cs;
+            m.b2_off = off; off += m.ce_p;
+            off = (off + 3) & ~(size_t)3;
+            m.c_proj = add_conv(e, m.ce, m.cout, 1, 1, 0, m.hout, m.wout, off);
+            m.bn2 = add_bn(m.cout);
+            e->convs[m.c_proj].bn = m.bn2;
+            e->mbs.push_back(m);
+            h = m.hout; w = m.wout;
+        }
+    e->c_head = add_conv(e, 320, 1280, 1, 1, 0, h, w, off);
+    e->bn_head = add_bn(1280);
+    e->convs[e->c_head].bn = e->bn_head;
+    e->off_fcw = off; off += (size_t)e->C * 1280;
+    e->off_fcb = off; off += e->C;
+    off = (off + 3) & ~(size_t)3;
+    e->n_bn_ch = ch;
+    e->off_gamma = off; off += ch;
+    e->off_beta = off; off += ch;
+    e->NP = off;
+    e->off_rm = off; off += ch;
+    e->off_rv = off; off += ch;
+    e->NS = off;
+    e->maxC = 1280;
+    // ---- state_dict entries ----------------------------------------------------------------
+    auto push_conv = [&](int ci) {
+        const Conv& c = e->convs[ci];
+        e->entries.push_back({0, ci, c.w_off, (size_t)c.cout * c.cin * c.k * c.k, -1, c.cout, c.cin, c.k, c.k, c.kw_p,
+                              c.cin_p});
+    };
+    auto push_bn = [&](int bi) {
+        const Bn& b = e->bns[bi];
+        e->entries.push_back({1, -1, e->off_gamma + b.ch_off, (size_t)b.C_real, -1});
+        e->entries.push_back({1, -1, e->off_beta + b.ch_off, (size_t)b.C_real, -1});
+        e->entries.push_back({1, -1, e->off_rm + b.ch_off, (size_t)b.C_real, -1});
+        e->entries.push_back({1, -1, e->off_rv + b.ch_off, (size_t)b.C_real, -1});
+        e->entries.push_back({2, -1, 0, 1, bi});
+    };
+    push_conv(e->c_stem); push_bn(e->bn_stem);
+    for (auto& m : e->mbs) {
+        if (m.c_exp >= 0) { push_conv(m.c_exp); push_bn(m.bn0); }
+        // depthwise [ce][1][k][k] -> [k][k][ce_p]: an OIHW->OHWI re-layout with O=1, I=ce
+        e->entries.push_back({0, -1, m.dw_off, (size_t)m.ce * m.k * m.k, -1, 1, m.ce, m.k, m.k, m.k, m.ce_p});
+        push_bn(m.bn1);
+        e->entries.push_back({0, -1, m.w1_off, (size_t)m.cs * m.ce, -1, m.cs, m.ce, 1, 1, 1, m.ce_p});
+        e->entries.push_back({1, -1, m.b1_off, (size_t)m.cs, -1});
+        e->entries.push_back({1, -1, m.w2_off, (size_t)m.ce * m.cs, -1});     // [ce][cs]: rows past ce stay 0
+        e->entries.push_back({1, -1, m.b2_off, (size_t)m.ce, -1});
+        push_conv(m.c_proj); push_bn(m.bn2);
+    }
+    push_conv(e->c_head); push_bn(e->bn_head);
+    e->entries.push_back({1, -1, e->off_fcw, (size_t)e->C * 1280, -1});
+    e->entries.push_back({1, -1, e->off_fcb, (size_t)e->C, -1});
+    e->nf_sd = 0; e->ni_sd = 0;
+    for (auto& en : e->entries) (en.kind == 2 ? e->ni_sd : e->nf_sd) += (int64_t)en.n;
+    e->counters.assign(e->bns.size(), 0);
+    return FM_OK;
+}
+
 int alloc_workspaces(fm_engine* e)
 {
     const size_t B = e->maxB;
@@ -295,32 +437,55 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->x4, B * e->H * e->W * 4);
     size_t max_stats = 0, max_slab = 0;
     for (auto& c : e->convs) {
-        DALLOC(c.y, B * c.hout * c.wout * c.cout);
-        const size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout) - 1) / igemm_tile_n(c.cout) + 2;
-        max_stats = std::max(max_stats, (tiles + 2 * 32) * 2 * c.cout);   // + folded partials
+        DALLOC(c.y, B * c.hout * c.wout * c.cout_p);
+        const size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout_p) - 1) / igemm_tile_n(c.cout_p) + 2;
+        max_stats = std::max(max_stats, (tiles + 2 * 32) * 2 * c.cout_p);   // + folded partials
         max_slab = std::max(max_slab, c.w_numel);
     }
     for (auto& b : e->bns) {
         DALLOC(b.mean, 2 * b.C); DALLOC(b.istd, 2 * b.C); DALLOC(b.scale, 2 * b.C); DALLOC(b.shift, 2 * b.C);
     }
     const Conv& c0 = e->convs[0];
-    const size_t pooled = B * (c0.hout / 2) * (c0.wout / 2) * 64;
-    DALLOC(e->p0, pooled); DALLOC(e->idx0, pooled);
-    DALLOC(e->dyh0, B * c0.hout * c0.wout * 64);
-    for (auto& blk : e->blocks) {
-        const Conv& c = e->convs[blk.c1];
-        const size_t n = B * c.hout * c.wout * c.cout;
-        DALLOC(blk.z1, n); DALLOC(blk.out, n);
+    if (e->model == 0) {
+        const size_t pooled = B * (c0.hout / 2) * (c0.wout / 2) * 64;
+        DALLOC(e->p0, pooled); DALLOC(e->idx0, pooled);
+        DALLOC(e->dyh0, B * c0.hout * c0.wout * 64);
+        for (auto& blk : e->blocks) {
+            const Conv& c = e->convs[blk.c1];
+            const size_t n = B * c.hout * c.wout * c.cout;
+            DALLOC(blk.z1, n); DALLOC(blk.out, n);
+        }
+        DALLOC(e->GA, pooled); DALLOC(e->GB, pooled); DALLOC(e->GC, pooled); DALLOC(e->GD, pooled); DALLOC(e->GE, pooled);
+    } else {
+        size_t g_io = B * c0.hout * c0.wout * c0.cout_p, t_small = 0, t_mid = 0, t_big = 0, max_ce = 0, max_cs = 0;
+        DALLOC(e->a0, g_io);
+        for (auto& m : e->mbs) {
+            const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
+            if (m.c_exp >= 0) DALLOC(m.a_e, nin * m.ce_p);
+            DALLOC(m.y_d, nout * m.ce_p); DALLOC(m.a_d, nout * m.ce_p); DALLOC(m.a_s, nout * m.ce_p);
+            DALLOC(m.out, nout * m.cout_p);
+            DALLOC(m.sq, B * m.ce_p); DALLOC(m.rpre, B * m.cs); DALLOC(m.gate, B * m.ce_p);
+            g_io = std::max(g_io, std::max(nin * m.cin_p, nout * m.cout_p));
+            t_small = std::max(t_small, nout * m.cout_p);
+            t_mid = std::max(t_mid, nout * m.ce_p);
+            t_big = std::max(t_big, nin * m.ce_p);
+            max_ce = std::max<size_t>(max_ce, m.ce_p); max_cs = std::max<size_t>(max_cs, m.cs);
+        }
+        const Conv& chd = e->convs[e->c_head];
+        t_mid = std::max(t_mid, B * chd.hout * chd.wout * chd.cout_p);
+        DALLOC(e->GA, g_io); DALLOC(e->GB, g_io);
+        DALLOC(e->T_small, t_small); DALLOC(e->T_mid, t_mid); DALLOC(e->T_big, t_big);
+        DALLOC(e->se_dgp, B * max_ce); DALLOC(e->se_drp, B * max_cs); DALLOC(e->se_ds, B * max_ce);
+        DALLOC(e->hfeat, B * e->D);
     }
-    DALLOC(e->GA, pooled); DALLOC(e->GB, pooled); DALLOC(e->GC, pooled); DALLOC(e->GD, pooled); DALLOC(e->GE, pooled);
     DALLOC(e->ws_stats, max_stats);
-    DALLOC(e->ws_part, (size_t)2 * (256 + 32) * 2 * 512);   // per-block partials + folded partials
+    DALLOC(e->ws_part, (size_t)2 * (256 + 32) * 2 * e->maxC);   // per-block partials + folded partials
     e->slab_floats = std::max<size_t>(max_slab * 8, (size_t)48 << 20);   // >= 192 MB of partial slabs
     DALLOC(e->ws_slab, e->slab_floats);
-    DALLOC(e->ca, 2 * 512); DALLOC(e->cb, 2 * 512); DALLOC(e->cc, 2 * 512);
-    DALLOC(e->feat, B * 512); DALLOC(e->tfeat, B * 512);
+    DALLOC(e->ca, 2 * e->maxC); DALLOC(e->cb, 2 * e->maxC); DALLOC(e->cc, 2 * e->maxC);
+    DALLOC(e->feat, B * e->D); DALLOC(e->tfeat, B * e->D);
     DALLOC(e->logits, B * e->C); DALLOC(e->tlogits, B * e->C); DALLOC(e->dlogits, B * e->C);
-    DALLOC(e->psum, (size_t)2 * e->C * 512); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
+    DALLOC(e->psum, (size_t)2 * e->C * e->D); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
     DALLOC(e->sel_counts, 2); DALLOC(e->cls_dev, FM_MAX_CLASSES);
     DALLOC(e->zeros, 64);
     DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);   // [blocks][2][BM*BN]
@@ -362,24 +527,24 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
     }
     p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
-    p.M = c.cout; p.nsteps = c.nsteps;
+    p.M = c.cout_p; p.nsteps = c.nsteps;
     p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
     p.Hg = c.hout; p.Wg = c.wout; p.sg = c.stride;
-    p.Ho = c.hout; p.Wo = c.wout; p.Co = c.cout;
+    p.Ho = c.hout; p.Wo = c.wout; p.Co = c.cout_p;
     p.os = 1; p.oh0 = 0; p.ow0 = 0;
     p.imgs_per_group = imgs / groups;
-    p.tilesM = c.cout / igemm_tile_m(c.cout);
-    const int bn = igemm_tile_n(c.cout);
+    p.tilesM = (c.cout_p + igemm_tile_m(c.cout_p) - 1) / igemm_tile_m(c.cout_p);
+    const int bn = igemm_tile_n(c.cout_p);
     p.tilesN = (p.imgs_per_group * c.hout * c.wout + bn - 1) / bn;
-    p.relu = relu;
-    ProfScope ps(e, c.cout >= 128 ? 0 : (c.cin == 3 ? 2 : 1), 2.0 * c.macs_per_img * imgs);
+    p.relu = relu;           // 0 none, 1 relu, 2 swish
+    ProfScope ps(e, c.cin == 3 ? 2 : (c.cout_p >= 128 ? 0 : 1), 2.0 * c.macs_per_img * imgs);
     launch_igemm(p, groups, e->st);
 }
 
 int stats_tiles(fm_engine* e, int ci, int imgs_per_group)
 {
     const Conv& c = e->convs[ci];
-    const int bn = igemm_tile_n(c.cout);
+    const int bn = igemm_tile_n(c.cout_p);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
 
@@ -391,25 +556,25 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
     Conv& c = e->convs[ci];
     for (int k = 0; k < c.ncls; ++k) {
         DgradClass& d = c.cls[k];
-        k_pack_dgrad(S + c.w_off, d.wpack, c.cout, c.k * c.k, c.cin, d.taps, e->st);
+        k_pack_dgrad(S + c.w_off, d.wpack, c.cout_p, c.k * c.k, c.cin_p, d.taps, e->st);
         IgemmParams p{};
         p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
         p.ntaps = d.taps.n;
         for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
         p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
-        p.M = c.cin; p.nsteps = d.nsteps;
-        p.Hi = c.hout; p.Wi = c.wout; p.Ci = c.cout;
+        p.M = c.cin_p; p.nsteps = d.nsteps;
+        p.Hi = c.hout; p.Wi = c.wout; p.Ci = c.cout_p;
         p.Hg = (c.hin - d.ph + c.stride - 1) / c.stride;
         p.Wg = (c.win - d.pw + c.stride - 1) / c.stride;
         p.sg = 1;
-        p.Ho = c.hin; p.Wo = c.win; p.Co = c.cin;
+        p.Ho = c.hin; p.Wo = c.win; p.Co = c.cin_p;
         p.os = c.stride; p.oh0 = d.ph; p.ow0 = d.pw;
         p.imgs_per_group = imgs;
-        p.tilesM = c.cin / igemm_tile_m(c.cin);
-        const int bn = igemm_tile_n(c.cin);
+        p.tilesM = (c.cin_p + igemm_tile_m(c.cin_p) - 1) / igemm_tile_m(c.cin_p);
+        const int bn = igemm_tile_n(c.cin_p);
         p.tilesN = (imgs * p.Hg * p.Wg + bn - 1) / bn;
         p.relu = 0;
-        ProfScope ps(e, c.cin >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
+        ProfScope ps(e, c.cin_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
         launch_igemm(p, 1, e->st);
     }
 }
@@ -419,11 +584,11 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     const Conv& c = e->convs[ci];
     WgradParams p{};
     p.dY = dy; p.X = x; p.slab = e->ws_slab; p.tab = c.tab; p.zeros = e->zeros;
-    p.M = c.cout; p.Nw = c.Kw;
+    p.M = c.cout_p; p.Nw = c.Kw;
     p.Ho = c.hout; p.Wo = c.wout; p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p; p.stride = c.stride;
     p.npix = imgs * c.hout * c.wout;
-    const int bm = c.cout >= 128 ? 128 : 64, bn = c.cout >= 128 ? 128 : 256;
-    p.tilesM = c.cout / bm;
+    const int bm = c.cout_p >= 128 ? 128 : 64, bn = c.cout_p >= 128 ? 128 : 256;
+    p.tilesM = (c.cout_p + bm - 1) / bm;
     p.tilesN = (c.Kw + bn - 1) / bn;
     const int tiles = p.tilesM * p.tilesN;
     int splits = std::max(1, 1024 / tiles);           // tiles*splits <= 1024 = 2 full rounds of 512 block slots
@@ -433,20 +598,22 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     p.pix_per_split = (((p.npix + splits - 1) / splits) + 31) & ~31;
     splits = (p.npix + p.pix_per_split - 1) / p.pix_per_split;
     {
-        ProfScope ps(e, c.cout >= 128 ? 3 : 4, 2.0 * c.macs_per_img * imgs);
+        ProfScope ps(e, c.cout_p >= 128 ? 3 : 4, 2.0 * c.macs_per_img * imgs);
         launch_wgrad(p, splits, e->st);
     }
     k_reduce_slabs(e->ws_slab, e->grad + c.w_off, splits, (int64_t)c.w_numel, e->st);
 }
 
-void bn_fwd_finalize(fm_engine* e, int bi, int groups, int imgs_per_group)
+// BN statistics of conv `ci`'s output (partials left in ws_stats by the conv epilogue)
+void bn_fwd_finalize(fm_engine* e, int ci, int groups, int imgs_per_group)
 {
-    const Conv& c = e->convs[bi];
+    const Conv& c = e->convs[ci];
+    const int bi = c.bn;
     Bn& b = e->bns[bi];
-    k_bn_finalize(e->ws_stats, groups, stats_tiles(e, bi, imgs_per_group), b.C, imgs_per_group * c.hout * c.wout,
+    k_bn_finalize(e->ws_stats, groups, stats_tiles(e, ci, imgs_per_group), b.C, imgs_per_group * c.hout * c.wout,
                   e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
                   e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale,
-                  b.shift, 1e-5f, 0.1f, e->st);
+                  b.shift, e->bn_eps, e->bn_mom, e->st);
     e->counters[bi] += groups;
 }
 
@@ -514,7 +681,7 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
 {
     if (dirty) {
         k_bn_eval_affine(S + e->off_gamma, S + e->off_beta, S + e->off_rm, S + e->off_rv, evs, evh, e->n_bn_ch,
-                         1e-5f, e->st);
+                         e->bn_eps, e->st);
         dirty = false;
     }
     auto sc = [&](int bi) { return evs + e->bns[bi].ch_off; };
@@ -545,8 +712,8 @@ void backward_and_step(fm_engine* e, int groups, int B)
     const int imgs = groups * B;
     const float* S = e->state;
     const Conv& cl = e->convs[e->blocks.back().c2];
-    k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, imgs, 512,
-             e->C, cl.hout * cl.wout, e->st);
+    k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, nullptr, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, imgs,
+             512, e->C, cl.hout * cl.wout, e->st);
     float *ga = e->GA, *ge = e->GE;
     for (int b = (int)e->blocks.size() - 1; b >= 0; --b) {
         Block& blk = e->blocks[b];
@@ -580,6 +747,220 @@ void backward_and_step(fm_engine* e, int groups, int B)
     e->ev_dirty = true;
 }
 
+// =============================== EfficientNet-B0 graph =================================
+// BN over an arbitrary NHWC tensor (depthwise output): statistics by chan_reduce, then the same finalize
+void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per_group, int HW)
+{
+    Bn& b = e->bns[bi];
+    k_chan_reduce(nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr, e->ws_part, groups, pix_per_group, HW, b.C,
+                  0, 0, e->st);
+    k_bn_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
+                  e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
+                  e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale, b.shift,
+                  e->bn_eps, e->bn_mom, e->st);
+    e->counters[bi] += groups;
+}
+
+// backward through act(bn(y))*rowscale: dz -> dy (may alias dz); writes dgamma/dbeta
+void bnact_bwd(fm_engine* e, int bi, const float* dz, const float* y, float* dy, const float* rowscale, int groups,
+               int pix_per_group, int HW, int act)
+{
+    Bn& b = e->bns[bi];
+    k_chan_reduce(dz, y, b.mean, b.istd, b.scale, b.shift, rowscale, e->ws_part, groups, pix_per_group, HW, b.C, 1,
+                  act, e->st);
+    k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
+                      e->state + e->off_gamma + b.ch_off, b.mean, b.istd, e->ca, e->cb, e->cc,
+                      e->grad + e->off_gamma + b.ch_off, e->grad + e->off_beta + b.ch_off, e->st);
+    k_bnact_bwd_apply(dz, y, e->ca, e->cb, e->cc, b.scale, b.shift, rowscale, dy, groups, pix_per_group, HW, b.C, act,
+                      e->st);
+}
+
+void eff_forward_train(fm_engine* e, int groups, int B)
+{
+    const int imgs = groups * B;
+    const float* S = e->state;
+    Conv& cs = e->convs[e->c_stem];
+    conv_fwd(e, e->c_stem, S, e->x4, cs.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+    bn_fwd_finalize(e, e->c_stem, groups, B);
+    {
+        Bn& b = e->bns[e->bn_stem];
+        k_bnact_apply(cs.y, b.scale, b.shift, nullptr, nullptr, e->a0, groups, B * cs.hout * cs.wout,
+                      cs.hout * cs.wout, b.C, 2, e->st);
+    }
+    const float* cur = e->a0;
+    for (size_t i = 0; i < e->mbs.size(); ++i) {
+        MBConv& m = e->mbs[i];
+        const int HWi = m.hin * m.win, HWo = m.hout * m.wout;
+        const float* a_e = cur;
+        if (m.c_exp >= 0) {
+            Conv& ce = e->convs[m.c_exp];
+            conv_fwd(e, m.c_exp, S, cur, ce.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+            bn_fwd_finalize(e, m.c_exp, groups, B);
+            Bn& b = e->bns[m.bn0];
+            k_bnact_apply(ce.y, b.scale, b.shift, nullptr, nullptr, m.a_e, groups, B * HWi, HWi, b.C, 2, e->st);
+            a_e = m.a_e;
+        }
+        k_dw_fwd(a_e, S + m.dw_off, m.y_d, nullptr, nullptr, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                 m.pad_t, m.pad_l, 0, e->st);
+        bn_fwd_tensor(e, m.bn1, m.y_d, groups, B * HWo, HWo);
+        {
+            Bn& b = e->bns[m.bn1];
+            k_bnact_apply(m.y_d, b.scale, b.shift, nullptr, nullptr, m.a_d, groups, B * HWo, HWo, b.C, 2, e->st);
+        }
+        k_se_fwd(m.a_d, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
+                 m.ce_p, m.cs, e->st);
+        k_se_scale(m.a_d, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
+        Conv& cp = e->convs[m.c_proj];
+        conv_fwd(e, m.c_proj, S, m.a_s, cp.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+        bn_fwd_finalize(e, m.c_proj, groups, B);
+        {
+            Bn& b = e->bns[m.bn2];
+            const float* dc = (m.skip && e->dc_dev) ? e->dc_dev + i * (size_t)imgs : nullptr;
+            k_bnact_apply(cp.y, b.scale, b.shift, m.skip ? cur : nullptr, dc, m.out, groups, B * HWo, HWo, b.C, 0,
+                          e->st);
+        }
+        cur = m.out;
+    }
+    Conv& ch = e->convs[e->c_head];
+    const int HWh = ch.hout * ch.wout;
+    conv_fwd(e, e->c_head, S, cur, ch.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+    bn_fwd_finalize(e, e->c_head, groups, B);
+    {
+        Bn& b = e->bns[e->bn_head];
+        k_bnact_apply(ch.y, b.scale, b.shift, nullptr, nullptr, e->T_mid, groups, B * HWh, HWh, b.C, 2, e->st);
+    }
+    k_avgpool(e->T_mid, e->feat, imgs, HWh, e->D, e->st);
+    const float* h = e->feat;
+    if (e->drop_dev) {
+        k_mul(e->feat, e->drop_dev, e->hfeat, (int64_t)imgs * e->D, e->st);
+        h = e->hfeat;
+    }
+    k_fc_fwd(h, S + e->off_fcw, S + e->off_fcb, e->logits, imgs, e->D, e->C, e->st);
+    e->ev_dirty = true;
+}
+
+void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& dirty, int imgs, float* feat,
+                      float* logits)
+{
+    if (dirty) {
+        k_bn_eval_affine(S + e->off_gamma, S + e->off_beta, S + e->off_rm, S + e->off_rv, evs, evh, e->n_bn_ch,
+                         e->bn_eps, e->st);
+        dirty = false;
+    }
+    auto sc = [&](int bi) { return evs + e->bns[bi].ch_off; };
+    auto sh = [&](int bi) { return evh + e->bns[bi].ch_off; };
+    conv_fwd(e, e->c_stem, S, e->x4, e->a0, imgs, 1, sc(e->bn_stem), sh(e->bn_stem), nullptr, 2, nullptr);
+    const float* cur = e->a0;
+    for (auto& m : e->mbs) {
+        const int HWo = m.hout * m.wout;
+        const float* a_e = cur;
+        if (m.c_exp >= 0) {
+            conv_fwd(e, m.c_exp, S, cur, m.a_e, imgs, 1, sc(m.bn0), sh(m.bn0), nullptr, 2, nullptr);
+            a_e = m.a_e;
+        }
+        k_dw_fwd(a_e, S + m.dw_off, m.a_d, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                 m.pad_t, m.pad_l, 2, e->st);
+        k_se_fwd(m.a_d, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
+                 m.ce_p, m.cs, e->st);
+        k_se_scale(m.a_d, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
+        conv_fwd(e, m.c_proj, S, m.a_s, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr);
+        cur = m.out;
+    }
+    Conv& ch = e->convs[e->c_head];
+    conv_fwd(e, e->c_head, S, cur, e->T_mid, imgs, 1, sc(e->bn_head), sh(e->bn_head), nullptr, 2, nullptr);
+    k_avgpool(e->T_mid, feat, imgs, ch.hout * ch.wout, e->D, e->st);
+    k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, e->D, e->C, e->st);
+}
+
+void adam_step(fm_engine* e)
+{
+    e->adam_t += 1;
+    const double bc1 = 1.0 - pow((double)e->hp.beta1, (double)e->adam_t);
+    const double bc2 = 1.0 - pow((double)e->hp.beta2, (double)e->adam_t);
+    k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
+           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
+    e->ev_dirty = true;
+}
+
+void eff_backward_and_step(fm_engine* e, int groups, int B)
+{
+    const int imgs = groups * B;
+    const float* S = e->state;
+    float* G = e->grad;
+    Conv& ch = e->convs[e->c_head];
+    const int HWh = ch.hout * ch.wout;
+    const float* h = e->drop_dev ? e->hfeat : e->feat;
+    k_fc_bwd(e->dlogits, h, S + e->off_fcw, e->drop_dev, G + e->off_fcw, G + e->off_fcb, e->T_mid, imgs, e->D, e->C,
+             HWh, e->st);
+    bnact_bwd(e, e->bn_head, e->T_mid, ch.y, e->T_mid, nullptr, groups, B * HWh, HWh, 2);
+    conv_wgrad(e, e->c_head, e->mbs.back().out, e->T_mid, imgs);
+    float *go = e->GA, *gi = e->GB;
+    conv_dgrad(e, e->c_head, S, e->T_mid, go, imgs, nullptr, false);
+    for (int i = (int)e->mbs.size() - 1; i >= 0; --i) {
+        MBConv& m = e->mbs[i];
+        const float* in = i == 0 ? e->a0 : e->mbs[i - 1].out;
+        const int HWi = m.hin * m.win, HWo = m.hout * m.wout;
+        Conv& cp = e->convs[m.c_proj];
+        const float* dc = (m.skip && e->dc_dev) ? e->dc_dev + (size_t)i * imgs : nullptr;
+        // out = bn2(y_p)*dc + in
+        bnact_bwd(e, m.bn2, go, cp.y, e->T_small, dc, groups, B * HWo, HWo, 0);
+        conv_wgrad(e, m.c_proj, m.a_s, e->T_small, imgs);
+        conv_dgrad(e, m.c_proj, S, e->T_small, e->T_mid, imgs, nullptr, false);          // d a_s
+        // a_s = a_d * gate(a_d)
+        k_se_bwd(e->T_mid, m.a_d, m.gate, m.rpre, S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, imgs,
+                 HWo, m.ce_p, m.cs, e->st);
+        k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, G + m.w1_off, G + m.b1_off, G + m.w2_off, G + m.b2_off, imgs,
+                   m.ce_p, m.cs, e->st);
+        k_se_bwd_apply(e->T_mid, m.gate, e->se_ds, e->T_mid, imgs, HWo, m.ce_p, e->st);  // d a_d
+        bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2);   // d y_d
+        const float* a_e = m.c_exp >= 0 ? m.a_e : in;
+        const int nb = dw_wgrad_blocks(imgs * HWo);
+        k_dw_wgrad(e->T_mid, a_e, e->ws_slab, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t, m.pad_l,
+                   e->st);
+        k_reduce_slabs(e->ws_slab, G + m.dw_off, nb, (int64_t)m.k * m.k * m.ce_p, e->st);
+        if (m.c_exp >= 0) {
+            Conv& ce = e->convs[m.c_exp];
+            k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
+                       m.pad_l, e->st);                                                   // d a_e
+            bnact_bwd(e, m.bn0, e->T_big, ce.y, e->T_big, nullptr, groups, B * HWi, HWi, 2);
+            conv_wgrad(e, m.c_exp, in, e->T_big, imgs);
+            conv_dgrad(e, m.c_exp, S, e->T_big, gi, imgs, m.skip ? go : nullptr, false);
+        } else {
+            k_dw_dgrad(e->T_mid, S + m.dw_off, gi, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
+                       m.pad_l, e->st);
+            if (m.skip) k_add_inplace(gi, go, (int64_t)imgs * HWi * m.cin_p, e->st);
+        }
+        std::swap(go, gi);
+    }
+    Conv& cs = e->convs[e->c_stem];
+    bnact_bwd(e, e->bn_stem, go, cs.y, go, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2);
+    conv_wgrad(e, e->c_stem, e->x4, go, imgs);
+    adam_step(e);
+}
+
+// model dispatch
+void net_forward_train(fm_engine* e, int groups, int B)
+{
+    if (e->model == 1) eff_forward_train(e, groups, B);
+    else forward_train(e, groups, B);
+}
+void net_forward_eval(fm_engine* e, bool teacher, int imgs)
+{
+    const float* S = teacher ? e->tstate : e->state;
+    float* evs = teacher ? e->tev_scale : e->ev_scale;
+    float* evh = teacher ? e->tev_shift : e->ev_shift;
+    bool& dirty = teacher ? e->tev_dirty : e->ev_dirty;
+    float* feat = teacher ? e->tfeat : e->feat;
+    float* logits = teacher ? e->tlogits : e->logits;
+    if (e->model == 1) eff_forward_eval(e, S, evs, evh, dirty, imgs, feat, logits);
+    else forward_eval(e, S, evs, evh, dirty, imgs, feat, logits);
+}
+void net_backward_and_step(fm_engine* e, int groups, int B)
+{
+    if (e->model == 1) eff_backward_and_step(e, groups, B);
+    else backward_and_step(e, groups, B);
+}
+
 ClassVec to_cv(const float* h, int C)
 {
     ClassVec v{};
@@ -595,7 +976,7 @@ extern "C" {
 int fm_create(const fm_config* cfg, fm_engine** out)
 {
     ARGCHK(cfg && out, "null cfg/out");
-    ARGCHK(cfg->model == 0, "only model 0 (ResNet-18) is built");
+    ARGCHK(cfg->model == 0 || cfg->model == 1, "model must be 0 (ResNet-18) or 1 (EfficientNet-B0)");
     ARGCHK(cfg->n_classes >= 1 && cfg->n_classes <= FM_MAX_CLASSES, "n_classes out of range");
     ARGCHK(cfg->in_h >= 32 && cfg->in_w >= 32 && cfg->in_h % 32 == 0 && cfg->in_w % 32 == 0,
            "in_h/in_w must be multiples of 32");
@@ -604,7 +985,8 @@ int fm_create(const fm_config* cfg, fm_engine** out)
     e->cfg = *cfg;
     e->st = reinterpret_cast<hipStream_t>(cfg->stream);
     e->C = cfg->n_classes; e->H = cfg->in_h; e->W = cfg->in_w; e->maxB = cfg->max_images;
-    int rc = build_resnet18(e);
+    e->model = cfg->model;
+    int rc = e->model == 1 ? build_effnet_b0(e) : build_resnet18(e);
     if (rc == FM_OK) rc = build_tables(e);
     if (rc == FM_OK) rc = alloc_workspaces(e);
     if (rc != FM_OK) { fm_destroy(e); return rc; }
@@ -647,8 +1029,7 @@ int fm_set_state(fm_engine* e, const float* host_f32, const int64_t* host_i64)
     int ic = 0;
     for (auto& en : e->entries) {
         if (en.kind == 0) {
-            const Conv& c = e->convs[en.conv];
-            k_oihw_to_ohwi(e->stage_sd + off, e->state + c.w_off, c.cout, c.cin, c.k, c.k, c.kw_p, c.cin_p, e->st);
+            k_oihw_to_ohwi(e->stage_sd + off, e->state + en.eng_off, en.O, en.I, en.KH, en.KW, en.Wpad, en.Ipad, e->st);
             off += en.n;
         } else if (en.kind == 1) {
             HIPCHK(hipMemcpyAsync(e->state + en.eng_off, e->stage_sd + off, en.n * 4, hipMemcpyDeviceToDevice, e->st));
@@ -670,8 +1051,7 @@ int fm_get_state(fm_engine* e, float* host_f32, int64_t* host_i64)
     int ic = 0;
     for (auto& en : e->entries) {
         if (en.kind == 0) {
-            const Conv& c = e->convs[en.conv];
-            k_ohwi_to_oihw(e->state + c.w_off, e->stage_sd + off, c.cout, c.cin, c.k, c.k, c.kw_p, c.cin_p, e->st);
+            k_ohwi_to_oihw(e->state + en.eng_off, e->stage_sd + off, en.O, en.I, en.KH, en.KW, en.Wpad, en.Ipad, e->st);
             off += en.n;
         } else if (en.kind == 1) {
             HIPCHK(hipMemcpyAsync(e->stage_sd + off, e->state + en.eng_off, en.n * 4, hipMemcpyDeviceToDevice, e->st));
@@ -741,12 +1121,9 @@ int fm_forward_eval(fm_engine* e, const float* x_dev, int32_t B, int32_t use_tea
     ARGCHK(B >= 1 && B <= e->maxB, "B exceeds max_images");
     const float* xs[1] = {x_dev};
     to_nhwc4(e, xs, 1, B);
-    if (use_teacher)
-        forward_eval(e, e->tstate, e->tev_scale, e->tev_shift, e->tev_dirty, B, e->tfeat, e->tlogits);
-    else
-        forward_eval(e, e->state, e->ev_scale, e->ev_shift, e->ev_dirty, B, e->feat, e->logits);
+    net_forward_eval(e, use_teacher != 0, B);
     if (feat_dev)
-        HIPCHK(hipMemcpyAsync(feat_dev, use_teacher ? e->tfeat : e->feat, (size_t)B * 512 * 4,
+        HIPCHK(hipMemcpyAsync(feat_dev, use_teacher ? e->tfeat : e->feat, (size_t)B * e->D * 4,
                               hipMemcpyDeviceToDevice, e->st));
     if (logits_dev)
         HIPCHK(hipMemcpyAsync(logits_dev, use_teacher ? e->tlogits : e->logits, (size_t)B * e->C * 4,
@@ -761,10 +1138,10 @@ int fm_step_bce(fm_engine* e, const float* x_dev, const float* y_dev, int32_t B,
     ARGCHK(B >= 1 && B <= e->maxB, "B exceeds max_images");
     const float* xs[1] = {x_dev};
     to_nhwc4(e, xs, 1, B);
-    forward_train(e, 1, B);
+    net_forward_train(e, 1, B);
     k_loss_bce(e->logits, y_dev, to_cv(pos_weight_host, e->C), B, e->C, 1.f / ((float)bs_norm * (float)e->C),
                e->dlogits, loss_dev, e->st);
-    backward_and_step(e, 1, B);
+    net_backward_and_step(e, 1, B);
     return FM_OK;
 }
 
@@ -778,12 +1155,12 @@ int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const
     const float* xs[2] = {x1_dev, x2_dev};
     to_nhwc4(e, xs, 2, B);
     // frozen teacher first (eval mode; its activations may be overwritten by the student)
-    forward_eval(e, e->tstate, e->tev_scale, e->tev_shift, e->tev_dirty, 2 * B, e->tfeat, e->tlogits);
-    forward_train(e, 2, B);
+    net_forward_eval(e, true, 2 * B);
+    net_forward_train(e, 2, B);
     k_loss_stage1(e->logits, e->tlogits, y_dev, to_cv(active_mask_host, e->C), B, e->C,
                   1.f / ((float)bs_norm * (float)annotation_num),
                   n_neg ? 1.f / ((float)bs_norm * (float)n_neg) : 0.f, e->dlogits, loss_dev, e->st);
-    backward_and_step(e, 2, B);
+    net_backward_and_step(e, 2, B);
     return FM_OK;
 }
 
@@ -794,9 +1171,9 @@ int fm_step_stage2(fm_engine* e, const float* x_dev, const float* y_dev, const f
     ARGCHK(B >= 1 && B <= e->maxB, "B exceeds max_images");
     const float* xs[1] = {x_dev};
     to_nhwc4(e, xs, 1, B);
-    forward_train(e, 1, B);
+    net_forward_train(e, 1, B);
     k_loss_stage2(e->logits, y_dev, distill_dev, B, e->C, e->dlogits, loss_dev, e->st);
-    backward_and_step(e, 1, B);
+    net_backward_and_step(e, 1, B);
     return FM_OK;
 }
 
@@ -811,18 +1188,18 @@ int fm_step_fixmatch(fm_engine* e, const float* xw_dev, const float* xs_dev, con
     for (int c = 0; c < e->C; ++c) n_neg += active_mask_host[c] == 0.f;
     const float* xs[2] = {xw_dev, xs_dev};
     to_nhwc4(e, xs, 2, B);
-    forward_train(e, 2, B);
+    net_forward_train(e, 2, B);
     k_loss_fixmatch(e->logits, y_dev, to_cv(pos_weight_host, e->C), to_cv(pos_weight_unk_host, e->C),
                     to_cv(active_mask_host, e->C), B, e->C, n_neg, 1.f / ((float)bs_norm * (float)annotation_num),
                     e->C - annotation_num, e->dlogits, loss_dev, e->st);
-    backward_and_step(e, 2, B);
+    net_backward_and_step(e, 2, B);
     return FM_OK;
 }
 
 int fm_proto_reset(fm_engine* e)
 {
     ARGCHK(e, "null engine");
-    HIPCHK(hipMemsetAsync(e->psum, 0, (size_t)2 * e->C * 512 * 4, e->st));
+    HIPCHK(hipMemsetAsync(e->psum, 0, (size_t)2 * e->C * e->D * 4, e->st));
     HIPCHK(hipMemsetAsync(e->pcnt, 0, (size_t)2 * e->C * 8, e->st));
     HIPCHK(hipMemsetAsync(e->tcnt, 0, (size_t)e->C * 8, e->st));
     return FM_OK;
@@ -832,7 +1209,7 @@ int fm_proto_accumulate(fm_engine* e, const float* feat_dev, const float* logits
                         int32_t B, const float* active_mask_host, const float* negative_mask_host, float L, float U)
 {
     ARGCHK(e && feat_dev && logits_dev && labels_dev && active_mask_host && negative_mask_host, "null");
-    k_proto_accumulate(feat_dev, logits_dev, labels_dev, B, 512, e->C, to_cv(active_mask_host, e->C),
+    k_proto_accumulate(feat_dev, logits_dev, labels_dev, B, e->D, e->C, to_cv(active_mask_host, e->C),
                        to_cv(negative_mask_host, e->C), L, U, e->psum, e->pcnt, e->tcnt, e->st);
     return FM_OK;
 }
@@ -842,7 +1219,8 @@ int fm_proto_finalize(fm_engine* e, int32_t zero_guard, int64_t n_local, const f
 {
     ARGCHK(e && active_mask_host && proto_host && t_host, "null");
     std::vector<int64_t> pc(2 * e->C), tc(e->C);
-    HIPCHK(hipMemcpyAsync(proto_host, e->psum, (size_t)2 * e->C * 512 * 4, hipMemcpyDeviceToHost, e->st));
+    const int D = e->D;
+    HIPCHK(hipMemcpyAsync(proto_host, e->psum, (size_t)2 * e->C * D * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(pc.data(), e->pcnt, pc.size() * 8, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipMemcpyAsync(tc.data(), e->tcnt, tc.size() * 8, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
@@ -853,7 +1231,7 @@ int fm_proto_finalize(fm_engine* e, int32_t zero_guard, int64_t n_local, const f
             const int r = 2 * c + v;
             if (zero_guard && pc[r] == 0) continue;
             const float den = (float)pc[r];
-            for (int d = 0; d < 512; ++d) proto_host[(size_t)r * 512 + d] = proto_host[(size_t)r * 512 + d] / den;
+            for (int d = 0; d < D; ++d) proto_host[(size_t)r * D + d] = proto_host[(size_t)r * D + d] / den;
         }
     }
     return FM_OK;
@@ -866,7 +1244,7 @@ int fm_cos_tag(fm_engine* e, const float* feat_dev, int64_t N, const float* prot
     ARGCHK(n_cls >= 0 && n_cls <= FM_MAX_CLASSES, "n_cls");
     if (n_cls == 0 || N == 0) return FM_OK;
     HIPCHK(hipMemcpyAsync(e->cls_dev, classes_host, (size_t)n_cls * 4, hipMemcpyHostToDevice, e->st));
-    k_cos_tag(feat_dev, N, 512, proto_dev, e->cls_dev, n_cls, sim_dev, e->st);
+    k_cos_tag(feat_dev, N, e->D, proto_dev, e->cls_dev, n_cls, sim_dev, e->st);
     return FM_OK;
 }
 
@@ -906,6 +1284,16 @@ int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, c
     return FM_OK;
 }
 
+int fm_set_stochastic(fm_engine* e, const float* drop_connect_dev, const float* dropout_dev)
+{
+    ARGCHK(e, "null engine");
+    e->dc_dev = drop_connect_dev;
+    e->drop_dev = dropout_dev;
+    return FM_OK;
+}
+
+int fm_feature_dim(fm_engine* e) { return e ? e->D : 0; }
+
 int fm_profile_enable(fm_engine* e, int32_t on)
 {
     ARGCHK(e, "null engine");
@@ -938,8 +1326,7 @@ int fm_debug_get_grads(fm_engine* e, float* host_f32)
     size_t off = 0;
     for (auto& en : e->entries) {
         if (en.kind == 0) {
-            const Conv& c = e->convs[en.conv];
-            k_ohwi_to_oihw(e->grad + c.w_off, e->stage_sd + off, c.cout, c.cin, c.k, c.k, c.kw_p, c.cin_p, e->st);
+            k_ohwi_to_oihw(e->grad + en.eng_off, e->stage_sd + off, en.O, en.I, en.KH, en.KW, en.Wpad, en.Ipad, e->st);
             off += en.n;
         } else if (en.kind == 1) {
             if (en.eng_off < e->NP)
@@ -978,14 +1365,14 @@ int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, co
         if (stats_dev) {
             // fold the per-tile partials with the finalize kernel's own reduction order: sum/sumsq only
             const int tiles = stats_tiles(e, conv, imgs / groups);
-            std::vector<float> h((size_t)groups * tiles * 2 * c.cout), o((size_t)groups * 2 * c.cout, 0.f);
+            std::vector<float> h((size_t)groups * tiles * 2 * c.cout_p), o((size_t)groups * 2 * c.cout_p, 0.f);
             HIPCHK(hipMemcpyAsync(h.data(), e->ws_stats, h.size() * 4, hipMemcpyDeviceToHost, e->st));
             HIPCHK(hipStreamSynchronize(e->st));
             for (int g = 0; g < groups; ++g)
-                for (int k = 0; k < 2 * c.cout; ++k) {
+                for (int k = 0; k < 2 * c.cout_p; ++k) {
                     double s = 0;
-                    for (int t = 0; t < tiles; ++t) s += h[((size_t)g * tiles + t) * 2 * c.cout + k];
-                    o[(size_t)g * 2 * c.cout + k] = (float)s;
+                    for (int t = 0; t < tiles; ++t) s += h[((size_t)g * tiles + t) * 2 * c.cout_p + k];
+                    o[(size_t)g * 2 * c.cout_p + k] = (float)s;
                 }
             HIPCHK(hipMemcpy(stats_dev, o.data(), o.size() * 4, hipMemcpyHostToDevice));
         }

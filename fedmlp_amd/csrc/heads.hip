@@ -85,7 +85,7 @@ __global__ void fc_bwd_w_kernel(const float* __restrict__ dz, const float* __res
     }
 }
 __global__ void fc_bwd_x_kernel(const float* __restrict__ dz, const float* __restrict__ W,
-                                float* __restrict__ dout, int D, int C, int HW)
+                                const float* __restrict__ mask, float* __restrict__ dout, int D, int C, int HW)
 {
     const int img = blockIdx.x;
     const float inv = 1.f / (float)HW;
@@ -93,14 +93,15 @@ __global__ void fc_bwd_x_kernel(const float* __restrict__ dz, const float* __res
         float s = 0.f;
         for (int k = 0; k < C; ++k) s += dz[(size_t)img * C + k] * W[(size_t)k * D + d];
         s *= inv;
+        if (mask) s *= mask[(size_t)img * D + d];      // dropout multiplier on the pooled feature
         for (int p = 0; p < HW; ++p) dout[((size_t)img * HW + p) * D + d] = s;
     }
 }
-void k_fc_bwd(const float* dz, const float* feat, const float* W, float* dW, float* db, float* dout, int imgs,
-              int D, int C, int HW, hipStream_t s)
+void k_fc_bwd(const float* dz, const float* feat, const float* W, const float* mask, float* dW, float* db,
+              float* dout, int imgs, int D, int C, int HW, hipStream_t s)
 {
     hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(C), dim3(256), 0, s, dz, feat, dW, db, imgs, D, C);
-    hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(imgs), dim3(256), 0, s, dz, W, dout, D, C, HW);
+    hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(imgs), dim3(256), 0, s, dz, W, mask, dout, D, C, HW);
 }
 
 // ------------------------------------------------------------ losses -----------

@@ -95,9 +95,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         // ---- LDS-DMA source state: this lane stages row 16*(wave*G+q)+drow of each operand -------
         const int csrc = (dpos ^ ((drow >> 1) & 3)) << 2;          // floats; same for every group (16 | group base)
         const float* asrc[GA];
+        bool av[GA];                                               // rows past M (M % BM != 0) read the zero page
 #pragma unroll
-        for (int q = 0; q < GA; ++q)
-            asrc[q] = p.W + (size_t)(m0 + 16 * (wave * GA + q) + drow) * Ktot + csrc;
+        for (int q = 0; q < GA; ++q) {
+            const int m = m0 + 16 * (wave * GA + q) + drow;
+            av[q] = m < p.M;
+            asrc[q] = p.W + (size_t)(av[q] ? m : 0) * Ktot + csrc;
+        }
         int ih0[GB], iw0[GB], xb[GB];
         bool rv[GB];
 #pragma unroll
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             }
 #pragma unroll
             for (int q = 0; q < GA; ++q)
-                __builtin_amdgcn_global_load_lds(asrc[q] + koff,
+                __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
                                                  (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
 #pragma unroll
             for (int q = 0; q < GB; ++q) {
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     u += red[(ww * BM + ch) * 2 + 0];
                     v += red[(ww * BM + ch) * 2 + 1];
                 }
+                if (m0 + ch >= p.M) continue;
                 float* st = p.stats + (size_t)(grp * p.tilesN + tn) * 2 * p.M;
                 st[m0 + ch] = u;
                 st[p.M + m0 + ch] = v;
@@ -291,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
             for (int r = 0; r < FR; ++r) {
                 const int m = mbase + 16 * r;
+                if (m >= p.M) continue;
                 f32x4 v = acc[r][c];
                 if (p.scale) {
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + m);
@@ -298,9 +304,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     v = v * sc + sh;
                 }
                 if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o + m);
-                if (p.relu) {
+                if (p.relu == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (p.relu == 2) {                           // swish (EfficientNet eval epilogue)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + expf(-v[q]));
                 }
                 *reinterpret_cast<f32x4*>(p.Y + o + m) = v;
             }

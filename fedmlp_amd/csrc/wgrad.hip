@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int pix = pb + ra0 + RPA * q;
-            const float* src = pix < pend ? p.dY + (size_t)pix * p.M + m0 + 4 * ca : p.zeros;
+            const float* src = (pix < pend && m0 + 4 * ca < p.M) ? p.dY + (size_t)pix * p.M + m0 + 4 * ca : p.zeros;
             ra[q] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + wm * 64 + 16 * lg + 4 * q + r;
+                if (m >= p.M) continue;
                 const f32x4 v = {acc[r][0][q], acc[r][1][q], acc[r][2][q], acc[r][3][q]};
                 *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + m) * p.Nw + n) = v;
             }

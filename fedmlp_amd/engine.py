@@ -10,7 +10,7 @@ import torch
 
 from . import _lib, spec
 
-MODEL_IDS = {"Resnet18": 0}
+MODEL_IDS = {"Resnet18": 0, "Efficient_b0": 1}
 
 
 def _ptr(t):
@@ -55,6 +55,26 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    # ---- EfficientNet-B0 training-time randomness ---------------------------------
+    def set_stochastic(self, drop_connect=None, dropout=None):
+        """Multipliers for the NEXT train steps (kept until replaced; None = no drop).
+        drop_connect: cuda fp32 [16, imgs]; dropout: cuda fp32 [imgs, 1280] (include/fedmlp_hip.h)."""
+        self._dc = None if drop_connect is None else drop_connect.contiguous().float()
+        self._dr = None if dropout is None else dropout.contiguous().float()
+        _lib.check(self.lib.fm_set_stochastic(self.h, _ptr(self._dc), _ptr(self._dr)))
+
+    def draw_stochastic(self, imgs, generator=None):
+        """One draw with efficientnet-pytorch's formulas (drop_connect_rate 0.2 scaled by
+        idx/16, dropout 0.2) on the engine's device, installed for the next train step."""
+        if self.model != "Efficient_b0":
+            return
+        dev = self.device
+        u = torch.rand((16, imgs), device=dev, generator=generator)
+        keep = 1.0 - 0.2 * torch.arange(16, device=dev, dtype=torch.float32).view(16, 1) / 16.0
+        dc = torch.floor(keep + u) / keep
+        dr = (torch.rand((imgs, 1280), device=dev, generator=generator) >= 0.2).float() / 0.8
+        self.set_stochastic(dc, dr)
 
     # ---- state -----------------------------------------------------------------
     def set_state(self, flat, counters):

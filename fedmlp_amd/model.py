@@ -19,7 +19,7 @@ import torch
 from . import spec
 from .engine import get_engine
 
-_MODEL_ALIASES = {"Resnet18": "Resnet18", "resnet18": "Resnet18"}
+_MODEL_ALIASES = {"Resnet18": "Resnet18", "resnet18": "Resnet18", "Efficient_b0": "Efficient_b0"}
 
 
 class HipNet:
@@ -170,7 +170,7 @@ def build_model(args):
     spec.init_state seeded with args.seed; load real weights with load_state_dict."""
     name = getattr(args, "model", "Resnet18")
     if name not in _MODEL_ALIASES:
-        raise ValueError(f"build_model: model {name!r} is not built (available: Resnet18)")
+        raise ValueError(f"build_model: model {name!r} is not built (available: Resnet18, Efficient_b0)")
     seed = int(getattr(args, "seed", 1037))
     flat, cnt = spec.init_state(_MODEL_ALIASES[name], args.n_classes, seed)
     net = HipNet(name, args.n_classes, flat, cnt)

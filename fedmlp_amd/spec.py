@@ -15,7 +15,20 @@ from collections import OrderedDict
 
 import numpy as np
 
-FEATURE_DIM = {"Resnet18": 512}
+FEATURE_DIM = {"Resnet18": 512, "Efficient_b0": 1280}
+
+# EfficientNet-B0 stages of efficientnet-pytorch 0.7.1: (repeats, kernel, stride, expand, in, out)
+B0_STAGES = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+             (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+
+
+def b0_blocks():
+    """[(kernel, stride, expand, cin, cout)] of the 16 MBConv blocks."""
+    out = []
+    for r, k, s, e, i, o in B0_STAGES:
+        out.append((k, s, e, i, o))
+        out += [(k, 1, e, o, o)] * (r - 1)
+    return out
 
 
 def resnet18_entries(n_classes):
@@ -52,10 +65,48 @@ def resnet18_entries(n_classes):
     return ent
 
 
+def efficientnet_b0_entries(n_classes):
+    """[(key, shape, dtype)] in efficientnet-pytorch 0.7.1 state_dict order (the reference builds it at
+    model/efficientnet.py:28-33 and swaps `_fc`, model/all_models.py:121-124)."""
+    ent = []
+
+    def bn(name, c):
+        ent.append((name + ".weight", (c,), "f32"))
+        ent.append((name + ".bias", (c,), "f32"))
+        ent.append((name + ".running_mean", (c,), "f32"))
+        ent.append((name + ".running_var", (c,), "f32"))
+        ent.append((name + ".num_batches_tracked", (), "i64"))
+
+    ent.append(("_conv_stem.weight", (32, 3, 3, 3), "f32"))
+    bn("_bn0", 32)
+    for i, (k, s, e, cin, cout) in enumerate(b0_blocks()):
+        p = f"_blocks.{i}"
+        ce = cin * e
+        if e != 1:
+            ent.append((p + "._expand_conv.weight", (ce, cin, 1, 1), "f32"))
+            bn(p + "._bn0", ce)
+        ent.append((p + "._depthwise_conv.weight", (ce, 1, k, k), "f32"))
+        bn(p + "._bn1", ce)
+        cs = max(1, int(cin * 0.25))
+        ent.append((p + "._se_reduce.weight", (cs, ce, 1, 1), "f32"))
+        ent.append((p + "._se_reduce.bias", (cs,), "f32"))
+        ent.append((p + "._se_expand.weight", (ce, cs, 1, 1), "f32"))
+        ent.append((p + "._se_expand.bias", (ce,), "f32"))
+        ent.append((p + "._project_conv.weight", (cout, ce, 1, 1), "f32"))
+        bn(p + "._bn2", cout)
+    ent.append(("_conv_head.weight", (1280, 320, 1, 1), "f32"))
+    bn("_bn1", 1280)
+    ent.append(("_fc.weight", (n_classes, 1280), "f32"))
+    ent.append(("_fc.bias", (n_classes,), "f32"))
+    return ent
+
+
 def entries(model, n_classes):
     if model == "Resnet18":
         return resnet18_entries(n_classes)
-    raise ValueError(f"unsupported model {model!r} (built so far: Resnet18)")
+    if model == "Efficient_b0":
+        return efficientnet_b0_entries(n_classes)
+    raise ValueError(f"unsupported model {model!r} (built: Resnet18, Efficient_b0)")
 
 
 def sizes(model, n_classes):
@@ -91,8 +142,8 @@ def init_state(model, n_classes, seed):
         if len(shape) == 4:
             fan_out = shape[0] * shape[2] * shape[3]
             v = rs.standard_normal(shape).astype(np.float32) * np.float32(np.sqrt(2.0 / fan_out))
-        elif key.startswith("fc."):
-            bound = 1.0 / np.sqrt(512.0)
+        elif key.startswith("fc.") or key.startswith("_fc."):
+            bound = 1.0 / np.sqrt(float(FEATURE_DIM[model]))
             v = rs.uniform(-bound, bound, size=shape).astype(np.float32)
         elif key.endswith("running_var") or (key.endswith(".weight") and len(shape) == 1):
             v = np.ones(shape, np.float32)

@@ -42,7 +42,8 @@ extern "C" {
 typedef struct fm_engine fm_engine;
 
 typedef struct fm_config {
-    int32_t model;        /* 0 = ResNet-18 (model/all_models.py:53-54, 117-120)      */
+    int32_t model;        /* 0 = ResNet-18 (model/all_models.py:53-54, 117-120);
+                             1 = EfficientNet-B0 (model/all_models.py:73-75, 121-124) */
     int32_t n_classes;    /* args.n_classes, <= FM_MAX_CLASSES                       */
     int32_t in_h, in_w;   /* input spatial size (224 in the reference, >= 32)        */
     int32_t max_images;   /* max images in ONE forward call (views x batch; eval     */
@@ -163,6 +164,19 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
  * out_dev: fp32 NCHW [B,3,H,W], i.e. what fm_step_* consume.  mean/std: host[3]. */
 int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const float* params_dev,
                int32_t B, const float* mean_host, const float* std_host, float* out_dev);
+
+/* ---- EfficientNet-B0 training-time randomness -----------------------------------
+ * The reference's model draws drop-connect (MBConvBlock, p = 0.2*idx/16 per block, per sample)
+ * and dropout (p = 0.2 before `_fc`) inside net(images) (utils/local_training.py:657, 937-947,
+ * 1178 through efficientnet_pytorch 0.7.1).  Here the draws are the caller's: device arrays of
+ * MULTIPLIERS, kept by pointer until replaced (NULL = identity, i.e. no drop).
+ *   drop_connect_dev [16][imgs]   imgs = images in the next train step (2B for two-view steps,
+ *                                 view-major), value floor(keep+U)/keep
+ *   dropout_dev      [imgs][1280] value 0 or 1/(1-p)
+ * Ignored by model 0. */
+int fm_set_stochastic(fm_engine* e, const float* drop_connect_dev, const float* dropout_dev);
+/* feature width of the model: 512 (ResNet-18) or 1280 (EfficientNet-B0) */
+int fm_feature_dim(fm_engine* e);
 
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the

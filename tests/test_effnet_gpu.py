@@ -1,0 +1,194 @@
+"""EfficientNet-B0 path (BASELINE configs 4-5) on a real MI355X through the C ABI: eval forward
+and one training step of each variant against the CPU oracle (oracle/efficientnet_ref.py) on the
+same seeded inputs and the same drop-connect / dropout draws."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from fedmlp_amd import spec
+from oracle import steps_ref as R
+from oracle.efficientnet_ref import EfficientNetB0Ref, draw_stochastic
+
+pytestmark = pytest.mark.gpu
+
+M = "Efficient_b0"
+C_, HW = 5, 64
+LR = 3e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fedmlp_amd.engine import Engine
+    e = Engine(M, C_, HW, HW, 16)
+    yield e
+    e.close()
+
+
+def _oracle(seed, perturb=True):
+    net = EfficientNetB0Ref(C_)
+    flat, cnt = spec.init_state(M, C_, seed)
+    sd = spec.flat_to_state_dict(M, C_, flat, cnt)
+    g = torch.Generator().manual_seed(seed + 1)
+    out = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(np.asarray(v))
+        if perturb and t.dtype == torch.float32:
+            # non-trivial BN affine / running stats and SE biases, so that nothing is tested at 0/1
+            if k.endswith("running_var"):
+                t = t * (0.5 + torch.rand(t.shape, generator=g))
+            elif k.endswith("running_mean") or k.endswith(".bias"):
+                t = t + 0.1 * torch.randn(t.shape, generator=g)
+            elif t.dim() == 1:
+                t = t * (1.0 + 0.1 * torch.randn(t.shape, generator=g))
+        out[k] = t
+    net.load_state_dict(out)
+    return net
+
+
+def _load(e, seed=1037):
+    net = _oracle(seed)
+    flat, cnt = spec.state_dict_to_flat(M, C_, net.state_dict())
+    e.set_state(flat, cnt)
+    e.adam_reset(LR)
+    return net
+
+
+def _data(B, seed, views=1):
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn((B, 3, HW, HW), generator=g) for _ in range(views)]
+    y = (torch.rand((B, C_), generator=g) < 0.3).float()
+    return xs, y
+
+
+def _cmp_grads(e, net, rtol=5e-4):
+    flat = e.debug_get_grads()
+    gsd = spec.flat_to_state_dict(M, C_, flat, np.zeros(e.ni, np.int64))
+    bad, worst = [], ("", 0.0)
+    for k, p in net.named_parameters():
+        want = p.grad.numpy()
+        got = gsd[k]
+        err = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        if err > worst[1]:
+            worst = (k, err)
+        if not err < rtol:
+            bad.append(f"{k}: {err:.3e}")
+    assert not bad, f"{len(bad)} tensors off; " + "; ".join(bad[-12:])
+    return worst
+
+
+def _cmp_state(e, net, atol_w):
+    flat, cnt = e.get_state()
+    sd = spec.flat_to_state_dict(M, C_, flat, cnt)
+    for k, v in net.state_dict().items():
+        want = v.numpy()
+        if "num_batches" in k:
+            assert int(sd[k]) == int(want), k
+            continue
+        tol = atol_w if ("running" not in k) else 1e-5 * (np.abs(want).max() + 1.0)
+        np.testing.assert_allclose(sd[k], want, rtol=1e-4, atol=tol, err_msg=k)
+
+
+def test_state_roundtrip(eng):
+    net = _load(eng)
+    flat, cnt = eng.get_state()
+    want, _ = spec.state_dict_to_flat(M, C_, net.state_dict())
+    np.testing.assert_array_equal(flat, want)
+
+
+def test_forward_eval(eng):
+    net = _load(eng)
+    (x,), _ = _data(5, 1)
+    net.eval()
+    with torch.no_grad():
+        f, z = net(x)
+    fe, ze = eng.forward_eval(x.cuda())
+    np.testing.assert_allclose(fe.cpu().numpy(), f.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ze.cpu().numpy(), z.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_forward_eval_224():
+    from fedmlp_amd.engine import Engine
+    e = Engine(M, C_, 224, 224, 4)
+    try:
+        net = _oracle(7)
+        flat, cnt = spec.state_dict_to_flat(M, C_, net.state_dict())
+        e.set_state(flat, cnt)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn((3, 3, 224, 224), generator=g)
+        net.eval()
+        with torch.no_grad():
+            f, z = net(x)
+        fe, ze = e.forward_eval(x.cuda())
+        np.testing.assert_allclose(fe.cpu().numpy(), f.numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ze.cpu().numpy(), z.numpy(), rtol=2e-4, atol=2e-5)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_step_bce(eng, stochastic):
+    net = _load(eng)
+    (x,), y = _data(6, 2)
+    pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+    dc = dr = None
+    if stochastic:
+        dc, dr = draw_stochastic(6, torch.Generator().manual_seed(5))
+    eng.set_stochastic(None if dc is None else dc.cuda(), None if dr is None else dr.cuda())
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x, dc, dr)
+    loss = R.loss_train(z, y, pw, 8, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
+    eng.set_stochastic(None, None)
+    assert abs(lo.item() - loss.item()) < 2e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+    _cmp_state(eng, net, atol_w=2.5 * LR)
+
+
+def test_step_stage1(eng):
+    net = _load(eng)
+    (x1, x2), y = _data(6, 3, views=2)
+    act, neg = [1], [0, 2, 3, 4]
+    glob = copy.deepcopy(net).eval()
+    eng.teacher_snapshot()
+    gen = torch.Generator().manual_seed(9)
+    dc1, dr1 = draw_stochastic(6, gen)
+    dc2, dr2 = draw_stochastic(6, gen)
+    eng.set_stochastic(torch.cat([dc1, dc2], 1).cuda(), torch.cat([dr1, dr2], 0).cuda())
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z1 = net(x1, dc1, dr1)
+    _, z2 = net(x2, dc2, dr2)
+    with torch.no_grad():
+        _, g1 = glob(x1)
+        _, g2 = glob(x2)
+    loss = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
+    opt.zero_grad(); loss.backward(); opt.step()
+    mask = [1.0 if c in act else 0.0 for c in range(C_)]
+    lo = torch.zeros(1, device="cuda")
+    eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+    eng.set_stochastic(None, None)
+    assert abs(lo.item() - loss.item()) < 2e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+    _cmp_state(eng, net, atol_w=2.5 * LR)
+
+
+def test_multi_step_loss_track(eng):
+    """5 consecutive BCE steps: per-step loss follows the oracle's."""
+    net = _load(eng, seed=11)
+    pw = [2.0] * C_
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=5e-4)
+    eng.adam_reset(1e-3)
+    lo = torch.zeros(1, device="cuda")
+    for it in range(5):
+        (x,), y = _data(8, 100 + it)
+        _, z = net(x)
+        loss = R.loss_train(z, y, pw, 8, C_)
+        opt.zero_grad(); loss.backward(); opt.step()
+        eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
+        assert abs(lo.item() - loss.item()) < 2e-3 * abs(loss.item()), (it, lo.item(), loss.item())

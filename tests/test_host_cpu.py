@@ -27,6 +27,31 @@ def test_spec_matches_reference_layout():
         assert tuple(ref[k].shape) == tuple(shape), k
 
 
+def test_efficientnet_b0_spec_matches_oracle_module():
+    """Efficient_b0 (BASELINE configs 4-5): key order, shapes and the 4,013,953-parameter count
+     of fedmlp_amd.spec agree with the oracle module's state_dict; the oracle forward
+    returns the (feature, logits) pair the trainer unpacks."""
+    import torch
+    from oracle.efficientnet_ref import EfficientNetB0Ref, draw_stochastic
+    net = EfficientNetB0Ref(5)
+    ent = spec.entries("Efficient_b0", 5)
+    sd = net.state_dict()
+    assert [k for k, _, _ in ent] == list(sd.keys())
+    for k, shape, dt in ent:
+        assert tuple(sd[k].shape) == tuple(shape), k
+        assert (sd[k].dtype == torch.int64) == (dt == "i64"), k
+    assert sum(p.numel() for p in net.parameters()) == 4013953
+    assert spec.sizes("Efficient_b0", 5) == (4055969, 49)
+    flat, cnt = spec.init_state("Efficient_b0", 5, 3)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                         spec.flat_to_state_dict("Efficient_b0", 5, flat, cnt).items()})
+    dc, dr = draw_stochastic(2, torch.Generator().manual_seed(0))
+    assert dc.shape == (16, 2) and dr.shape == (2, 1280) and float(dc[0].min()) == 1.0
+    net.train()
+    f, z = net(torch.randn(2, 3, 64, 64), dc, dr)
+    assert f.shape == (2, 1280) and z.shape == (2, 5)
+
+
 def test_state_flat_roundtrip():
     flat, cnt = spec.init_state("Resnet18", 8, 3)
     sd = spec.flat_to_state_dict("Resnet18", 8, flat, cnt)
