@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=5)
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--workload", default="stage1", choices=["stage1", "train", "stage2"])
+    ap.add_argument("--model", default="Resnet18", choices=["Resnet18", "Efficient_b0"],
+                    help="Efficient_b0 = BASELINE configs[3] (use --batch 256)")
     ap.add_argument("--round-steps", type=int, default=40, help="steps per FL round (5000/128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -52,7 +54,11 @@ def cpu_baseline(args):
     from tests.helpers import oracle_net
     import copy
     B = 8
-    net = oracle_net(args.classes, 1037)
+    if args.model == "Efficient_b0":
+        from oracle.efficientnet_ref import EfficientNetB0Ref
+        net = EfficientNetB0Ref(args.classes)
+    else:
+        net = oracle_net(args.classes, 1037)
     glob = copy.deepcopy(net).eval()
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=3e-5, betas=(0.9, 0.999), weight_decay=5e-4)
@@ -105,8 +111,8 @@ def main():
 
     B, C = args.batch, args.classes
     views = 2 if args.workload == "stage1" else 1
-    eng = Engine("Resnet18", C, args.hw, args.hw, views * B, device=str(dev))
-    flat, cnt = spec.init_state("Resnet18", C, 1037)
+    eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev))
+    flat, cnt = spec.init_state(args.model, C, 1037)
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
     eng.adam_reset(3e-5)
@@ -130,6 +136,7 @@ def main():
     def step(i, k):
         lo = losses[k:k + 1]
         j = i % npool
+        eng.draw_stochastic(views * B, g)      # EfficientNet drop-connect / dropout draws (no-op for ResNet)
         if args.workload == "stage1":
             eng.step_stage1(x1[j], x2[j], ys[j], mask, 1, B, lo)
         elif args.workload == "train":
@@ -173,7 +180,7 @@ def main():
         passes over this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md); null when the
         workload differs from the profiled one."""
         try:
-            if args.workload != "stage1" or args.batch != 128 or args.hw != 224:
+            if args.workload != "stage1" or args.batch != 128 or args.hw != 224 or args.model != "Resnet18":
                 return None
             with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
                 ks = json.load(f)["kernels"]
@@ -208,7 +215,7 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": f"FedMLP {args.workload} step, ResNet-18, ICH-shaped synthetic "
+               "config": {"workload": f"FedMLP {args.workload} step, {args.model}, ICH-shaped synthetic "
                                       f"3x{args.hw}x{args.hw}, C={C}, bs={B}, one client per GPU, "
                                       f"FedAvg all-reduce every {args.round_steps} steps + once at end",
                           "images_per_sec_per_client": round(B * args.steps / dt, 3),

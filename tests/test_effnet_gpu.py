@@ -66,14 +66,22 @@ def _cmp_grads(e, net, rtol=5e-4):
     flat = e.debug_get_grads()
     gsd = spec.flat_to_state_dict(M, C_, flat, np.zeros(e.ni, np.int64))
     bad, worst = [], ("", 0.0)
+    # Without drop-connect `_bn2.bias` of every block has an analytically ZERO gradient (a per-channel
+    # constant added before a conv that is followed by BatchNorm is removed by that BatchNorm): both
+    # sides hold rounding noise there (~1e-9 against typical gradients of ~4e-3).  Such tensors pass
+    # when both sides are zero to 1e-4 of the typical per-tensor gradient magnitude.
+    typ = float(np.median([p.grad.abs().max().item() for _, p in net.named_parameters()]))
+    floor = 1e-4 * typ
     for k, p in net.named_parameters():
         want = p.grad.numpy()
         got = gsd[k]
-        err = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        if k.endswith("._bn2.bias") and np.abs(want).max() < floor and np.abs(got).max() < floor:
+            continue
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), floor))
         if err > worst[1]:
             worst = (k, err)
         if not err < rtol:
-            bad.append(f"{k}: {err:.3e}")
+            bad.append(f"{k}: {err:.3e} (|want| {np.abs(want).max():.2e} |got| {np.abs(got).max():.2e} floor {floor:.1e})")
     assert not bad, f"{len(bad)} tensors off; " + "; ".join(bad[-12:])
     return worst
 
@@ -158,7 +166,6 @@ def test_step_stage1(eng):
     gen = torch.Generator().manual_seed(9)
     dc1, dr1 = draw_stochastic(6, gen)
     dc2, dr2 = draw_stochastic(6, gen)
-    eng.set_stochastic(torch.cat([dc1, dc2], 1).cuda(), torch.cat([dr1, dr2], 0).cuda())
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
     _, z1 = net(x1, dc1, dr1)
@@ -166,12 +173,15 @@ def test_step_stage1(eng):
     with torch.no_grad():
         _, g1 = glob(x1)
         _, g2 = glob(x2)
-    loss = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
+    loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
     opt.zero_grad(); loss.backward(); opt.step()
     mask = [1.0 if c in act else 0.0 for c in range(C_)]
     lo = torch.zeros(1, device="cuda")
-    eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
-    eng.set_stochastic(None, None)
+    eng.set_stochastic(torch.cat([dc1, dc2], 1).cuda(), torch.cat([dr1, dr2], 0).cuda())
+    try:
+        eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+    finally:
+        eng.set_stochastic(None, None)
     assert abs(lo.item() - loss.item()) < 2e-5 * abs(loss.item()) + 1e-7
     _cmp_grads(eng, net)
     _cmp_state(eng, net, atol_w=2.5 * LR)
