@@ -62,5 +62,7 @@ struct WgradParams {
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 int igemm_max_blocks();
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s);
+// 1x1 stride-1 convs with min(M, Nw) <= 128: returns the splits written to p.slab, 0 = not handled
+int launch_wgrad_skinny(const WgradParams& p, size_t slab_floats, hipStream_t s);
 int igemm_tile_n(int M);   // pixel-tile width the igemm uses for this M
 int igemm_tile_m(int M);

@@ -262,71 +262,119 @@ void k_dw_dgrad(const float* dy, const float* w, float* dx, int imgs, int Hi, in
                            stride, pad_t, pad_l);
 }
 
-// dw[kh][kw][c] = sum over output pixels of dy * x(shifted): each block owns a chunk of output
-// pixels and one tile of 64 channel-quads x 4 pixel lanes; partial [nblk][K*K][C], summed later
-// in a fixed order (reduce_slabs).
+// dw[kh][kw][c] = sum over output pixels of dy * x(shifted).  Thread = (channel quad, pixel lane):
+// QT quads x P lanes per block (QT*P <= 256 threads, see dw_map), each block owns a chunk of output
+// pixels; K*K float4 accumulators per thread, folded over the pixel lanes through LDS; partial
+// [nblk][K*K][C], summed later in a fixed order (reduce_slabs) -> run-to-run deterministic.
 template <int K>
-__global__ void dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
-                                int imgs, int Hi, int Wi, int Ho, int Wo, int C, int stride, int pad_t, int pad_l)
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       float* __restrict__ part, int imgs, int Hi, int Wi, int Ho,
+                                                       int Wo, int C, int stride, int pad_t, int pad_l, int QT, int P)
 {
-    __shared__ f32x4 red[4][64];
-    const int Q = C >> 2;
-    const int cq = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    __shared__ f32x4 red[256];
+    const int cq = blockIdx.y * QT + threadIdx.x % QT, pl = threadIdx.x / QT;
     const int npix = imgs * Ho * Wo, nblk = gridDim.x;
     const int chunk = (npix + nblk - 1) / nblk;
     const int pb = blockIdx.x * chunk, pe = min(npix, pb + chunk);
     f32x4 acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (cq < Q) {
-        for (int p = pb + pl; p < pe; p += 4) {
-            const int img = p / (Ho * Wo);
-            const int rem = p - img * Ho * Wo;
-            const int oh = rem / Wo, ow = rem - oh * Wo;
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * C + cq * 4);
+    for (int p = pb + pl; p < pe; p += P) {
+        const int img = p / (Ho * Wo);
+        const int rem = p - img * Ho * Wo;
+        const int oh = rem / Wo, ow = rem - oh * Wo;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * C + cq * 4);
+        const float* xi = x + (size_t)img * Hi * Wi * C + cq * 4;
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) {
-                const int ih = oh * stride + kh - pad_t;
-                if ((unsigned)ih >= (unsigned)Hi) continue;
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = oh * stride + kh - pad_t;
+            if ((unsigned)ih >= (unsigned)Hi) continue;
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const int iw = ow * stride + kw - pad_l;
-                    if ((unsigned)iw >= (unsigned)Wi) continue;
-                    acc[kh * K + kw] += d * *reinterpret_cast<const f32x4*>(x + ((size_t)(img * Hi + ih) * Wi + iw) * C + cq * 4);
-                }
+            for (int kw = 0; kw < K; ++kw) {
+                const int iw = ow * stride + kw - pad_l;
+                if ((unsigned)iw >= (unsigned)Wi) continue;
+                acc[kh * K + kw] += d * *reinterpret_cast<const f32x4*>(xi + (size_t)(ih * Wi + iw) * C);
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < K * K; ++t) {
         __syncthreads();
-        red[pl][threadIdx.x & 63] = acc[t];
+        red[threadIdx.x] = acc[t];
         __syncthreads();
-        if (pl == 0 && cq < Q) {
-            const f32x4 v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (pl == 0) {
+            f32x4 v = red[threadIdx.x];
+            for (int k = 1; k < P; ++k) v += red[k * QT + threadIdx.x];
             *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
         }
     }
 }
-int dw_wgrad_blocks(int npix) { return std::max(1, std::min(256, npix / 256)); }
+// QT = channel quads per block (a divisor of Q, <= 256), P = pixel lanes
+static inline void dw_map(int C, int& QT, int& P, int& ytiles)
+{
+    const int Q = C / 4;
+    ytiles = (Q + 255) / 256;
+    while (Q % ytiles) ++ytiles;
+    QT = Q / ytiles;
+    P = std::max(1, 256 / QT);
+}
+int dw_wgrad_blocks(int npix) { return std::max(1, std::min(2048, npix / 128)); }
 void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s)
 {
-    dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), cdiv(C / 4, 64));
+    int QT, P, yt;
+    dw_map(C, QT, P, yt);
+    dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt);
     if (K == 3)
-        hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t,
-                           pad_l);
+        hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride,
+                           pad_t, pad_l, QT, P);
     else
-        hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t,
-                           pad_l);
+        hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride,
+                           pad_t, pad_l, QT, P);
+}
+
+// per-image channel sums over a chunk of pixels: part[img][chunk][C] = sum_p a[p][c] (* b[p][c])
+__global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ part, int HW, int C, int QT, int P)
+{
+    __shared__ f32x4 red[256];
+    const int img = blockIdx.y, nch = gridDim.x;
+    const int Q = C >> 2;
+    const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
+    const int chunk = (HW + nch - 1) / nch;
+    const int pb = blockIdx.x * chunk, pe = min(HW, pb + chunk);
+    for (int cq = cq0; cq < Q; cq += QT) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        for (int p = pb + pl; p < pe; p += P) {
+            const size_t o = ((size_t)img * HW + p) * C + cq * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
+            if (b) v = v * *reinterpret_cast<const f32x4*>(b + o);
+            s1 += v;
+        }
+        __syncthreads();
+        red[threadIdx.x] = s1;
+        __syncthreads();
+        if (pl == 0) {
+            for (int k = 1; k < P; ++k) s1 += red[k * QT + cq0];
+            *reinterpret_cast<f32x4*>(part + ((size_t)img * nch + blockIdx.x) * C + cq * 4) = s1;
+        }
+    }
+}
+int chan_pool_chunks(int HW) { return std::max(1, std::min(16, HW / 64)); }
+void k_chan_pool(const float* a, const float* b, float* part, int imgs, int HW, int C, hipStream_t s)
+{
+    int QT, P, yt;
+    dw_map(C, QT, P, yt);
+    hipLaunchKernelGGL(chan_pool_kernel, dim3(chan_pool_chunks(HW), imgs), dim3(QT * P), 0, s, a, b, part, HW, C, QT, P);
 }
 
 // ------------------------------------------------------------ squeeze-excite ---
-// one block per image: s = mean_hw(a); r_pre = W1 s + b1; g = sigmoid(W2 swish(r_pre) + b2)
-// W1 [Cs][C], W2 [C][Cs].  Stores s [imgs][C], r_pre [imgs][Cs], g [imgs][C].
-__global__ void se_fwd_kernel(const float* __restrict__ a, const float* __restrict__ W1, const float* __restrict__ b1,
-                              const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ sq,
-                              float* __restrict__ rpre, float* __restrict__ gate, int HW, int C, int Cs)
+// one block per image: s = mean_hw(a) (from chan_pool partials [img][nch][C]); r_pre = W1 s + b1;
+// g = sigmoid(W2 swish(r_pre) + b2).  W1 [Cs][C], W2 [C][Cs].  Stores s [imgs][C], r_pre [imgs][Cs], g [imgs][C].
+__global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const float* __restrict__ W1,
+                              const float* __restrict__ b1, const float* __restrict__ W2,
+                              const float* __restrict__ b2, float* __restrict__ sq, float* __restrict__ rpre,
+                              float* __restrict__ gate, int HW, int C, int Cs)
 {
     extern __shared__ float sm[];            // s[C] then r[Cs]
     float* s_ = sm;
@@ -335,7 +383,7 @@ __global__ void se_fwd_kernel(const float* __restrict__ a, const float* __restri
     const float inv = 1.f / (float)HW;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float t = 0.f;
-        for (int p = 0; p < HW; ++p) t += a[((size_t)img * HW + p) * C + c];
+        for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * C + c];
         t *= inv;
         s_[c] = t;
         sq[(size_t)img * C + c] = t;
@@ -359,11 +407,12 @@ __global__ void se_fwd_kernel(const float* __restrict__ a, const float* __restri
         gate[(size_t)img * C + c] = sigm(t);
     }
 }
-void k_se_fwd(const float* a, const float* W1, const float* b1, const float* W2, const float* b2, float* sq,
-              float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s)
+void k_se_fwd(const float* a, float* pool_ws, const float* W1, const float* b1, const float* W2, const float* b2,
+              float* sq, float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s)
 {
-    hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, a, W1, b1, W2, b2, sq, rpre,
-                       gate, HW, C, Cs);
+    k_chan_pool(a, nullptr, pool_ws, imgs, HW, C, s);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
+                       W1, b1, W2, b2, sq, rpre, gate, HW, C, Cs);
 }
 
 // out = a * gate[img][c]   (+ optional second output: dsum[img][c] left to se_bwd)
@@ -387,7 +436,7 @@ void k_se_scale(const float* a, const float* gate, float* out, int imgs, int HW,
 
 // backward, one block per image:  dgs[c] = sum_hw dout*a ; dgp = dgs*g(1-g) ; dr = W2^T dgp ;
 // drp = dr*swish'(r_pre) ; ds = W1^T drp.  Stores dgp [imgs][C], drp [imgs][Cs], ds [imgs][C].
-__global__ void se_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+__global__ void se_bwd_kernel(const float* __restrict__ pool, int nch,
                               const float* __restrict__ gate, const float* __restrict__ rpre,
                               const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ dgp,
                               float* __restrict__ drp, float* __restrict__ ds, int HW, int C, int Cs)
@@ -398,10 +447,7 @@ __global__ void se_bwd_kernel(const float* __restrict__ dout, const float* __res
     const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float t = 0.f;
-        for (int p = 0; p < HW; ++p) {
-            const size_t o = ((size_t)img * HW + p) * C + c;
-            t += dout[o] * a[o];
-        }
+        for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * C + c];
         const float g = gate[(size_t)img * C + c];
         t *= g * (1.f - g);
         g_[c] = t;
@@ -426,11 +472,13 @@ __global__ void se_bwd_kernel(const float* __restrict__ dout, const float* __res
         ds[(size_t)img * C + c] = t;
     }
 }
-void k_se_bwd(const float* dout, const float* a, const float* gate, const float* rpre, const float* W1,
-              const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs, hipStream_t s)
+void k_se_bwd(const float* dout, const float* a, float* pool_ws, const float* gate, const float* rpre,
+              const float* W1, const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs,
+              hipStream_t s)
 {
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, dout, a, gate, rpre, W1, W2,
-                       dgp, drp, ds, HW, C, Cs);
+    k_chan_pool(dout, a, pool_ws, imgs, HW, C, s);
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
+                       gate, rpre, W1, W2, dgp, drp, ds, HW, C, Cs);
 }
 
 // dW2[c][j] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]

@@ -119,7 +119,7 @@ struct fm_engine {
     int maxC = 512;                   // widest BN (sizes ca/cb/cc and the partial-sum workspace)
     float *a0 = nullptr;              // EfficientNet: swish(bn(stem))
     float *T_small = nullptr, *T_mid = nullptr, *T_big = nullptr;
-    float *se_dgp = nullptr, *se_drp = nullptr, *se_ds = nullptr, *hfeat = nullptr;
+    float *se_dgp = nullptr, *se_drp = nullptr, *se_ds = nullptr, *se_pool = nullptr, *hfeat = nullptr;
     const float *dc_dev = nullptr, *drop_dev = nullptr;   // caller-owned stochastic multipliers (or null)
     std::vector<StateEntry> entries;
     int n_bn_ch = 0;
@@ -476,6 +476,7 @@ int alloc_workspaces(fm_engine* e)
         DALLOC(e->GA, g_io); DALLOC(e->GB, g_io);
         DALLOC(e->T_small, t_small); DALLOC(e->T_mid, t_mid); DALLOC(e->T_big, t_big);
         DALLOC(e->se_dgp, B * max_ce); DALLOC(e->se_drp, B * max_cs); DALLOC(e->se_ds, B * max_ce);
+        DALLOC(e->se_pool, B * 16 * max_ce);
         DALLOC(e->hfeat, B * e->D);
     }
     DALLOC(e->ws_stats, max_stats);
@@ -587,6 +588,17 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     p.M = c.cout_p; p.Nw = c.Kw;
     p.Ho = c.hout; p.Wo = c.wout; p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p; p.stride = c.stride;
     p.npix = imgs * c.hout * c.wout;
+    if (c.k == 1 && e->model == 1) {
+        int sk;
+        {
+            ProfScope ps(e, 4, 2.0 * c.macs_per_img * imgs);
+            sk = launch_wgrad_skinny(p, e->slab_floats, e->st);
+        }
+        if (sk > 0) {
+            k_reduce_slabs(e->ws_slab, e->grad + c.w_off, sk, (int64_t)c.w_numel, e->st);
+            return;
+        }
+    }
     const int bm = c.cout_p >= 128 ? 128 : 64, bn = c.cout_p >= 128 ? 128 : 256;
     p.tilesM = (c.cout_p + bm - 1) / bm;
     p.tilesN = (c.Kw + bn - 1) / bn;
@@ -807,7 +819,7 @@ void eff_forward_train(fm_engine* e, int groups, int B)
             Bn& b = e->bns[m.bn1];
             k_bnact_apply(m.y_d, b.scale, b.shift, nullptr, nullptr, m.a_d, groups, B * HWo, HWo, b.C, 2, e->st);
         }
-        k_se_fwd(m.a_d, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
+        k_se_fwd(m.a_d, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
                  m.ce_p, m.cs, e->st);
         k_se_scale(m.a_d, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
         Conv& cp = e->convs[m.c_proj];
@@ -860,7 +872,7 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
         }
         k_dw_fwd(a_e, S + m.dw_off, m.a_d, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
                  m.pad_t, m.pad_l, 2, e->st);
-        k_se_fwd(m.a_d, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
+        k_se_fwd(m.a_d, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
                  m.ce_p, m.cs, e->st);
         k_se_scale(m.a_d, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
         conv_fwd(e, m.c_proj, S, m.a_s, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr);
@@ -907,7 +919,7 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         conv_wgrad(e, m.c_proj, m.a_s, e->T_small, imgs);
         conv_dgrad(e, m.c_proj, S, e->T_small, e->T_mid, imgs, nullptr, false);          // d a_s
         // a_s = a_d * gate(a_d)
-        k_se_bwd(e->T_mid, m.a_d, m.gate, m.rpre, S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, imgs,
+        k_se_bwd(e->T_mid, m.a_d, e->se_pool, m.gate, m.rpre, S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, imgs,
                  HWo, m.ce_p, m.cs, e->st);
         k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, G + m.w1_off, G + m.b1_off, G + m.w2_off, G + m.b2_off, imgs,
                    m.ce_p, m.cs, e->st);

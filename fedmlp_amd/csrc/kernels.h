@@ -79,11 +79,13 @@ int dw_wgrad_blocks(int npix);
 void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
 // squeeze-excite: W1 [Cs][C], W2 [C][Cs]
-void k_se_fwd(const float* a, const float* W1, const float* b1, const float* W2, const float* b2, float* sq,
-              float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s);
+// pool_ws: [imgs][16][C] scratch for the per-image channel sums
+void k_se_fwd(const float* a, float* pool_ws, const float* W1, const float* b1, const float* W2, const float* b2,
+              float* sq, float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s);
 void k_se_scale(const float* a, const float* gate, float* out, int imgs, int HW, int C, hipStream_t s);
-void k_se_bwd(const float* dout, const float* a, const float* gate, const float* rpre, const float* W1,
-              const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs, hipStream_t s);
+void k_se_bwd(const float* dout, const float* a, float* pool_ws, const float* gate, const float* rpre,
+              const float* W1, const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs,
+              hipStream_t s);
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
                 float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s);
 void k_se_bwd_apply(const float* dout, const float* gate, const float* ds, float* da, int imgs, int HW, int C,

@@ -15,6 +15,8 @@
 // stores of the partial slab.  The pixel axis is split over blockIdx.y; slabs
 // are summed in a fixed order by reduce_slabs (run-to-run deterministic, like
 // the reference's cudnn.deterministic=True, main.py:36-37).
+#include <algorithm>
+
 #include "common.h"
 
 template <int BM, int BN, int WN>
@@ -137,6 +139,141 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
                 *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + m) * p.Nw + n) = v;
             }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// "Skinny" weight gradient of a 1x1 stride-1 convolution whose smaller channel count S is
+// <= 128 (EfficientNet-B0's expand / project convs: 96x16, 32x96, 480x80 ...).  These GEMMs are
+// HBM-bound (K = all pixels, output tiny), so the 64x64-per-wave tiles above would spend most
+// of their MFMA work and LDS traffic on padding.  Here the block tile is 64 (large channel dim
+// L) x 16*CC (the WHOLE small dim): the large operand is read exactly once, each wave owns 16
+// rows of L and all CC column tiles, no cross-wave reduction.
+//   P[l][s] = sum_p Big[p][l] * Small[p][s]
+// `swap` = the large operand is X (then P is dW transposed; the store transposes back).
+// ---------------------------------------------------------------------------------------
+struct SkinnyParams {
+    const float* Big;     // [npix][L]
+    const float* Small;   // [npix][S]
+    float* slab;          // [splits][M][Nw]
+    const float* zeros;
+    int L, S, M, Nw, swap;
+    int npix, pix_per_split;
+};
+
+template <int CC>
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
+{
+    constexpr int BS = 16 * CC;                   // small-dim tile (covers S)
+    constexpr int CB = BS / 4;                    // 16-B chunks per Small row
+    constexpr int NB = (32 * CB + 255) / 256;     // staging passes for the Small tile
+    __shared__ __attribute__((aligned(16))) float As[2][32][64];
+    __shared__ __attribute__((aligned(16))) float Bs[2][32][BS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int l0 = blockIdx.x * 64;
+    const int split = blockIdx.y;
+    const int pbeg = split * p.pix_per_split;
+    const int pend = min(p.npix, pbeg + p.pix_per_split);
+    const int nsteps = (pend - pbeg + 31) >> 5;
+
+    // staging: A tile = 32 rows x 16 chunks (2 per thread), Small tile = 32 rows x CB chunks
+    const int ca = tid & 15, ra = tid >> 4;       // rows ra, ra+16
+    const bool a_ok = l0 + 4 * ca < p.L;
+    f32x4 va[2], vb[NB];
+    auto gload = [&](int s) {
+        const int pb = pbeg + s * 32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pix = pb + ra + 16 * q;
+            const float* src = (a_ok && pix < pend) ? p.Big + (size_t)pix * p.L + l0 + 4 * ca : p.zeros;
+            va[q] = *reinterpret_cast<const f32x4*>(src);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c / CB, cb = c - row * CB;
+            const int pix = pb + row;
+            const float* src = (c < 32 * CB && 4 * cb < p.S && pix < pend) ? p.Small + (size_t)pix * p.S + 4 * cb : p.zeros;
+            vb[q] = *reinterpret_cast<const f32x4*>(src);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(&As[buf][ra + 16 * q][4 * ca]) = va[q];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c / CB, cb = c - row * CB;
+            if (c < 32 * CB) *reinterpret_cast<f32x4*>(&Bs[buf][row][4 * cb]) = vb[q];
+        }
+    };
+
+    f32x4 acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float a = As[buf][4 * kk + lg][16 * wave + li];
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[buf][4 * kk + lg][16 * c + li], acc[c], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[c][q] = P[l = l0 + 16*wave + 4*lg + q][s = 16*c + li]
+    const int l = l0 + 16 * wave + 4 * lg;
+    if (l < p.L) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int sc = 16 * c + li;
+            if (sc >= p.S) continue;
+            if (p.swap) {            // l = n (X channel), s = m: 4 consecutive n -> one 16-B store
+                *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + sc) * p.Nw + l) = acc[c];
+            } else {                 // l = m, s = n
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p.slab[((size_t)split * p.M + l + q) * p.Nw + sc] = acc[c][q];
+            }
+        }
+    }
+}
+
+// returns the number of splits used, or 0 if the shape is not handled (caller falls back)
+int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
+{
+    const int S = std::min(w.M, w.Nw), L = std::max(w.M, w.Nw);
+    if (S > 128 || w.stride != 1 || w.Ci != w.Nw || w.Ho != w.Hi || w.Wo != w.Wi) return 0;
+    SkinnyParams p{};
+    p.swap = w.Nw > w.M;      // large operand is X
+    p.Big = p.swap ? w.X : w.dY;
+    p.Small = p.swap ? w.dY : w.X;
+    p.slab = w.slab; p.zeros = w.zeros;
+    p.L = L; p.S = S; p.M = w.M; p.Nw = w.Nw; p.npix = w.npix;
+    const int tilesL = (L + 63) / 64;
+    int splits = std::max(1, 4096 / tilesL);
+    splits = std::min(splits, std::max(1, w.npix / 512));
+    splits = (int)std::min<size_t>(splits, std::max<size_t>(1, slab_floats / ((size_t)w.M * w.Nw)));
+    p.pix_per_split = (((w.npix + splits - 1) / splits) + 31) & ~31;
+    splits = (w.npix + p.pix_per_split - 1) / p.pix_per_split;
+    dim3 grid(tilesL, splits);
+    const int cc = (S + 15) / 16;
+    switch (cc) {
+    case 1: hipLaunchKernelGGL(wgrad_skinny_kernel<1>, grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(wgrad_skinny_kernel<2>, grid, dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL(wgrad_skinny_kernel<3>, grid, dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(wgrad_skinny_kernel<4>, grid, dim3(256), 0, s, p); break;
+    case 5: hipLaunchKernelGGL(wgrad_skinny_kernel<5>, grid, dim3(256), 0, s, p); break;
+    case 6: hipLaunchKernelGGL(wgrad_skinny_kernel<6>, grid, dim3(256), 0, s, p); break;
+    case 7: hipLaunchKernelGGL(wgrad_skinny_kernel<7>, grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL(wgrad_skinny_kernel<8>, grid, dim3(256), 0, s, p); break;
+    }
+    return splits;
 }
 
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
