@@ -9,6 +9,8 @@
 // utils/local_training.py:657, 937-947, 983, 1030, 1178).  The model is HBM-bound on MI355X
 // (10.4 FLOP/B in fp32): every kernel here moves 16 B per lane on NHWC tensors whose
 // channel counts are padded to multiples of 16 (24->32, 40->48; padded channels are exactly 0).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -206,9 +208,85 @@ __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restri
     }
     *reinterpret_cast<f32x4*>(y + i * 4) = acc;
 }
+// Register-blocked forms (the ones that run for EfficientNet-B0's shapes): one thread computes 4
+// consecutive output columns of one channel quad, so a K-wide row of taps costs 3*S+K loads
+// instead of 4*K.  Compile-time TF-"same" padding of an even input: (K-1)/2 at stride 1,
+// (K-2)/2 at stride 2; other paddings take the generic kernels above.
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int imgs, int Hi, int Wi,
+                                                         int Ho, int Wo, int C, int act)
+{
+    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+    constexpr int NIN = 3 * S + K;
+    const int Q = C >> 2, WB = (Wo + 3) >> 2;
+    const int64_t n = (int64_t)imgs * Ho * WB * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int ow0 = (int)(t % WB) * 4; t /= WB;
+    const int oh = (int)(t % Ho);
+    const int img = (int)(t / Ho);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int iw0 = ow0 * S - PT;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int ih = oh * S + kh - PT;
+        if ((unsigned)ih >= (unsigned)Hi) continue;
+        const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+        f32x4 xin[NIN], wr[K];
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const int iw = iw0 + j;
+            xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wr[kw] = *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) acc[j] += xin[j * S + kw] * wr[kw];
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) {
+        sc = *reinterpret_cast<const f32x4*>(scale + cq * 4);
+        sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (ow0 + j >= Wo) continue;
+        f32x4 v = acc[j];
+        if (scale) v = act_fwd(v * sc + sh, act);
+        *reinterpret_cast<f32x4*>(y + ((size_t)(img * Ho + oh) * Wo + ow0 + j) * C + cq * 4) = v;
+    }
+}
+static inline bool dw_blk_ok(int K, int S, int Hi, int Wi, int pad_t, int pad_l)
+{
+    const int pt = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+    return (K == 3 || K == 5) && (S == 1 || S == 2) && pad_t == pt && pad_l == pt && !getenv("FM_DW_GENERIC");
+}
+#define DW_DISPATCH(KERN, ...)                                                              \
+    do {                                                                                    \
+        if (K == 3 && stride == 1) hipLaunchKernelGGL((KERN<3, 1>), __VA_ARGS__);           \
+        else if (K == 3) hipLaunchKernelGGL((KERN<3, 2>), __VA_ARGS__);                     \
+        else if (stride == 1) hipLaunchKernelGGL((KERN<5, 1>), __VA_ARGS__);                \
+        else hipLaunchKernelGGL((KERN<5, 2>), __VA_ARGS__);                                 \
+    } while (0)
+
 void k_dw_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
 {
+    if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        const int64_t nb = (int64_t)imgs * Ho * ((Wo + 3) / 4) * (C / 4);
+        DW_DISPATCH(dw_fwd_blk_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo,
+                    C, act);
+        return;
+    }
     const int64_t n = (int64_t)imgs * Ho * Wo * (C / 4);
     if (K == 3)
         hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi,
@@ -250,9 +328,70 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dy, const float* __res
     }
     *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
 }
+// dgrad, register-blocked: 4 consecutive input columns per thread.  For input column iw0+j and tap
+// kw the output column is (iw0 + j + PT - kw)/S when that is an exact division; iw0 is a multiple
+// of 4, so which (j, kw) pairs are exact and their column offsets are compile-time.
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           float* __restrict__ dx, int imgs, int Hi, int Wi, int Ho,
+                                                           int Wo, int C)
+{
+    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+    constexpr int OMIN = -((K - PT) / S);            // lowest column offset any (j, kw) can need (generous)
+    constexpr int OMAX = (3 + PT) / S;
+    constexpr int NC = OMAX - OMIN + 1;
+    const int Q = C >> 2, WB = (Wi + 3) >> 2;
+    const int64_t n = (int64_t)imgs * Hi * WB * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int iw0 = (int)(t % WB) * 4; t /= WB;
+    const int ih = (int)(t % Hi);
+    const int img = (int)(t / Hi);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int cbase = iw0 / S + OMIN;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        const int a = ih + PT - kh;
+        if (a < 0 || (a % S) != 0) continue;
+        const int oh = a / S;
+        if (oh >= Ho) continue;
+        const float* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
+        f32x4 din[NC], wr[K];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int ow = cbase + c;
+            din[c] = (unsigned)ow < (unsigned)Wo ? *reinterpret_cast<const f32x4*>(dr + (size_t)ow * C)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wr[kw] = *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int d = j + PT - kw;              // compile-time after unrolling
+                if (d % S != 0) continue;
+                acc[j] += din[d / S - OMIN] * wr[kw];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (iw0 + j < Wi)
+            *reinterpret_cast<f32x4*>(dx + ((size_t)(img * Hi + ih) * Wi + iw0 + j) * C + cq * 4) = acc[j];
+}
+
 void k_dw_dgrad(const float* dy, const float* w, float* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s)
 {
+    if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        const int64_t nb = (int64_t)imgs * Hi * ((Wi + 3) / 4) * (C / 4);
+        DW_DISPATCH(dw_dgrad_blk_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
+        return;
+    }
     const int64_t n = (int64_t)imgs * Hi * Wi * (C / 4);
     if (K == 3)
         hipLaunchKernelGGL(dw_dgrad_kernel<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C,
@@ -309,6 +448,63 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         }
     }
 }
+// wgrad, register-blocked: the pixel loop walks blocks of 4 consecutive output columns
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ part, int imgs, int Hi, int Wi,
+                                                           int Ho, int Wo, int C, int QT, int P)
+{
+    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+    constexpr int NIN = 3 * S + K;
+    __shared__ f32x4 red[256];
+    const int cq = blockIdx.y * QT + threadIdx.x % QT, pl = threadIdx.x / QT;
+    const int WB = (Wo + 3) >> 2;
+    const int npb = imgs * Ho * WB, nblk = gridDim.x;
+    const int chunk = (npb + nblk - 1) / nblk;
+    const int pb = blockIdx.x * chunk, pe = min(npb, pb + chunk);
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = pb + pl; p < pe; p += P) {
+        const int img = p / (Ho * WB);
+        const int rem = p - img * Ho * WB;
+        const int oh = rem / WB, ow0 = (rem - oh * WB) * 4;
+        const float* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
+        f32x4 d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            d[j] = ow0 + j < Wo ? *reinterpret_cast<const f32x4*>(dr + (size_t)(ow0 + j) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int iw0 = ow0 * S - PT;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int ih = oh * S + kh - PT;
+            if ((unsigned)ih >= (unsigned)Hi) continue;
+            const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            f32x4 xin[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int iw = iw0 + j;
+                xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[kh * K + kw] += d[j] * xin[j * S + kw];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        __syncthreads();
+        red[threadIdx.x] = acc[t];
+        __syncthreads();
+        if (pl == 0) {
+            f32x4 v = red[threadIdx.x];
+            for (int k = 1; k < P; ++k) v += red[k * QT + threadIdx.x];
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
+        }
+    }
+}
 // QT = channel quads per block (a divisor of Q, <= 256), P = pixel lanes
 static inline void dw_map(int C, int& QT, int& P, int& ytiles)
 {
@@ -325,6 +521,10 @@ void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, 
     int QT, P, yt;
     dw_map(C, QT, P, yt);
     dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt);
+    if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        DW_DISPATCH(dw_wgrad_blk_kernel, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        return;
+    }
     if (K == 3)
         hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride,
                            pad_t, pad_l, QT, P);
