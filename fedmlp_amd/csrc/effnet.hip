@@ -682,22 +682,31 @@ void k_se_bwd(const float* dout, const float* a, float* pool_ws, const float* ga
 }
 
 // dW2[c][j] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]
+// 16 lanes share one (c, j) pair and split the images; fixed shuffle tree -> deterministic.
 __global__ void se_wgrad_kernel(const float* __restrict__ dgp, const float* __restrict__ drp,
                                 const float* __restrict__ rpre, const float* __restrict__ sq, float* __restrict__ dW1,
                                 float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2, int imgs,
                                 int C, int Cs)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * Cs) return;
-    const int c = i / Cs, j = i - c * Cs;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), il = threadIdx.x & 15;
+    const bool ok = i < C * Cs;
+    const int c = ok ? i / Cs : 0, j = ok ? i - c * Cs : 0;
     float w2 = 0.f, w1 = 0.f, bb2 = 0.f, bb1 = 0.f;
-    for (int m = 0; m < imgs; ++m) {
+    for (int m = il; m < imgs; m += 16) {
         const float g = dgp[(size_t)m * C + c], rp = rpre[(size_t)m * Cs + j], d = drp[(size_t)m * Cs + j];
         w2 += g * (rp * sigm(rp));
         w1 += d * sq[(size_t)m * C + c];
         bb2 += g;
         bb1 += d;
     }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        w2 += __shfl_xor(w2, d);
+        w1 += __shfl_xor(w1, d);
+        bb2 += __shfl_xor(bb2, d);
+        bb1 += __shfl_xor(bb1, d);
+    }
+    if (!ok || il != 0) return;
     dW2[(size_t)c * Cs + j] = w2;
     dW1[(size_t)j * C + c] = w1;
     if (j == 0) db2[c] = bb2;
@@ -706,7 +715,7 @@ __global__ void se_wgrad_kernel(const float* __restrict__ dgp, const float* __re
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
                 float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s)
 {
-    hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv((int64_t)C * Cs, 256)), dim3(256), 0, s, dgp, drp, rpre, sq, dW1, db1,
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv((int64_t)C * Cs, 16)), dim3(256), 0, s, dgp, drp, rpre, sq, dW1, db1,
                        dW2, db2, imgs, C, Cs);
 }
 

@@ -1355,12 +1355,13 @@ int fm_debug_get_grads(fm_engine* e, float* host_f32)
 
 int fm_debug_num_convs(fm_engine* e) { return e ? (int)e->convs.size() : 0; }
 
-int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info12)
+int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info16)
 {
-    ARGCHK(e && info12 && conv >= 0 && conv < (int)e->convs.size(), "conv index");
+    ARGCHK(e && info16 && conv >= 0 && conv < (int)e->convs.size(), "conv index");
     const Conv& c = e->convs[conv];
-    const int v[12] = {c.cin, c.cout, c.k, c.stride, c.pad, c.hin, c.win, c.hout, c.wout, c.cin_p, c.Kw, c.kw_p};
-    memcpy(info12, v, sizeof v);
+    const int v[16] = {c.cin, c.cout, c.k, c.stride, c.pad, c.hin, c.win, c.hout, c.wout, c.cin_p, c.Kw, c.kw_p,
+                       c.cout_p, 0, 0, 0};
+    memcpy(info16, v, sizeof v);
     return FM_OK;
 }
 

@@ -205,9 +205,9 @@ class Engine:
 
     # ---- kernel-level test hooks ----------------------------------------------------------
     def debug_conv_info(self, conv):
-        info = (C.c_int32 * 12)()
+        info = (C.c_int32 * 16)()
         _lib.check(self.lib.fm_debug_conv_info(self.h, conv, info))
-        keys = ("cin", "cout", "k", "stride", "pad", "hin", "win", "hout", "wout", "cin_p", "Kw", "kw_p")
+        keys = ("cin", "cout", "k", "stride", "pad", "hin", "win", "hout", "wout", "cin_p", "Kw", "kw_p", "cout_p")
         return dict(zip(keys, list(info)))
 
     def debug_get_grads(self):

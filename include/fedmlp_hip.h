@@ -189,10 +189,11 @@ int fm_profile_enable(fm_engine* e, int32_t on);
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops);
 
 /* ---- kernel-level test hooks (tests/ only; not part of the drop-in surface) -- */
-/* info[0..11] = cin, cout, k, stride, pad, hin, win, hout, wout, cin_p (padded
+/* info[0..12] = cin, cout, k, stride, pad, hin, win, hout, wout, cin_p (padded
  * input channels of the NHWC operand), Kw (row length of the engine-layout
- * weight matrix [cout][Kw] = [cout][k][kw_p][cin_p]), kw_p. */
-int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info12);
+ * weight matrix [cout_p][Kw] = [cout_p][k][kw_p][cin_p]), kw_p, cout_p (padded output
+ * channels of the NHWC result; = cout for ResNet-18); info[13..15] = 0. */
+int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info16);
 int fm_debug_num_convs(fm_engine* e);
 /* op 0: raw forward  x[imgs,hin,win,cin_p] -> out[imgs,hout,wout,cout]; if stats_dev
  *       != NULL also the per-group per-channel (sum, sumsq) [groups][2][cout]
