@@ -116,6 +116,7 @@ def main():
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
     eng.adam_reset(3e-5)
+    # Efficient_b0: the engine draws drop-connect / dropout multipliers before every train step
 
     # synthetic client data resident in HBM (seed = reference default, utils/options.py:10)
     g = torch.Generator(device=dev).manual_seed(1037 + rank)
@@ -136,7 +137,6 @@ def main():
     def step(i, k):
         lo = losses[k:k + 1]
         j = i % npool
-        eng.draw_stochastic(views * B, g)      # EfficientNet drop-connect / dropout draws (no-op for ResNet)
         if args.workload == "stage1":
             eng.step_stage1(x1[j], x2[j], ys[j], mask, 1, B, lo)
         elif args.workload == "train":

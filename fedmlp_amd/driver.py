@@ -34,7 +34,7 @@ def args_parser():
     p.add_argument("--L", type=float, default=0.3)
     p.add_argument("--clean_threshold", type=float, default=0.005)
     p.add_argument("--noise_threshold", type=float, default=0.01)
-    p.add_argument("--feature_dim", type=int, default=512)
+    p.add_argument("--feature_dim", type=int, default=0, help="0 = the model's own (512 ResNet-18, 1280 Efficient_b0)")
     p.add_argument("--n_local", type=int, default=512, help="samples per client (5000 for ICH)")
     p.add_argument("--hw", type=int, default=224)
     return p.parse_args()
@@ -77,6 +77,7 @@ def main():
     from fedmlp_amd.fedavg import allreduce_weighted_, tao_allreduce, proto_allreduce
 
     C, S1 = args.n_classes, args.rounds_FedMLP_stage1
+    args.feature_dim = args.feature_dim or spec.FEATURE_DIM[args.model]
     eng = Engine(args.model, C, args.hw, args.hw, 4 * args.batch_size, device=str(dev))
     flat, cnt = spec.init_state(args.model, C, args.seed)
     eng.set_state(flat, cnt)

@@ -44,6 +44,11 @@ class Engine:
         assert (self.nf, self.ni) == spec.sizes(model, self.n_classes), \
             "engine and fedmlp_amd.spec disagree on the state_dict layout"
         self.feature_dim = spec.FEATURE_DIM[model]
+        # Efficient_b0: draw drop-connect / dropout multipliers before every train step, like the
+        # reference's model does inside net(images) in train mode.  Parity tests switch it off and
+        # install their own draws with set_stochastic().
+        self.stochastic = model == "Efficient_b0"
+        self.stochastic_generator = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -123,23 +128,31 @@ class Engine:
         _lib.check(self.lib.fm_forward_eval(self.h, _ptr(x), B, int(teacher), _ptr(feat), _ptr(logits)))
         return feat, logits
 
+    def _draw(self, imgs):
+        if self.stochastic:
+            self.draw_stochastic(imgs, self.stochastic_generator)
+
     def step_bce(self, x, y, pos_weight, bs_norm, loss_out):
+        self._draw(x.shape[0])
         _lib.check(self.lib.fm_step_bce(self.h, _ptr(x), _ptr(y), x.shape[0],
                                         _lib.fvec(pos_weight, self.n_classes), int(bs_norm),
                                         _ptr(loss_out)))
 
     def step_stage1(self, x1, x2, y, active_mask, annotation_num, bs_norm, loss_out):
+        self._draw(2 * x1.shape[0])
         _lib.check(self.lib.fm_step_stage1(self.h, _ptr(x1), _ptr(x2), _ptr(y), x1.shape[0],
                                            _lib.fvec(active_mask, self.n_classes),
                                            int(annotation_num), int(bs_norm), _ptr(loss_out)))
 
     def step_stage2(self, x, y, distill, loss_out):
+        self._draw(x.shape[0])
         _lib.check(self.lib.fm_step_stage2(self.h, _ptr(x), _ptr(y), _ptr(distill), x.shape[0],
                                            _ptr(loss_out)))
 
     def step_fixmatch(self, xw, xs, y, pos_weight, pos_weight_unk, active_mask, annotation_num,
                       bs_norm, loss_out):
         n = self.n_classes
+        self._draw(2 * xw.shape[0])
         _lib.check(self.lib.fm_step_fixmatch(
             self.h, _ptr(xw), _ptr(xs), _ptr(y), xw.shape[0], _lib.fvec(pos_weight, n),
             _lib.fvec(pos_weight_unk, n), _lib.fvec(active_mask, n), int(annotation_num),

@@ -22,6 +22,7 @@ LR = 3e-5
 def eng():
     from fedmlp_amd.engine import Engine
     e = Engine(M, C_, HW, HW, 16)
+    e.stochastic = False          # the tests install the oracle's draws themselves
     yield e
     e.close()
 
@@ -202,3 +203,41 @@ def test_multi_step_loss_track(eng):
         opt.zero_grad(); loss.backward(); opt.step()
         eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
         assert abs(lo.item() - loss.item()) < 2e-3 * abs(loss.item()), (it, lo.item(), loss.item())
+
+
+def test_localupdate_surface_efficient_b0():
+    """build_model(args.model='Efficient_b0') + LocalUpdate.train + stage-1/2 of train_FedMLP run
+    through the same drop-in surface as ResNet-18; with the stochastic draws off, one epoch of
+    LocalUpdate.train follows the oracle's RefClient.train on the same batch order."""
+    import types
+    from fedmlp_amd.model import build_model
+    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import make_args, data_dict
+    from tests.test_local_training_gpu import SynthDataset
+    from tests.synth import class_lists
+    C, N, hw = 5, 24, 64
+    args = make_args(n_classes=C, n_clients=1, seed=5, model=M, batch_size=8, feature_dim=1280)
+    ds = SynthDataset(N, C, hw, 77, False)
+    pos, neg = class_lists(ds.targets, C)
+    net = build_model(args)
+    loc = LocalUpdate(args, 0, ds, list(range(N)), pos, neg, active_class_list=[0])
+    order = torch.randperm(N, generator=torch.Generator().manual_seed(1)).tolist()
+    loc.order_queue.append(order)
+    eng = loc._bind(net, "image")
+    eng.stochastic = False
+    ref_net = EfficientNetB0Ref(C)
+    ref_net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in net.state_dict().items()})
+    sd, loss, _, _, negl, actl = loc.train(0, net, None)
+    eng.stochastic = True
+    rc = R.RefClient(args, 0, data_dict(N, C, hw, 77, False), list(range(N)), neg, [0])
+    _, want_loss, _ = rc.train(ref_net, order)
+    assert abs(loss - want_loss) < 2e-3 * abs(want_loss), (loss, want_loss)
+    for k, v in ref_net.state_dict().items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v)
+        elif "running" in k:
+            np.testing.assert_allclose(np.asarray(sd[k]), v.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+    # with the draws on (the product default) the step still runs and the loss stays finite
+    loc.order_queue.append(order)
+    _, loss2, _, _, _, _ = loc.train(1, net, None)
+    assert np.isfinite(loss2)
