@@ -241,3 +241,67 @@ def test_localupdate_surface_efficient_b0():
     loc.order_queue.append(order)
     _, loss2, _, _, _, _ = loc.train(1, net, None)
     assert np.isfinite(loss2)
+
+
+def test_step_stage2(eng):
+    net = _load(eng)
+    (x,), y = _data(7, 4)
+    g = torch.Generator().manual_seed(44)
+    dist = (torch.rand((7, C_), generator=g) < 0.4).float()
+    dc, dr = draw_stochastic(7, torch.Generator().manual_seed(6))
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x, dc, dr)
+    loss = R.loss_stage2(z, y, dist)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.set_stochastic(dc.cuda(), dr.cuda())
+    try:
+        eng.step_stage2(x.cuda(), y.cuda(), dist.cuda(), lo)
+    finally:
+        eng.set_stochastic(None, None)
+    assert abs(lo.item() - loss.item()) < 2e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
+    _cmp_state(eng, net, atol_w=2.5 * LR)
+
+
+def test_step_fixmatch(eng):
+    net = _load(eng)
+    with torch.no_grad():
+        net._fc.weight.mul_(40.0)              # saturate some probabilities -> confident rows
+    flat, cnt = spec.state_dict_to_flat(M, C_, net.state_dict())
+    eng.set_state(flat, cnt)
+    eng.adam_reset(LR)
+    (xw, xs), y = _data(8, 5, views=2)
+    act, neg = [0], [1, 2, 3, 4]
+    pw, pwu = [3.0, 1.5, 4.0, 2.0, 2.5], [3.3, 1, 1, 1, 1]
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, zw = net(xw); _, zs = net(xs)
+    assert len(R.fixmatch_mask(zw, neg, 8)) > 0, "test needs at least one confident row"
+    loss = R.loss_fixmatch(zw, zs, y, pw, pwu, act, neg, 8, 1, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    mask = [1.0 if c in act else 0.0 for c in range(C_)]
+    eng.step_fixmatch(xw.cuda(), xs.cuda(), y.cuda(), pw, pwu, mask, 1, 8, lo)
+    assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net, rtol=2e-3)
+
+
+def test_prototype_pass_and_tagging_1280(eng):
+    """Prototype accumulation / cosine tagging run at the model's feature width (1280)."""
+    _load(eng)
+    (x,), y = _data(8, 21)
+    y[:, 0] = torch.tensor([0, 1, 0, 1, 1, 0, 0, 1.0])
+    fe, ze = eng.forward_eval(x.cuda())
+    assert fe.shape == (8, 1280)
+    act, negm = [1.0, 0, 0, 0, 0], [0.0, 1, 1, 1, 1]
+    eng.proto_reset()
+    eng.proto_accumulate(fe, ze, y.cuda(), act, negm, 0.3, 0.7)
+    t, proto = eng.proto_finalize(False, 8, act)
+    want_t, want_proto = R.prototype_pass([(fe.cpu(), ze.cpu(), y)], C_, [0], [1, 2, 3, 4], 0.3, 0.7, 8, False)
+    np.testing.assert_allclose(proto[:2], want_proto[:2].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(t, want_t, rtol=0, atol=1e-12)
+    sim = eng.cos_tag(fe, torch.from_numpy(proto).cuda(), [0])
+    want = R.cosine_diff(fe.cpu(), want_proto[0], want_proto[1])
+    np.testing.assert_allclose(sim[0].cpu().numpy(), np.asarray(want), rtol=1e-4, atol=1e-5)

@@ -228,3 +228,42 @@ def test_multi_step_trajectory(eng):
             continue
         a, b = np.linalg.norm(sd[k].astype(np.float64)), float(torch.linalg.vector_norm(v.double()))
         assert abs(a - b) <= 1e-3 * b + 0.25 * LR, (k, a, b)
+
+
+def test_step_stage1_chestxray14_shape():
+    """BASELINE configs[2] (ChestXray14: 14 labels): stage-1 step with 3 annotated classes per
+    client (annotation_num 3) -> loss, gradients and post-Adam state against the oracle."""
+    from fedmlp_amd.engine import Engine
+    C = 14
+    e = Engine("Resnet18", C, HW, HW, 16)
+    try:
+        flat, cnt = spec.init_state("Resnet18", C, 7)
+        e.set_state(flat, cnt)
+        e.adam_reset(LR)
+        net = oracle_net(C, 7)
+        g = torch.Generator().manual_seed(31)
+        x1 = torch.randn((6, 3, HW, HW), generator=g)
+        x2 = torch.randn((6, 3, HW, HW), generator=g)
+        y = (torch.rand((6, C), generator=g) < 0.3).float()
+        act = [2, 5, 11]
+        neg = [c for c in range(C) if c not in act]
+        glob = copy.deepcopy(net).eval()
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+        _, z1 = net(x1); _, z2 = net(x2)
+        with torch.no_grad():
+            _, g1 = glob(x1); _, g2 = glob(x2)
+        loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 3)
+        opt.zero_grad(); loss.backward(); opt.step()
+        e.teacher_snapshot()
+        lo = torch.zeros(1, device="cuda")
+        mask = [1.0 if c in act else 0.0 for c in range(C)]
+        e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 3, 8, lo)
+        assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
+        gsd = spec.flat_to_state_dict("Resnet18", C, e.debug_get_grads(), np.zeros(e.ni, np.int64))
+        for k, p in net.named_parameters():
+            want = p.grad.numpy()
+            err = float(np.abs(gsd[k] - want).max() / (np.abs(want).max() + 1e-12))
+            assert err < 1e-3, (k, err)
+    finally:
+        e.close()
