@@ -56,6 +56,10 @@ SYMBOLS = {
     "fm_select_topk": (C.c_int, [_P, _P, _I64, C.c_double, C.c_double, _I32, C.POINTER(_I32),
                                  C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "fm_augment": (C.c_int, [_P, _P, _P, _P, _I32, _F, _F, _P]),
+    "fm_forward_train": (C.c_int, [_P, _P, _P, _I32, _P, _P]),
+    "fm_backward_step": (C.c_int, [_P, _P]),
+    "fm_teacher_axpby": (C.c_int, [_P, C.c_float, C.c_float]),
+    "fm_teacher_swap": (C.c_int, [_P]),
     "fm_set_stochastic": (C.c_int, [_P, _P, _P]),
     "fm_feature_dim": (C.c_int, [_P]),
     "fm_profile_enable": (C.c_int, [_P, _I32]),

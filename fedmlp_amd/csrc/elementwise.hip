@@ -81,6 +81,15 @@ __global__ void scale_kernel(float* __restrict__ x, float w, int64_t n)
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) x[i] *= w;
 }
+__global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, float a, float b, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * y[i] + b * x[i];
+}
+void k_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(axpby_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, y, x, a, b, n);
+}
 void k_scale(float* x, float w, int64_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(scale_kernel, dim3(min(2048, cdiv(n, 256))), dim3(256), 0, s, x, w, n);

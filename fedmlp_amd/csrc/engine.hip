@@ -121,6 +121,8 @@ struct fm_engine {
     float *T_small = nullptr, *T_mid = nullptr, *T_big = nullptr;
     float *se_dgp = nullptr, *se_drp = nullptr, *se_ds = nullptr, *se_pool = nullptr, *hfeat = nullptr;
     const float *dc_dev = nullptr, *drop_dev = nullptr;   // caller-owned stochastic multipliers (or null)
+    int pending_views = 0, pending_B = 0;                 // fm_forward_train awaiting fm_backward_step
+    std::vector<int64_t> tcounters;                       // the teacher's num_batches_tracked
     std::vector<StateEntry> entries;
     int n_bn_ch = 0;
     size_t NP = 0, NS = 0;            // trainable floats (padded to 4), whole state floats
@@ -311,6 +313,7 @@ int build_resnet18(fm_engine* e)
     e->nf_sd = 0; e->ni_sd = 0;
     for (auto& en : e->entries) (en.kind == 2 ? e->ni_sd : e->nf_sd) += (int64_t)en.n;
     e->counters.assign(e->bns.size(), 0);
+    e->tcounters = e->counters;
     return FM_OK;
 }
 
@@ -420,6 +423,7 @@ int build_effnet_b0(fm_engine* e)
     e->nf_sd = 0; e->ni_sd = 0;
     for (auto& en : e->entries) (en.kind == 2 ? e->ni_sd : e->nf_sd) += (int64_t)en.n;
     e->counters.assign(e->bns.size(), 0);
+    e->tcounters = e->counters;
     return FM_OK;
 }
 
@@ -1112,6 +1116,7 @@ int fm_teacher_snapshot(fm_engine* e)
 {
     ARGCHK(e, "null engine");
     HIPCHK(hipMemcpyAsync(e->tstate, e->state, e->NS * 4, hipMemcpyDeviceToDevice, e->st));
+    e->tcounters = e->counters;
     e->tev_dirty = true;
     return FM_OK;
 }
@@ -1293,6 +1298,56 @@ int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, c
     ARGCHK(e && cache_dev && idx_dev && params_dev && mean_host && std_host && out_dev && B >= 1, "null");
     k_augment(cache_dev, idx_dev, params_dev, out_dev, B, e->H, e->W, mean_host[0], mean_host[1], mean_host[2],
               std_host[0], std_host[1], std_host[2], e->st);
+    return FM_OK;
+}
+
+int fm_forward_train(fm_engine* e, const float* x1_dev, const float* x2_dev, int32_t B, float* feat_dev,
+                     float* logits_dev)
+{
+    ARGCHK(e && x1_dev, "null");
+    const int views = x2_dev ? 2 : 1;
+    ARGCHK(B >= 1 && views * B <= e->maxB, "views*B exceeds max_images");
+    const float* xs[2] = {x1_dev, x2_dev};
+    to_nhwc4(e, xs, views, B);
+    net_forward_train(e, views, B);
+    if (feat_dev)
+        HIPCHK(hipMemcpyAsync(feat_dev, e->feat, (size_t)views * B * e->D * 4, hipMemcpyDeviceToDevice, e->st));
+    if (logits_dev)
+        HIPCHK(hipMemcpyAsync(logits_dev, e->logits, (size_t)views * B * e->C * 4, hipMemcpyDeviceToDevice, e->st));
+    e->pending_views = views; e->pending_B = B;
+    return FM_OK;
+}
+
+int fm_backward_step(fm_engine* e, const float* dlogits_dev)
+{
+    ARGCHK(e && dlogits_dev, "null");
+    ARGCHK(e->pending_views > 0, "fm_backward_step without a preceding fm_forward_train");
+    const int views = e->pending_views, B = e->pending_B;
+    HIPCHK(hipMemcpyAsync(e->dlogits, dlogits_dev, (size_t)views * B * e->C * 4, hipMemcpyDeviceToDevice, e->st));
+    net_backward_and_step(e, views, B);
+    e->pending_views = 0;
+    return FM_OK;
+}
+
+int fm_teacher_axpby(fm_engine* e, float w_teacher, float w_student)
+{
+    ARGCHK(e, "null engine");
+    k_axpby(e->tstate, e->state, w_teacher, w_student, (int64_t)e->NS, e->st);
+    // int64 num_batches_tracked: the float result is truncated when it is loaded back (like FedAvg, Q7)
+    for (size_t i = 0; i < e->counters.size(); ++i)
+        e->tcounters[i] = (int64_t)(w_teacher * (float)e->tcounters[i] + w_student * (float)e->counters[i]);
+    e->tev_dirty = true;
+    return FM_OK;
+}
+
+int fm_teacher_swap(fm_engine* e)
+{
+    ARGCHK(e, "null engine");
+    std::swap(e->state, e->tstate);
+    std::swap(e->ev_scale, e->tev_scale);
+    std::swap(e->ev_shift, e->tev_shift);
+    std::swap(e->ev_dirty, e->tev_dirty);
+    std::swap(e->counters, e->tcounters);
     return FM_OK;
 }
 

@@ -17,6 +17,7 @@ void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, in
 // dgrad pack: out[ci][j][co] = w[co][taps.t[j]][ci]   (w is [Co][T][Ci])
 void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList taps, hipStream_t s);
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
+void k_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);   // y = a*y + b*x
 
 // ---- input pipeline: uint8 HBM cache -> augmented, normalised fp32 NCHW batch.
 // params[b] = {m0..m5 (inverse affine, PIL AFFINE convention), flip, unused}; nearest sampling,

@@ -159,6 +159,25 @@ class Engine:
             int(bs_norm), _ptr(loss_out)))
 
     # ---- prototypes / tagging ------------------------------------------------------
+    # ---- generic split step (rank-4 baselines: loss head computed by the host mirror) -----------
+    def forward_train(self, x1, x2=None):
+        views = 1 if x2 is None else 2
+        B = x1.shape[0]
+        self._draw(views * B)
+        feat = torch.empty((views * B, self.feature_dim), device=self.device, dtype=torch.float32)
+        logits = torch.empty((views * B, self.n_classes), device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.fm_forward_train(self.h, _ptr(x1), _ptr(x2), B, _ptr(feat), _ptr(logits)))
+        return feat, logits
+
+    def backward_step(self, dlogits):
+        _lib.check(self.lib.fm_backward_step(self.h, _ptr(dlogits.contiguous().float())))
+
+    def teacher_axpby(self, w_teacher, w_student):
+        _lib.check(self.lib.fm_teacher_axpby(self.h, C.c_float(w_teacher), C.c_float(w_student)))
+
+    def teacher_swap(self):
+        _lib.check(self.lib.fm_teacher_swap(self.h))
+
     def proto_reset(self):
         _lib.check(self.lib.fm_proto_reset(self.h))
 

@@ -130,3 +130,11 @@ def proto_allreduce(proto, n_i, is_active_client_mask, device="cpu"):
         d.all_reduce(den, op=d.ReduceOp.SUM)
     with np.errstate(invalid="ignore", divide="ignore"):
         return torch.from_numpy(num.cpu().numpy() / den.cpu().numpy()[:, None])   # 0/0 -> NaN
+
+
+def consistency_weight(rnd, begin, end):
+    """get_current_consistency_weight(rnd, args.begin, args.end) (utils/FedNoRo.py:72-81): the
+    sigmoid ramp-up main.py:127-128 multiplies by args.a to get train_FedNoRo's weight_kd."""
+    cur = float(np.clip(rnd, begin, end))
+    phase = 1.0 - (cur - begin) / (end - begin)
+    return float(np.exp(-5.0 * phase * phase))

@@ -194,6 +194,161 @@ class LocalUpdate(object):
         return self._sd(net), np.array(epoch_loss).mean(), None, None, \
             list(self.negative_class_list), list(self.active_class_list)
 
+    # ==== SURVEY 8f rank 4: the other baselines of main.py's --exp switch =========================
+    # Their forward/backward/Adam run on the engine through the split step (fm_forward_train /
+    # fm_backward_step); only the loss head on the [B,C] logits is host-mirror code (torch ops on the
+    # device tensors, gradient by autograd on that [B,C] leaf).
+    @staticmethod
+    def _head_grad(z, loss_fn):
+        zl = z.detach().requires_grad_(True)
+        loss = loss_fn(zl)
+        (dz,) = torch.autograd.grad(loss, zl)
+        return loss.detach(), dz
+
+    # ---- LocalUpdate.train_RSCFed (:705-769) ---------------------------------------------------------
+    def train_RSCFed(self, rnd, net):
+        a = self.args
+        assert isinstance(self.teacher_neg, HipNet), "LocalUpdate(teacher_neg=build_model(...)) is required"
+        eng = self._bind(net, "image_aug_1")
+        # the EMA teacher lives in the engine's teacher slot for the duration of the call
+        self.teacher_neg._pull()
+        eng.teacher_swap()
+        eng.set_state(self.teacher_neg.flat, self.teacher_neg.counters)
+        eng.teacher_swap()
+        eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+        y = self._labels_dev(eng, self._y_masked, "y_masked")
+        n = len(self.idxs)
+        act, neg = list(self.active_class_list), list(self.negative_class_list)
+        pw = torch.tensor(self.loss_w, dtype=torch.float32, device=eng.device)
+        F = torch.nn.functional
+        epoch_loss = []
+        for _ in range(a.local_ep):
+            batches = _batches(self._order(n), a.batch_size)
+            losses = torch.zeros(len(batches), device=eng.device)
+            for k, pos in enumerate(batches):
+                yb = self._rows(y, pos, eng)
+                _, zt = eng.forward_eval(self._images(eng, "image_aug_2", pos), teacher=True)
+                _, z1 = eng.forward_train(self._images(eng, "image_aug_1", pos))
+
+                def head(z):
+                    l = F.binary_cross_entropy_with_logits(z, yb, pos_weight=pw, reduction="none")
+                    sup = l[:, act].sum() / (a.batch_size * a.annotation_num)
+                    return sup + F.mse_loss(torch.sigmoid(z)[:, neg], torch.sigmoid(zt)[:, neg])
+                loss, dz = self._head_grad(z1, head)
+                eng.backward_step(dz)
+                eng.teacher_axpby(1 - 0.001, 0.001)                 # :751-759
+                losses[k] = loss
+                self.iter_num += 1
+            self.epoch += 1
+            epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+        eng.teacher_swap()
+        self.teacher_neg.flat, self.teacher_neg.counters = eng.get_state()
+        self.teacher_neg._version += 1
+        eng.teacher_swap()
+        net.mark_trained()
+        return self._sd(net), np.array(epoch_loss).mean(), None, None, neg, act
+
+    # ---- LocalUpdate.train_FedNoRo (:115-234) ----------------------------------------------------------
+    def train_FedNoRo(self, id, rnd, net, writer1=None, weight_kd=None, clean_clients=None, noisy_clients=None):
+        a = self.args
+        if rnd >= a.rounds_FedNoRo_warmup:
+            # The reference's post-warm-up branches cannot run: the clean-client branch calls
+            # backward() on an unreduced [B,C] loss (:174-176) and the noisy-client branch builds
+            # LA_KD without its required class lists (:201); main.py keeps both commented out (:145-148).
+            raise NotImplementedError("train_FedNoRo after the warm-up rounds is not runnable in the reference")
+        eng = self._bind(net, "image")
+        eng.teacher_snapshot()                                      # teacher_net = deepcopy(net), frozen
+        eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+        y = self._labels_dev(eng, self._y_masked, "y_masked")
+        n = len(self.idxs)
+        act, neg = list(self.active_class_list), list(self.negative_class_list)
+        for c in neg:                                               # :136-137
+            self.class_num_list[c] = 0
+        w_kd = float(weight_kd)
+        F = torch.nn.functional
+        epoch_loss = []
+        for _ in range(a.local_ep):
+            batches = _batches(self._order(n), a.batch_size)
+            losses = torch.zeros(len(batches), device=eng.device)
+            for k, pos in enumerate(batches):
+                x, yb = self._images(eng, "image", pos), self._rows(y, pos, eng)
+                _, zt = eng.forward_eval(x, teacher=True)
+                soft = torch.sigmoid(zt / 0.8)
+                _, z = eng.forward_train(x)
+
+                def head(zz):
+                    p = torch.sigmoid(zz)
+                    B = p.shape[0]
+                    bce = F.binary_cross_entropy(p, yb, reduction="none")[:, act].sum() / (B * len(act))
+                    kl = F.mse_loss(p, soft, reduction="none")[:, neg].sum() / (B * len(neg))
+                    return w_kd * kl + (1 - w_kd) * bce
+                loss, dz = self._head_grad(z, head)
+                eng.backward_step(dz)
+                losses[k] = loss
+                self.iter_num += 1
+            self.epoch += 1
+            epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+        net.mark_trained()
+        return self._sd(net), np.array(epoch_loss).mean(), None, None, neg, act
+
+    # ---- LocalUpdate.train_CBAFed (:236-342) -------------------------------------------------------------
+    def train_CBAFed(self, rnd, net, pt=None, tao=None):
+        a = self.args
+        eng = self._bind(net, "image")
+        eng.adam_reset(self.lr, (0.9, 0.999), 1e-8, 5e-4)
+        y = self._labels_dev(eng, self._y_masked, "y_masked")
+        n = len(self.idxs)
+        act, neg = list(self.active_class_list), list(self.negative_class_list)
+        warm = rnd < a.rounds_CBAFed_warmup
+        class_num_list = torch.zeros(a.n_classes)
+        data_num = 0
+        F = torch.nn.functional
+        epoch_loss = []
+        for _ in range(a.local_ep):
+            batches = _batches(self._order(n), a.batch_size)
+            losses = torch.zeros(len(batches), device=eng.device)
+            for k, pos in enumerate(batches):
+                yb = self._rows(y, pos, eng)
+                _, z = eng.forward_train(self._images(eng, "image", pos))
+                labels, idx_neg = yb, []
+                if warm:
+                    data_num += len(pos)
+                else:
+                    prob = torch.sigmoid(z)
+                    labels = yb.clone()
+                    for i in neg:                                    # :303-316 (one host sync per class, like the reference)
+                        hi, lo = prob[:, i] > tao[i], prob[:, i] < (1 - tao[i])
+                        noise_num, clean_num = int(hi.sum()), int(lo.sum())
+                        labels[:, i] = torch.where(hi, torch.ones_like(labels[:, i]), labels[:, i])
+                        pseudo = torch.where(hi | lo)[0]
+                        idx_neg.append(pseudo)
+                        class_num_list[i] += len(pseudo)
+                        data_num += len(pseudo)
+                        self.loss_w[i] = 1 if noise_num == 0 else (noise_num + clean_num) / noise_num
+                    for i in act:
+                        class_num_list[i] += len(pos)
+                    data_num += len(pos) * a.annotation_num
+                pw = torch.tensor(self.loss_w, dtype=torch.float32, device=eng.device)
+
+                def head(zz):
+                    l = F.binary_cross_entropy_with_logits(zz, labels, pos_weight=pw, reduction="none")
+                    loss = l[:, act].sum() / (a.batch_size * a.annotation_num)
+                    for kk, i in enumerate(neg if not warm else []):
+                        if len(idx_neg[kk]) != 0:
+                            loss = loss + l[idx_neg[kk], i].sum() / len(idx_neg[kk])
+                    return loss
+                loss, dz = self._head_grad(z, head)
+                eng.backward_step(dz)
+                losses[k] = loss
+                self.iter_num += 1
+            if warm:
+                for c in act:
+                    class_num_list[c] = data_num
+            self.epoch += 1
+            epoch_loss.append(losses.cpu().numpy().astype(np.float64).mean())
+        net.mark_trained()
+        return self._sd(net), np.array(epoch_loss).mean(), None, None, neg, act, class_num_list, data_num
+
     # ---- prototype + t pass (:971-1002 unguarded, :1208-1250 zero-guarded) ----------------------------
     def _proto_pass(self, eng, negative_list, zero_guard):
         a = self.args

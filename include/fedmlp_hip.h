@@ -165,6 +165,22 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
 int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const float* params_dev,
                int32_t B, const float* mean_host, const float* std_host, float* out_dev);
 
+/* ---- generic train step (the other baselines of main.py's --exp switch) -----
+ * train_RSCFed (utils/local_training.py:705-769), train_FedNoRo (:115-234) and train_CBAFed
+ * (:236-342) differ from the steps above only in the loss head on the [B,C] logits.  The split
+ * step lets the host mirror compute that head: fm_forward_train runs the train-mode forward of one
+ * view (x2_dev NULL) or two views (BN statistics per view, logits view-major [views*B][C]);
+ * fm_backward_step takes d(loss)/d(logits) of the same shape, runs the backward pass and
+ * optimizer.step().  The pair must be called back to back. */
+int fm_forward_train(fm_engine* e, const float* x1_dev, const float* x2_dev, int32_t B, float* feat_dev,
+                     float* logits_dev);
+int fm_backward_step(fm_engine* e, const float* dlogits_dev);
+/* teacher <- w_teacher*teacher + w_student*student over every state entry (train_RSCFed's EMA,
+ * utils/local_training.py:751-759, weights 0.999 / 0.001). */
+int fm_teacher_axpby(fm_engine* e, float w_teacher, float w_student);
+/* exchange the student and teacher slots (so fm_set_state / fm_get_state reach the teacher) */
+int fm_teacher_swap(fm_engine* e);
+
 /* ---- EfficientNet-B0 training-time randomness -----------------------------------
  * The reference's model draws drop-connect (MBConvBlock, p = 0.2*idx/16 per block, per sample)
  * and dropout (p = 0.2 before `_fc`) inside net(images) (utils/local_training.py:657, 937-947,

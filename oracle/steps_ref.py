@@ -80,6 +80,76 @@ def loss_fixmatch(z_weak, z_strong, y, pos_w, pos_w_unknown, act, neg, bs_norm,
 # --------------------------------------------------------------------------
 # label masking (DatasetSplit / DatasetSplit_pseudo)
 # --------------------------------------------------------------------------
+# ---- loss heads of the other baselines ------------------------------------
+def loss_rscfed(z_student, z_teacher, y, pos_weight, act, neg, bs_norm, annotation_num):
+    """train_RSCFed loss (utils/local_training.py:719, 740-743): BCEWithLogits(pos_weight) on the
+    active classes / (args.batch_size*annotation_num) + nn.MSELoss() (mean over B*|neg| elements)
+    between student(view 1) and EMA-teacher(view 2) probabilities on the missing classes."""
+    l = F.binary_cross_entropy_with_logits(
+        z_student, y, pos_weight=torch.as_tensor(pos_weight, dtype=torch.float32, device=z_student.device),
+        reduction="none")
+    sup = l[:, act].sum() / (bs_norm * annotation_num)
+    unsup = F.mse_loss(torch.sigmoid(z_student)[:, neg], torch.sigmoid(z_teacher.detach())[:, neg])
+    return sup + unsup
+
+
+def loss_la_kd(z_student, z_teacher, y, act, neg, w_kd):
+    """train_FedNoRo warm-up loss = LA_KD.forward (utils/FedNoRo.py:35-38) on sigmoid(logits) with
+    soft_label = sigmoid(teacher/0.8) (utils/local_training.py:143-151): both terms are divided by
+    the ACTUAL batch length len(x)."""
+    p = torch.sigmoid(z_student)
+    soft = torch.sigmoid(z_teacher.detach() / 0.8)
+    B = p.shape[0]
+    bce = bce_on_probs(p, y)[:, act].sum() / (B * len(act))
+    kl = F.mse_loss(p, soft, reduction="none")[:, neg].sum() / (B * len(neg))
+    return w_kd * kl + (1 - w_kd) * bce
+
+
+def loss_cbafed_stage1(z, y, pos_weight, act, bs_norm, annotation_num):
+    """train_CBAFed warm-up loss (utils/local_training.py:247-248, 266-269)."""
+    l = F.binary_cross_entropy_with_logits(
+        z, y, pos_weight=torch.as_tensor(pos_weight, dtype=torch.float32, device=z.device), reduction="none")
+    return l[:, act].sum() / (bs_norm * annotation_num)
+
+
+def cbafed_stage2_targets(prob, y, neg, tao, loss_w):
+    """Per-batch pseudo-labelling of train_CBAFed stage 2 (utils/local_training.py:303-316).
+    Returns (labels, idx_neg [per negative class: LongTensor of rows], loss_w (updated copy),
+    per-class pseudo counts)."""
+    labels = y.clone()
+    loss_w = list(loss_w)
+    idx_neg, counts = [], []
+    for i in neg:
+        hi = prob[:, i] > tao[i]
+        lo = prob[:, i] < (1 - tao[i])
+        noise_num, clean_num = int(hi.sum()), int(lo.sum())
+        labels[:, i] = torch.where(hi, torch.ones_like(labels[:, i]), labels[:, i])
+        pseudo = torch.where(hi | lo)[0]
+        idx_neg.append(pseudo)
+        counts.append(len(pseudo))
+        loss_w[i] = 1 if noise_num == 0 else (noise_num + clean_num) / noise_num
+    return labels, idx_neg, loss_w, counts
+
+
+def loss_cbafed_stage2(z, labels, idx_neg, loss_w, act, neg, bs_norm, annotation_num):
+    """train_CBAFed stage-2 loss (utils/local_training.py:321-331)."""
+    l = F.binary_cross_entropy_with_logits(
+        z, labels, pos_weight=torch.as_tensor(loss_w, dtype=torch.float32, device=z.device), reduction="none")
+    loss = l[:, act].sum() / (bs_norm * annotation_num)
+    for k, i in enumerate(neg):
+        if len(idx_neg[k]) != 0:
+            loss = loss + l[idx_neg[k], i].sum() / len(idx_neg[k])
+    return loss
+
+
+def consistency_weight(rnd, begin, end):
+    """get_current_consistency_weight -> sigmoid_rampup (utils/FedNoRo.py:72-81):
+    exp(-5 (1 - (clip(rnd, begin, end)-begin)/(end-begin))^2), i.e. exp(-5) before `begin`, 1 after `end`."""
+    cur = float(np.clip(rnd, begin, end))
+    phase = 1.0 - (cur - begin) / (end - begin)
+    return float(np.exp(-5.0 * phase * phase))
+
+
 def class_counts(targets, idxs):
     """DatasetSplit.get_num_of_each_class (utils/local_training.py:1358-1362):
     per-class sum of the UNMASKED targets over the client's indices (float64)."""
@@ -305,6 +375,79 @@ class RefClient:
             opt.zero_grad(); loss.backward(); opt.step()
             losses.append(loss.item())
         return net.state_dict(), float(np.mean(losses)), losses
+
+    # -- LocalUpdate.train_RSCFed (utils/local_training.py:705-769) ------------
+    def train_rscfed(self, net, teacher, order):
+        """`teacher` (self.teacher_neg in the reference) is updated in place by the per-step EMA
+        over every state_dict entry (int64 counters: float result truncated on load)."""
+        a = self.args
+        student = copy.deepcopy(net)
+        teacher.eval(); student.train()
+        opt = _adam(student, a.base_lr)
+        losses = []
+        for pos in _batches(order, a.batch_size):
+            _, z1 = student(self._img("image_aug_1", pos))
+            with torch.no_grad():
+                _, zt = teacher(self._img("image_aug_2", pos))
+            loss = loss_rscfed(z1, zt, self.y_masked[pos], self.loss_w, self.active, self.negative,
+                               a.batch_size, a.annotation_num)
+            opt.zero_grad(); loss.backward(); opt.step()
+            sd1, sd2 = teacher.state_dict(), student.state_dict()
+            teacher.load_state_dict({k: (1 - 0.001) * sd1[k] + 0.001 * sd2[k] for k in sd1})
+            losses.append(loss.item())
+        return student.state_dict(), float(np.mean(losses)), losses
+
+    # -- LocalUpdate.train_FedNoRo, warm-up branch (utils/local_training.py:118-155) --
+    def train_fednoro(self, net, order, weight_kd):
+        a = self.args
+        student, teacher = copy.deepcopy(net), copy.deepcopy(net)
+        student.train(); teacher.eval()
+        opt = _adam(student, a.base_lr)
+        for i in self.negative:                 # :136-137 zeroes the missing classes' counts
+            self.class_num_list[i] = 0
+        losses = []
+        for pos in _batches(order, a.batch_size):
+            x = self._img("image", pos)
+            _, z = student(x)
+            with torch.no_grad():
+                _, zt = teacher(x)
+            loss = loss_la_kd(z, zt, self.y_masked[pos], self.active, self.negative, weight_kd)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+        return student.state_dict(), float(np.mean(losses)), losses
+
+    # -- LocalUpdate.train_CBAFed (utils/local_training.py:236-342) ---------------
+    def train_cbafed(self, net, order, tao=None):
+        """tao None = warm-up stage.  Returns (state_dict, mean loss, losses, class_num_list, data_num)."""
+        a = self.args
+        net.train()
+        opt = _adam(net, a.base_lr)
+        class_num = torch.zeros(a.n_classes)
+        data_num = 0
+        losses = []
+        for pos in _batches(order, a.batch_size):
+            y = self.y_masked[pos]
+            _, z = net(self._img("image", pos))
+            if tao is None:
+                data_num += len(pos)
+                loss = loss_cbafed_stage1(z, y, self.loss_w, self.active, a.batch_size, a.annotation_num)
+            else:
+                labels, idx_neg, self.loss_w, counts = cbafed_stage2_targets(
+                    torch.sigmoid(z.detach()), y, self.negative, tao, self.loss_w)
+                for k, i in enumerate(self.negative):
+                    class_num[i] += counts[k]
+                    data_num += counts[k]
+                for i in self.active:
+                    class_num[i] += len(pos)
+                data_num += len(pos) * a.annotation_num
+                loss = loss_cbafed_stage2(z, labels, idx_neg, self.loss_w, self.active, self.negative,
+                                          a.batch_size, a.annotation_num)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+        if tao is None:
+            for i in self.active:
+                class_num[i] = data_num
+        return net.state_dict(), float(np.mean(losses)), losses, class_num.tolist(), int(data_num)
 
     # -- LocalUpdate.train_FixMatch (utils/local_training.py:771-825) --------
     def train_fixmatch(self, net, order):

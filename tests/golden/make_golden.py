@@ -392,10 +392,74 @@ def g_eval(out):
 
 
 
+def g_baselines(out):
+    """one round each of train_RSCFed (utils/local_training.py:705-769),
+    train_FedNoRo warm-up (:115-155) and train_CBAFed warm-up + pseudo-label stage (:236-342)
+    through the imported reference: 1 client, 72 samples, C=4, bs 32 (tail batch 8), 32x32."""
+    C, N, hw = 4, 72, 32
+    rs = np.random.RandomState(404)
+    rec = {"C": C, "N": N, "hw": hw, "init_seed": 1037, "bs": 32}
+
+    # ---- RSCFed: two views, EMA teacher persists in the LocalUpdate ---------------------------
+    args = make_args(n_classes=C, n_clients=1)
+    ds = SynthDataset(N, C, hw, 41, True)
+    pos, neg = class_lists(ds.targets, C)
+    net = build_net(C, 1037)
+    teacher = build_net(C, 2024)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[0],
+                         teacher_neg=teacher)
+    order = rs.permutation(N).tolist()
+    ORDERS.append(order)
+    loc.ldr_train = FixedLoader(loc.local_dataset, 32, True)
+    ret = loc.train_RSCFed(0, deepcopy(net))
+    rec["rscfed"] = {"data_seed": 41, "teacher_seed": 2024, "order": order, "loss": float(ret[1]),
+                     "norms": tensor_norms(ret[0]), "teacher_norms": tensor_norms(loc.teacher_neg.state_dict()),
+                     "neg": ret[4], "act": ret[5], "loss_w": loc.loss_w}
+
+    # ---- FedNoRo warm-up: single view, frozen round-start teacher, LA_KD -------------------------
+    args = make_args(n_classes=C, n_clients=1, rounds_FedNoRo_warmup=500)
+    ds = SynthDataset(N, C, hw, 42, False)
+    pos, neg = class_lists(ds.targets, C)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[1])
+    order = rs.permutation(N).tolist()
+    ORDERS.append(order)
+    loc.ldr_train = FixedLoader(loc.local_dataset, 32, True)
+    w_kd = float(FN.get_current_consistency_weight(100, 10, 499) * 0.8)
+    ret = loc.train_FedNoRo(0, 100, deepcopy(net), None, weight_kd=w_kd)
+    rec["fednoro"] = {"data_seed": 42, "order": order, "weight_kd": w_kd, "rnd": 100, "begin": 10, "end": 499,
+                      "a": 0.8, "loss": float(ret[1]), "norms": tensor_norms(ret[0]), "neg": ret[4], "act": ret[5],
+                      "class_num_list": [float(v) for v in loc.class_num_list]}
+
+    # ---- CBAFed: warm-up round, then one pseudo-labelling round with tao ---------------------------
+    args = make_args(n_classes=C, n_clients=1, rounds_CBAFed_warmup=1)
+    ds = SynthDataset(N, C, hw, 43, False)
+    pos, neg = class_lists(ds.targets, C)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[2])
+    o1, o2 = rs.permutation(N).tolist(), rs.permutation(N).tolist()
+    ORDERS.append(o1)
+    loc.ldr_train = FixedLoader(loc.local_dataset, 32, True)
+    net1 = deepcopy(net)
+    r1 = loc.train_CBAFed(0, net1)
+    w1 = deepcopy(r1[0])
+    tao = [0.52, 0.5, 0.55, 0.51]
+    ORDERS.append(o2)
+    loc.ldr_train = FixedLoader(loc.local_dataset, 32, True)
+    net2 = deepcopy(net)
+    net2.load_state_dict(w1)
+    r2 = loc.train_CBAFed(1, net2, pt=None, tao=tao)
+    rec["cbafed"] = {"data_seed": 43, "orders": [o1, o2], "tao": tao,
+                     "loss": [float(r1[1]), float(r2[1])],
+                     "norms": [tensor_norms(w1), tensor_norms(r2[0])],
+                     "class_num_list": [[float(v) for v in r1[6]], [float(v) for v in r2[6]]],
+                     "data_num": [int(r1[7]), int(r2[7])],
+                     "loss_w_after": [float(v) for v in loc.loss_w], "neg": r2[4], "act": r2[5]}
+    json.dump(rec, open(os.path.join(out, "traj_baselines.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224", "eval"]
+    which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224", "eval", "baselines"]
     fns = {"kat": g_kat, "train": g_train_traj, "fedmlp": g_fedmlp_traj,
-           "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval}
+           "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval, "baselines": g_baselines}
     for w in which:
         print("==> golden:", w, flush=True)
         fns[w](HERE)

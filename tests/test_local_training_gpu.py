@@ -250,3 +250,74 @@ def test_step224_full_size():
     assert report["stage1 loss rel err"] < 1e-4
     _cmp_norms(_norms(out[0]), g["stage1"]["norms"], 1e-4, "stage1_224", report)
     _dump(report, "parity_step224.json")
+
+
+def test_traj_baselines_rscfed_fednoro_cbafed():
+    """train_RSCFed / train_FedNoRo (warm-up) / train_CBAFed through the drop-in
+    surface replay the trajectories recorded from the imported reference."""
+    from fedmlp_amd.model import build_model
+    from fedmlp_amd.local_training import LocalUpdate
+    from fedmlp_amd.fedavg import consistency_weight
+    g = load_golden("traj_baselines.json")
+    C, N, hw = g["C"], g["N"], g["hw"]
+    report = {}
+
+    def fresh(seed):
+        return build_model(make_args(n_classes=C, n_clients=1, seed=seed))
+
+    # ---- RSCFed -------------------------------------------------------------------------------
+    r = g["rscfed"]
+    args = make_args(n_classes=C, n_clients=1, seed=g["init_seed"])
+    ds = SynthDataset(N, C, hw, r["data_seed"], True)
+    pos, neg = class_lists(ds.targets, C)
+    teacher = fresh(r["teacher_seed"])
+    loc = LocalUpdate(args, 0, ds, list(range(N)), pos, neg, active_class_list=[0], teacher_neg=teacher)
+    np.testing.assert_allclose(loc.loss_w, r["loss_w"], rtol=0)
+    loc.order_queue.append(r["order"])
+    out = loc.train_RSCFed(0, fresh(g["init_seed"]))
+    report["rscfed loss rel err"] = abs(out[1] - r["loss"]) / abs(r["loss"])
+    assert report["rscfed loss rel err"] < 2e-3, (out[1], r["loss"])
+    assert out[4] == r["neg"] and out[5] == r["act"]
+    _cmp_norms(_norms(out[0]), r["norms"], 1e-3, "rscfed student", report)
+    _cmp_norms(_norms(teacher.state_dict()), r["teacher_norms"], 1e-4, "rscfed teacher", report)
+
+    # ---- FedNoRo warm-up --------------------------------------------------------------------------
+    r = g["fednoro"]
+    args = make_args(n_classes=C, n_clients=1, seed=g["init_seed"], rounds_FedNoRo_warmup=500)
+    ds = SynthDataset(N, C, hw, r["data_seed"], False)
+    pos, neg = class_lists(ds.targets, C)
+    loc = LocalUpdate(args, 0, ds, list(range(N)), pos, neg, active_class_list=[1])
+    loc.order_queue.append(r["order"])
+    w_kd = consistency_weight(r["rnd"], r["begin"], r["end"]) * r["a"]
+    assert abs(w_kd - r["weight_kd"]) < 1e-12
+    out = loc.train_FedNoRo(0, r["rnd"], fresh(g["init_seed"]), None, weight_kd=w_kd)
+    report["fednoro loss rel err"] = abs(out[1] - r["loss"]) / abs(r["loss"])
+    assert report["fednoro loss rel err"] < 2e-3, (out[1], r["loss"])
+    _cmp_norms(_norms(out[0]), r["norms"], 1e-3, "fednoro", report)
+    np.testing.assert_allclose(loc.class_num_list, r["class_num_list"], rtol=0)
+    with pytest.raises(NotImplementedError):
+        loc.train_FedNoRo(0, 500, fresh(g["init_seed"]), None, weight_kd=w_kd)
+
+    # ---- CBAFed: warm-up round, then a pseudo-labelling round ------------------------------------------
+    r = g["cbafed"]
+    args = make_args(n_classes=C, n_clients=1, seed=g["init_seed"], rounds_CBAFed_warmup=1)
+    ds = SynthDataset(N, C, hw, r["data_seed"], False)
+    pos, neg = class_lists(ds.targets, C)
+    loc = LocalUpdate(args, 0, ds, list(range(N)), pos, neg, active_class_list=[2])
+    net = fresh(g["init_seed"])
+    loc.order_queue.append(r["orders"][0])
+    out = loc.train_CBAFed(0, net)
+    assert abs(out[1] - r["loss"][0]) < 2e-3 * abs(r["loss"][0])
+    _cmp_norms(_norms(out[0]), r["norms"][0], 1e-3, "cbafed warm-up", report)
+    assert out[6].tolist() == r["class_num_list"][0] and out[7] == r["data_num"][0]
+    net.load_state_dict(out[0])
+    loc.order_queue.append(r["orders"][1])
+    out = loc.train_CBAFed(1, net, pt=None, tao=r["tao"])
+    report["cbafed stage-2 loss rel err"] = abs(out[1] - r["loss"][1]) / abs(r["loss"][1])
+    assert report["cbafed stage-2 loss rel err"] < 5e-3, (out[1], r["loss"][1])
+    _cmp_norms(_norms(out[0]), r["norms"][1], 1e-3, "cbafed stage 2", report, rnd=1)
+    # thresholded counts: a probability within rounding of tao may fall on the other side
+    np.testing.assert_allclose(out[6].tolist(), r["class_num_list"][1], atol=2)
+    assert abs(out[7] - r["data_num"][1]) <= 4
+    np.testing.assert_allclose(loc.loss_w, r["loss_w_after"], rtol=0.15)
+    _dump(report, "parity_traj_baselines.json")

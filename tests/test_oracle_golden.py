@@ -205,3 +205,49 @@ def test_step224():
     ret = cl.stage1(copy.deepcopy(net0), list(range(N)), with_proto=False)
     assert abs(ret[1] - g["stage1"]["loss"]) <= 1e-5 * abs(ret[1])
     assert_norms_close(norms_of(ret[0]), g["stage1"]["norms"], 1e-5)
+
+
+def test_traj_baselines_rscfed_fednoro_cbafed():
+    """the oracle's restatement of train_RSCFed / train_FedNoRo (warm-up) /
+    train_CBAFed follows the imported reference (tests/golden/traj_baselines.json)."""
+    g = load_golden("traj_baselines.json")
+    C, N, hw = g["C"], g["N"], g["hw"]
+    args = make_args(n_classes=C, n_clients=1)
+    # RSCFed
+    r = g["rscfed"]
+    data = data_dict(N, C, hw, r["data_seed"], True)
+    _, neg = class_lists(data["targets"], C)
+    cl = R.RefClient(args, 0, data, list(range(N)), neg, [0])
+    np.testing.assert_allclose(cl.loss_w, r["loss_w"], rtol=0)
+    teacher = oracle_net(C, r["teacher_seed"])
+    sd, loss, _ = cl.train_rscfed(oracle_net(C, g["init_seed"]), teacher, r["order"])
+    assert abs(loss - r["loss"]) <= 1e-5 * abs(r["loss"])
+    assert_norms_close(norms_of(sd), r["norms"], 1e-5)
+    assert_norms_close(norms_of(teacher.state_dict()), r["teacher_norms"], 1e-6)
+    assert cl.negative == r["neg"] and cl.active == r["act"]
+    # FedNoRo warm-up
+    r = g["fednoro"]
+    data = data_dict(N, C, hw, r["data_seed"], False)
+    _, neg = class_lists(data["targets"], C)
+    cl = R.RefClient(args, 0, data, list(range(N)), neg, [1])
+    w_kd = R.consistency_weight(r["rnd"], r["begin"], r["end"]) * r["a"]
+    assert abs(w_kd - r["weight_kd"]) < 1e-12
+    sd, loss, _ = cl.train_fednoro(oracle_net(C, g["init_seed"]), r["order"], w_kd)
+    assert abs(loss - r["loss"]) <= 1e-5 * abs(r["loss"])
+    assert_norms_close(norms_of(sd), r["norms"], 1e-5)
+    np.testing.assert_allclose(cl.class_num_list, r["class_num_list"], rtol=0)
+    # CBAFed: warm-up round then pseudo-labelling round
+    r = g["cbafed"]
+    data = data_dict(N, C, hw, r["data_seed"], False)
+    _, neg = class_lists(data["targets"], C)
+    cl = R.RefClient(args, 0, data, list(range(N)), neg, [2])
+    net = oracle_net(C, g["init_seed"])
+    sd, loss, _, cnum, dnum = cl.train_cbafed(net, r["orders"][0])
+    assert abs(loss - r["loss"][0]) <= 1e-5 * abs(r["loss"][0])
+    assert_norms_close(norms_of(sd), r["norms"][0], 1e-5)
+    assert cnum == r["class_num_list"][0] and dnum == r["data_num"][0]
+    sd, loss, _, cnum, dnum = cl.train_cbafed(net, r["orders"][1], tao=r["tao"])
+    assert abs(loss - r["loss"][1]) <= 1e-5 * abs(r["loss"][1])
+    assert_norms_close(norms_of(sd), r["norms"][1], 1e-5)
+    assert cnum == r["class_num_list"][1] and dnum == r["data_num"][1]
+    np.testing.assert_allclose(cl.loss_w, r["loss_w_after"], rtol=1e-12)
