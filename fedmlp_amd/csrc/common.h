@@ -26,6 +26,7 @@ struct IgemmParams {
     int ntaps;
     int tap_minor;        // K walked chunk-major / tap-minor (L2 reuse) instead of tap-major
     int stem_kw, stem_pad;
+    int stem_h2;          // 1: kernel width padded to 8 (two 16-k steps per kernel row), 0: padded to 4
     const float* zeros;   // >= 16 B of zeros (source of padded / out-of-range chunks)
     const float* res;     // optional residual, indexed like Y (may alias Y)
     const float* scale;   // optional per-m affine (eval-mode BN folded), else null
@@ -57,6 +58,7 @@ struct WgradParams {
     int npix;             // imgs*Ho*Wo
     int pix_per_split;    // multiple of 32
     int tilesM, tilesN;
+    int gather_k, gather_pad, gather_kw_p;   // stem form for launch_wgrad_skinny (kernel size, top/left pad, padded width)
 };
 
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);

@@ -369,7 +369,12 @@ void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* i
 }
 
 // ------------------------------------------------------------ BN backward ------
-int bn_bwd_blocks(int pix_per_group) { return max(1, min(256, cdiv(pix_per_group, 64))); }
+int bn_bwd_blocks(int pix_per_group)
+{
+    // blocks per group of the channel reductions (<= 1024: ws_part is sized for that)
+    static const int cap = getenv("FM_BN_BLOCKS") ? std::min(1024, std::max(1, atoi(getenv("FM_BN_BLOCKS")))) : 1024;
+    return max(1, min(cap, cdiv(pix_per_group, 64)));
+}
 
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                      const float* __restrict__ y, const float* __restrict__ mean,

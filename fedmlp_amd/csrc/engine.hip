@@ -192,7 +192,7 @@ int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hi
     const bool eff = e->model == 1;
     c.cin_p = (cin == 3) ? 4 : (eff ? (cin + 15) / 16 * 16 : cin);
     c.cout_p = eff ? (cout + 15) / 16 * 16 : cout;
-    c.kw_p = (cin == 3) ? 8 : k;
+    c.kw_p = (cin == 3) ? (k <= 4 ? 4 : 8) : k;
     c.hin = hin; c.win = win;
     if (eff) {                       // TF-"same": out = ceil(in/stride); pad here = top/left padding
         c.hout = (hin + stride - 1) / stride;
@@ -484,7 +484,7 @@ int alloc_workspaces(fm_engine* e)
         DALLOC(e->hfeat, B * e->D);
     }
     DALLOC(e->ws_stats, max_stats);
-    DALLOC(e->ws_part, (size_t)2 * (256 + 32) * 2 * e->maxC);   // per-block partials + folded partials
+    DALLOC(e->ws_part, (size_t)2 * (1024 + 32) * 2 * e->maxC);   // per-block partials + folded partials
     e->slab_floats = std::max<size_t>(max_slab * 8, (size_t)48 << 20);   // >= 192 MB of partial slabs
     DALLOC(e->ws_slab, e->slab_floats);
     DALLOC(e->ca, 2 * e->maxC); DALLOC(e->cb, 2 * e->maxC); DALLOC(e->cc, 2 * e->maxC);
@@ -525,7 +525,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     const Conv& c = e->convs[ci];
     IgemmParams p{};
     p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
-    if (c.cin == 3) { p.stem_kw = c.k; p.stem_pad = c.pad; }
+    if (c.cin == 3) { p.stem_kw = c.k; p.stem_pad = c.pad; p.stem_h2 = c.kw_p == 8 ? 1 : 0; }
     else
     {
         p.ntaps = c.k * c.k;
@@ -592,7 +592,8 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
     p.M = c.cout_p; p.Nw = c.Kw;
     p.Ho = c.hout; p.Wo = c.wout; p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p; p.stride = c.stride;
     p.npix = imgs * c.hout * c.wout;
-    if (c.k == 1 && e->model == 1) {
+    if (e->model == 1 && (c.k == 1 || c.cin == 3)) {
+        if (c.cin == 3) { p.gather_k = c.k; p.gather_pad = c.pad; p.gather_kw_p = c.kw_p; }
         int sk;
         {
             ProfScope ps(e, 4, 2.0 * c.macs_per_img * imgs);

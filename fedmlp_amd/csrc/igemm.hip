@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             int dh, dw, c0, koff;
             bool cv = true;
             if constexpr (STEM) {
-                // stem: K = (kh, kw padded to 8, ci padded to 4); step = half a kernel row, chunk = kw
-                const int kw = ((s & 1) << 2) + (csrc >> 2);
-                dh = (s >> 1) - p.stem_pad; dw = kw - p.stem_pad; c0 = 0; cv = kw < p.stem_kw;
+                // stem: K = (kh, kw padded to 8 or 4, ci padded to 4); step = (half) a kernel row, chunk = kw
+                const int kw = ((s & p.stem_h2) << 2) + (csrc >> 2);
+                dh = (s >> p.stem_h2) - p.stem_pad; dw = kw - p.stem_pad; c0 = 0; cv = kw < p.stem_kw;
                 koff = s * 16;
             } else {
                 if (p.tap_minor) {

@@ -158,6 +158,9 @@ struct SkinnyParams {
     const float* zeros;
     int L, S, M, Nw, swap;
     int npix, pix_per_split;
+    // gather != 0: the X operand is the im2col row of a stem conv (Ci = 4): 16-B chunk c of a row is
+    // input pixel (oh*stride + c/kw_p - pad, ow*stride + c%kw_p - pad), valid while c%kw_p < k
+    int gather, Hi, Wi, Ho, Wo, stride, pad, k, kw_p;
 };
 
 template <int CC>
@@ -181,12 +184,24 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
     const int ca = tid & 15, ra = tid >> 4;       // rows ra, ra+16
     const bool a_ok = l0 + 4 * ca < p.L;
     f32x4 va[2], vb[NB];
+    // address of 16-B chunk `ch` of pixel `pix` of the X operand in gather (stem) mode
+    auto xgather = [&](const float* X, int pix, int ch) -> const float* {
+        const int HWo = p.Ho * p.Wo;
+        const int img = pix / HWo, rem = pix - img * HWo;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int kh = ch / p.kw_p, kw = ch - kh * p.kw_p;
+        const int ih = oh * p.stride + kh - p.pad, iw = ow * p.stride + kw - p.pad;
+        const bool ok = kw < p.k && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        return ok ? X + ((size_t)(img * p.Hi + ih) * p.Wi + iw) * 4 : p.zeros;
+    };
+    const bool big_g = p.gather && p.swap, small_g = p.gather && !p.swap;
     auto gload = [&](int s) {
         const int pb = pbeg + s * 32;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pix = pb + ra + 16 * q;
-            const float* src = (a_ok && pix < pend) ? p.Big + (size_t)pix * p.L + l0 + 4 * ca : p.zeros;
+            const float* src = p.zeros;
+            if (a_ok && pix < pend) src = big_g ? xgather(p.Big, pix, (l0 >> 2) + ca) : p.Big + (size_t)pix * p.L + l0 + 4 * ca;
             va[q] = *reinterpret_cast<const f32x4*>(src);
         }
 #pragma unroll
@@ -194,7 +209,8 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
             const int c = tid + 256 * q;
             const int row = c / CB, cb = c - row * CB;
             const int pix = pb + row;
-            const float* src = (c < 32 * CB && 4 * cb < p.S && pix < pend) ? p.Small + (size_t)pix * p.S + 4 * cb : p.zeros;
+            const float* src = p.zeros;
+            if (c < 32 * CB && 4 * cb < p.S && pix < pend) src = small_g ? xgather(p.Small, pix, cb) : p.Small + (size_t)pix * p.S + 4 * cb;
             vb[q] = *reinterpret_cast<const f32x4*>(src);
         }
     };
@@ -248,8 +264,14 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
 int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
 {
     const int S = std::min(w.M, w.Nw), L = std::max(w.M, w.Nw);
-    if (S > 128 || w.stride != 1 || w.Ci != w.Nw || w.Ho != w.Hi || w.Wo != w.Wi) return 0;
+    const bool stem = w.Ci == 4 && w.gather_k > 0;
+    if (S > 128) return 0;
+    if (!stem && (w.stride != 1 || w.Ci != w.Nw || w.Ho != w.Hi || w.Wo != w.Wi)) return 0;
     SkinnyParams p{};
+    if (stem) {
+        p.gather = 1; p.Hi = w.Hi; p.Wi = w.Wi; p.Ho = w.Ho; p.Wo = w.Wo; p.stride = w.stride;
+        p.pad = w.gather_pad; p.k = w.gather_k; p.kw_p = w.gather_kw_p;
+    }
     p.swap = w.Nw > w.M;      // large operand is X
     p.Big = p.swap ? w.X : w.dY;
     p.Small = p.swap ? w.dY : w.X;
