@@ -70,7 +70,8 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
                                    const float* __restrict__ mean, const float* __restrict__ istd,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ rowscale, float* __restrict__ part, int pix_per_group,
-                                   int HW, int C, int mode, int act)
+                                   int HW, int C, int mode, int act, const float* __restrict__ gate,
+                                   const float* __restrict__ dsv)
 {
     __shared__ f32x4 red[2][256];
     const int g = blockIdx.y, nblk = gridDim.x;
@@ -103,6 +104,11 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
                 } else {
                     f32x4 d = *reinterpret_cast<const f32x4*>(a + o);
                     const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+                    if (gate) {          // squeeze-excite backward folded in: d(a_d) = d(a_s)*gate + ds/HW
+                        const size_t io = ((size_t)g * (pix_per_group / HW) + p / HW) * C + cq * 4;
+                        d = d * *reinterpret_cast<const f32x4*>(gate + io) +
+                            *reinterpret_cast<const f32x4*>(dsv + io) * (1.f / (float)HW);
+                    }
                     if (act == 2) {
                         const f32x4 v = yy * sc + sh;
 #pragma unroll
@@ -127,10 +133,10 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
 }
 void k_chan_reduce(const float* a, const float* y, const float* mean, const float* istd, const float* scale,
                    const float* shift, const float* rowscale, float* part, int groups, int pix_per_group, int HW,
-                   int C, int mode, int act, hipStream_t s)
+                   int C, int mode, int act, const float* gate, const float* dsv, hipStream_t s)
 {
     hipLaunchKernelGGL(chan_reduce_kernel, dim3(bn_bwd_blocks(pix_per_group), groups), dim3(256), 0, s, a, y, mean,
-                       istd, scale, shift, rowscale, part, pix_per_group, HW, C, mode, act);
+                       istd, scale, shift, rowscale, part, pix_per_group, HW, C, mode, act, gate, dsv);
 }
 
 // dy = ca*dyh + cb*y + cc with dyh = dz * act'(v) * rowscale
@@ -138,7 +144,8 @@ __global__ void bnact_bwd_apply_kernel(const float* __restrict__ dz, const float
                                        const float* __restrict__ ca, const float* __restrict__ cb,
                                        const float* __restrict__ cc, const float* __restrict__ scale,
                                        const float* __restrict__ shift, const float* __restrict__ rowscale,
-                                       float* __restrict__ dy, int pix_per_group, int HW, int C, int act)
+                                       float* __restrict__ dy, int pix_per_group, int HW, int C, int act,
+                                       const float* __restrict__ gate, const float* __restrict__ dsv)
 {
     const int g = blockIdx.y;
     const int Q = C >> 2;
@@ -151,6 +158,10 @@ __global__ void bnact_bwd_apply_kernel(const float* __restrict__ dz, const float
         const size_t o = base + (size_t)i * 4;
         f32x4 d = *reinterpret_cast<const f32x4*>(dz + o);
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+        if (gate) {
+            const size_t io = ((size_t)g * (pix_per_group / HW) + pix / HW) * C + cq * 4;
+            d = d * *reinterpret_cast<const f32x4*>(gate + io) + *reinterpret_cast<const f32x4*>(dsv + io) * (1.f / (float)HW);
+        }
         if (act == 2) {
             const f32x4 v = yy * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
                             *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
@@ -165,11 +176,11 @@ __global__ void bnact_bwd_apply_kernel(const float* __restrict__ dz, const float
 }
 void k_bnact_bwd_apply(const float* dz, const float* y, const float* ca, const float* cb, const float* cc,
                        const float* scale, const float* shift, const float* rowscale, float* dy, int groups,
-                       int pix_per_group, int HW, int C, int act, hipStream_t s)
+                       int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s)
 {
     const int64_t n4 = (int64_t)pix_per_group * (C / 4);
     hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(std::min(2048, cdiv(n4, 256)), groups), dim3(256), 0, s, dz, y,
-                       ca, cb, cc, scale, shift, rowscale, dy, pix_per_group, HW, C, act);
+                       ca, cb, cc, scale, shift, rowscale, dy, pix_per_group, HW, C, act, gate, dsv);
 }
 
 // ------------------------------------------------------------ depthwise conv ---
@@ -533,9 +544,13 @@ void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, 
                            pad_t, pad_l, QT, P);
 }
 
-// per-image channel sums over a chunk of pixels: part[img][chunk][C] = sum_p a[p][c] (* b[p][c])
+// per-image channel sums over a chunk of pixels: part[img][chunk][C] = sum_p a[p][c] (* b[p][c]).
+// `tsel` 1 / 2: operand a / b is a raw BN input and is read as swish(v*scale[g]+shift[g]), g = img/ipg
+// (the post-BN activation is never materialised).
 __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        float* __restrict__ part, int HW, int C, int QT, int P)
+                                                        float* __restrict__ part, int HW, int C, int QT, int P,
+                                                        int tsel, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int ipg)
 {
     __shared__ f32x4 red[256];
     const int img = blockIdx.y, nch = gridDim.x;
@@ -543,12 +558,23 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
     const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
     const int chunk = (HW + nch - 1) / nch;
     const int pb = blockIdx.x * chunk, pe = min(HW, pb + chunk);
+    const int g = tsel ? img / ipg : 0;
     for (int cq = cq0; cq < Q; cq += QT) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (tsel) {
+            sc = *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4);
+            sh = *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+        }
         for (int p = pb + pl; p < pe; p += P) {
             const size_t o = ((size_t)img * HW + p) * C + cq * 4;
             f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
-            if (b) v = v * *reinterpret_cast<const f32x4*>(b + o);
+            if (tsel == 1) v = act_fwd(v * sc + sh, 2);
+            if (b) {
+                f32x4 w = *reinterpret_cast<const f32x4*>(b + o);
+                if (tsel == 2) w = act_fwd(w * sc + sh, 2);
+                v = v * w;
+            }
             s1 += v;
         }
         __syncthreads();
@@ -561,11 +587,13 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
     }
 }
 int chan_pool_chunks(int HW) { return std::max(1, std::min(16, HW / 64)); }
-void k_chan_pool(const float* a, const float* b, float* part, int imgs, int HW, int C, hipStream_t s)
+void k_chan_pool(const float* a, const float* b, float* part, int imgs, int HW, int C, int tsel, const float* scale,
+                 const float* shift, int ipg, hipStream_t s)
 {
     int QT, P, yt;
     dw_map(C, QT, P, yt);
-    hipLaunchKernelGGL(chan_pool_kernel, dim3(chan_pool_chunks(HW), imgs), dim3(QT * P), 0, s, a, b, part, HW, C, QT, P);
+    hipLaunchKernelGGL(chan_pool_kernel, dim3(chan_pool_chunks(HW), imgs), dim3(QT * P), 0, s, a, b, part, HW, C, QT, P,
+                       tsel, scale, shift, ipg);
 }
 
 // ------------------------------------------------------------ squeeze-excite ---
@@ -607,31 +635,40 @@ __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const flo
         gate[(size_t)img * C + c] = sigm(t);
     }
 }
-void k_se_fwd(const float* a, float* pool_ws, const float* W1, const float* b1, const float* W2, const float* b2,
-              float* sq, float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s)
+void k_se_fwd(const float* a, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
+              const float* b1, const float* W2, const float* b2, float* sq, float* rpre, float* gate, int imgs, int HW,
+              int C, int Cs, hipStream_t s)
 {
-    k_chan_pool(a, nullptr, pool_ws, imgs, HW, C, s);
+    k_chan_pool(a, nullptr, pool_ws, imgs, HW, C, scale ? 1 : 0, scale, shift, ipg, s);
     hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
                        W1, b1, W2, b2, sq, rpre, gate, HW, C, Cs);
 }
 
-// out = a * gate[img][c]   (+ optional second output: dsum[img][c] left to se_bwd)
+// out = A * gate[img][c], A = a or (scale != null) swish(a*scale[g]+shift[g]) with g = img/ipg
 __global__ void se_scale_kernel(const float* __restrict__ a, const float* __restrict__ gate, float* __restrict__ out,
-                                int64_t n4, int HW, int C)
+                                int64_t n4, int HW, int C, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int ipg)
 {
     const int Q = C >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int cq = (int)(i % Q);
         const int64_t img = i / Q / HW;
-        *reinterpret_cast<f32x4*>(out + i * 4) =
-            *reinterpret_cast<const f32x4*>(a + i * 4) * *reinterpret_cast<const f32x4*>(gate + img * C + cq * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4);
+        if (scale) {
+            const int g = (int)(img / ipg);
+            v = act_fwd(v * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
+                            *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4), 2);
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = v * *reinterpret_cast<const f32x4*>(gate + img * C + cq * 4);
     }
 }
-void k_se_scale(const float* a, const float* gate, float* out, int imgs, int HW, int C, hipStream_t s)
+void k_se_scale(const float* a, const float* scale, const float* shift, int ipg, const float* gate, float* out, int imgs,
+                int HW, int C, hipStream_t s)
 {
     const int64_t n4 = (int64_t)imgs * HW * (C / 4);
-    hipLaunchKernelGGL(se_scale_kernel, dim3(std::min(4096, cdiv(n4, 256))), dim3(256), 0, s, a, gate, out, n4, HW, C);
+    hipLaunchKernelGGL(se_scale_kernel, dim3(std::min(4096, cdiv(n4, 256))), dim3(256), 0, s, a, gate, out, n4, HW, C,
+                       scale, shift, ipg);
 }
 
 // backward, one block per image:  dgs[c] = sum_hw dout*a ; dgp = dgs*g(1-g) ; dr = W2^T dgp ;
@@ -672,11 +709,11 @@ __global__ void se_bwd_kernel(const float* __restrict__ pool, int nch,
         ds[(size_t)img * C + c] = t;
     }
 }
-void k_se_bwd(const float* dout, const float* a, float* pool_ws, const float* gate, const float* rpre,
-              const float* W1, const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs,
-              hipStream_t s)
+void k_se_bwd(const float* dout, const float* a, const float* scale, const float* shift, int ipg, float* pool_ws,
+              const float* gate, const float* rpre, const float* W1, const float* W2, float* dgp, float* drp, float* ds,
+              int imgs, int HW, int C, int Cs, hipStream_t s)
 {
-    k_chan_pool(dout, a, pool_ws, imgs, HW, C, s);
+    k_chan_pool(dout, a, pool_ws, imgs, HW, C, scale ? 2 : 0, scale, shift, ipg, s);
     hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
                        gate, rpre, W1, W2, dgp, drp, ds, HW, C, Cs);
 }

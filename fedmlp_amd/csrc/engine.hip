@@ -89,7 +89,7 @@ struct MBConv {               // EfficientNet block (efficientnet-pytorch MBConv
     int c_exp = -1, c_proj = -1;          // 1x1 conv indices
     int bn0 = -1, bn1 = -1, bn2 = -1;
     size_t dw_off, w1_off, b1_off, w2_off, b2_off;
-    float *a_e = nullptr, *y_d = nullptr, *a_d = nullptr, *a_s = nullptr, *out = nullptr;
+    float *a_e = nullptr, *y_d = nullptr, *a_s = nullptr, *out = nullptr;
     float *sq = nullptr, *rpre = nullptr, *gate = nullptr;
 };
 
@@ -466,7 +466,7 @@ int alloc_workspaces(fm_engine* e)
         for (auto& m : e->mbs) {
             const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
             if (m.c_exp >= 0) DALLOC(m.a_e, nin * m.ce_p);
-            DALLOC(m.y_d, nout * m.ce_p); DALLOC(m.a_d, nout * m.ce_p); DALLOC(m.a_s, nout * m.ce_p);
+            DALLOC(m.y_d, nout * m.ce_p); DALLOC(m.a_s, nout * m.ce_p);
             DALLOC(m.out, nout * m.cout_p);
             DALLOC(m.sq, B * m.ce_p); DALLOC(m.rpre, B * m.cs); DALLOC(m.gate, B * m.ce_p);
             g_io = std::max(g_io, std::max(nin * m.cin_p, nout * m.cout_p));
@@ -770,7 +770,7 @@ void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per
 {
     Bn& b = e->bns[bi];
     k_chan_reduce(nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr, e->ws_part, groups, pix_per_group, HW, b.C,
-                  0, 0, e->st);
+                  0, 0, nullptr, nullptr, e->st);
     k_bn_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
                   e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
                   e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale, b.shift,
@@ -780,16 +780,16 @@ void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per
 
 // backward through act(bn(y))*rowscale: dz -> dy (may alias dz); writes dgamma/dbeta
 void bnact_bwd(fm_engine* e, int bi, const float* dz, const float* y, float* dy, const float* rowscale, int groups,
-               int pix_per_group, int HW, int act)
+               int pix_per_group, int HW, int act, const float* gate = nullptr, const float* dsv = nullptr)
 {
     Bn& b = e->bns[bi];
     k_chan_reduce(dz, y, b.mean, b.istd, b.scale, b.shift, rowscale, e->ws_part, groups, pix_per_group, HW, b.C, 1,
-                  act, e->st);
+                  act, gate, dsv, e->st);
     k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
                       e->state + e->off_gamma + b.ch_off, b.mean, b.istd, e->ca, e->cb, e->cc,
                       e->grad + e->off_gamma + b.ch_off, e->grad + e->off_beta + b.ch_off, e->st);
     k_bnact_bwd_apply(dz, y, e->ca, e->cb, e->cc, b.scale, b.shift, rowscale, dy, groups, pix_per_group, HW, b.C, act,
-                      e->st);
+                      gate, dsv, e->st);
 }
 
 void eff_forward_train(fm_engine* e, int groups, int B)
@@ -821,12 +821,12 @@ void eff_forward_train(fm_engine* e, int groups, int B)
                  m.pad_t, m.pad_l, 0, e->st);
         bn_fwd_tensor(e, m.bn1, m.y_d, groups, B * HWo, HWo);
         {
+            // a_d = swish(bn1(y_d)) is never written: the pooling and the gating pass form it on load
             Bn& b = e->bns[m.bn1];
-            k_bnact_apply(m.y_d, b.scale, b.shift, nullptr, nullptr, m.a_d, groups, B * HWo, HWo, b.C, 2, e->st);
+            k_se_fwd(m.y_d, b.scale, b.shift, B, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off,
+                     m.sq, m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st);
+            k_se_scale(m.y_d, b.scale, b.shift, B, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
         }
-        k_se_fwd(m.a_d, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
-                 m.ce_p, m.cs, e->st);
-        k_se_scale(m.a_d, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
         Conv& cp = e->convs[m.c_proj];
         conv_fwd(e, m.c_proj, S, m.a_s, cp.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
         bn_fwd_finalize(e, m.c_proj, groups, B);
@@ -875,11 +875,11 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
             conv_fwd(e, m.c_exp, S, cur, m.a_e, imgs, 1, sc(m.bn0), sh(m.bn0), nullptr, 2, nullptr);
             a_e = m.a_e;
         }
-        k_dw_fwd(a_e, S + m.dw_off, m.a_d, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
-                 m.pad_t, m.pad_l, 2, e->st);
-        k_se_fwd(m.a_d, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq, m.rpre, m.gate, imgs, HWo,
-                 m.ce_p, m.cs, e->st);
-        k_se_scale(m.a_d, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
+        k_dw_fwd(a_e, S + m.dw_off, m.y_d, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                 m.pad_t, m.pad_l, 2, e->st);          // eval: y_d holds swish(bn1(.)) directly
+        k_se_fwd(m.y_d, nullptr, nullptr, 1, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq,
+                 m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st);
+        k_se_scale(m.y_d, nullptr, nullptr, 1, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
         conv_fwd(e, m.c_proj, S, m.a_s, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr);
         cur = m.out;
     }
@@ -924,12 +924,13 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         conv_wgrad(e, m.c_proj, m.a_s, e->T_small, imgs);
         conv_dgrad(e, m.c_proj, S, e->T_small, e->T_mid, imgs, nullptr, false);          // d a_s
         // a_s = a_d * gate(a_d)
-        k_se_bwd(e->T_mid, m.a_d, e->se_pool, m.gate, m.rpre, S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, imgs,
-                 HWo, m.ce_p, m.cs, e->st);
+        Bn& b1 = e->bns[m.bn1];
+        k_se_bwd(e->T_mid, m.y_d, b1.scale, b1.shift, B, e->se_pool, m.gate, m.rpre, S + m.w1_off, S + m.w2_off,
+                 e->se_dgp, e->se_drp, e->se_ds, imgs, HWo, m.ce_p, m.cs, e->st);
         k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, G + m.w1_off, G + m.b1_off, G + m.w2_off, G + m.b2_off, imgs,
                    m.ce_p, m.cs, e->st);
-        k_se_bwd_apply(e->T_mid, m.gate, e->se_ds, e->T_mid, imgs, HWo, m.ce_p, e->st);  // d a_d
-        bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2);   // d y_d
+        // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward (no separate pass)
+        bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds);   // d y_d
         const float* a_e = m.c_exp >= 0 ? m.a_e : in;
         const int nb = dw_wgrad_blocks(imgs * HWo);
         k_dw_wgrad(e->T_mid, a_e, e->ws_slab, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t, m.pad_l,

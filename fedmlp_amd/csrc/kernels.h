@@ -66,10 +66,11 @@ void k_bnact_apply(const float* y, const float* scale, const float* shift, const
 // part [groups][bn_bwd_blocks(pix_per_group)][2][C]
 void k_chan_reduce(const float* a, const float* y, const float* mean, const float* istd, const float* scale,
                    const float* shift, const float* rowscale, float* part, int groups, int pix_per_group, int HW,
-                   int C, int mode, int act, hipStream_t s);
+                   int C, int mode, int act, const float* gate, const float* dsv, hipStream_t s);
 void k_bnact_bwd_apply(const float* dz, const float* y, const float* ca, const float* cb, const float* cc,
                        const float* scale, const float* shift, const float* rowscale, float* dy, int groups,
-                       int pix_per_group, int HW, int C, int act, hipStream_t s);
+                       int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s);
+// gate/dsv (optional, [imgs][C]): the incoming gradient is d(a_s); d(a_d) = d(a_s)*gate + dsv/HW is formed on load
 // depthwise KxK (K 3 or 5): x [imgs][Hi][Wi][C], w [K*K][C]; optional fused y = act(y*scale+shift)
 void k_dw_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s);
@@ -81,12 +82,16 @@ void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, 
                 int stride, int pad_t, int pad_l, hipStream_t s);
 // squeeze-excite: W1 [Cs][C], W2 [C][Cs]
 // pool_ws: [imgs][16][C] scratch for the per-image channel sums
-void k_se_fwd(const float* a, float* pool_ws, const float* W1, const float* b1, const float* W2, const float* b2,
-              float* sq, float* rpre, float* gate, int imgs, int HW, int C, int Cs, hipStream_t s);
-void k_se_scale(const float* a, const float* gate, float* out, int imgs, int HW, int C, hipStream_t s);
-void k_se_bwd(const float* dout, const float* a, float* pool_ws, const float* gate, const float* rpre,
-              const float* W1, const float* W2, float* dgp, float* drp, float* ds, int imgs, int HW, int C, int Cs,
-              hipStream_t s);
+// scale/shift (optional, [groups][C], ipg images per group): `a` is the raw depthwise output and is read
+// as swish(a*scale+shift) -- the post-BN activation is not materialised in the train path
+void k_se_fwd(const float* a, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
+              const float* b1, const float* W2, const float* b2, float* sq, float* rpre, float* gate, int imgs, int HW,
+              int C, int Cs, hipStream_t s);
+void k_se_scale(const float* a, const float* scale, const float* shift, int ipg, const float* gate, float* out, int imgs,
+                int HW, int C, hipStream_t s);
+void k_se_bwd(const float* dout, const float* a, const float* scale, const float* shift, int ipg, float* pool_ws,
+              const float* gate, const float* rpre, const float* W1, const float* W2, float* dgp, float* drp, float* ds,
+              int imgs, int HW, int C, int Cs, hipStream_t s);
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
                 float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s);
 void k_se_bwd_apply(const float* dout, const float* gate, const float* ds, float* da, int imgs, int HW, int C,
