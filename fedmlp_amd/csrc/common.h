@@ -25,6 +25,7 @@ struct IgemmParams {
     int dh[9], dw[9];     // per-tap input offsets
     int ntaps;
     int tap_minor;        // K walked chunk-major / tap-minor (L2 reuse) instead of tap-major
+    int tn_fast;          // tile order: pixel tiles fastest within an M-tile (weight slice stays in L2)
     int stem_kw, stem_pad;
     int stem_h2;          // 1: kernel width padded to 8 (two 16-k steps per kernel row), 0: padded to 4
     const float* zeros;   // >= 16 B of zeros (source of padded / out-of-range chunks)

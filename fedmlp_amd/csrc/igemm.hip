@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         w += k1 - k0;
         const int grp = tile / tiles_pg;
         const int tl = tile - grp * tiles_pg;
-        const int tm = tl % p.tilesM, tn = tl / p.tilesM;
+        // tile order inside a group: pixel tiles fastest (tn_fast) keeps ONE M-tile's weight slice hot in
+        // an XCD's L2 while its blocks walk the pixel tiles; channel tiles fastest shares the X tile instead
+        const int tm = p.tn_fast ? tl / p.tilesN : tl % p.tilesM;
+        const int tn = p.tn_fast ? tl % p.tilesN : tl / p.tilesM;
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- LDS-DMA source state: this lane stages row 16*(wave*G+q)+drow of each operand -------
@@ -345,6 +348,9 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     p.total_steps = T * p.nsteps;
     static const int tap_major = getenv("FM_TAP_MAJOR") ? 1 : 0;
     p.tap_minor = !tap_major;
+    static const int tn_fast = getenv("FM_TN_FAST") ? atoi(getenv("FM_TN_FAST")) : 0;
+    // weights of one M-tile: BM rows x K floats; beyond ~1 MB per M-tile the all-M-tiles working set no longer fits L2
+    p.tn_fast = tn_fast == 1 ? 1 : (tn_fast == 2 ? (p.tilesM > 1 && (long long)p.M * p.nsteps * 64 > (2LL << 20)) : 0);
     // persistent grid: every block slot whenever there are >= 4 K-steps for each of them, otherwise
     // one tile per block.  FM_IGEMM_BLOCKS overrides the grid (tests force odd splits so that every
     // fix-up path runs on small shapes).
