@@ -305,3 +305,20 @@ def test_prototype_pass_and_tagging_1280(eng):
     sim = eng.cos_tag(fe, torch.from_numpy(proto).cuda(), [0])
     want = R.cosine_diff(fe.cpu(), want_proto[0], want_proto[1])
     np.testing.assert_allclose(sim[0].cpu().numpy(), np.asarray(want), rtol=1e-4, atol=1e-5)
+
+
+def test_step_bce_tail_batch_of_one(eng):
+    """A tail batch of one image through the EfficientNet-B0 train step."""
+    net = _load(eng)
+    (x,), y = _data(1, 78)
+    pw = [2.0] * C_
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x)
+    loss = R.loss_train(z, y, pw, 32, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.step_bce(x.cuda(), y.cuda(), pw, 32, lo)
+    assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
+    flat, _ = eng.get_state()
+    assert np.isfinite(flat).all()

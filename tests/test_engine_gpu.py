@@ -267,3 +267,27 @@ def test_step_stage1_chestxray14_shape():
             assert err < 1e-3, (k, err)
     finally:
         e.close()
+
+
+def test_step_bce_tail_batch_of_one(eng):
+    """ChestXray14's partitions leave a tail batch of ONE image (5889 mod 32/128/256 = 1),
+    so train-mode BN sees a single image; the loss is still divided by args.batch_size."""
+    net = _load(eng)
+    (x,), y = _data(1, 77)
+    pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x)
+    loss = R.loss_train(z, y, pw, 32, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.step_bce(x.cuda(), y.cuda(), pw, 32, lo)
+    assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
+    # 4 values per channel in layer4's batch statistics: the normalised activations are O(1) functions of
+    # rounding-level differences, so only the loss and the well-conditioned tensors are compared tightly
+    gsd = _grads_sd(eng)
+    for k in ("fc.weight", "fc.bias"):
+        want = dict(net.named_parameters())[k].grad.numpy()
+        np.testing.assert_allclose(gsd[k], want, rtol=2e-3, atol=2e-3 * np.abs(want).max())
+    flat, cnt = eng.get_state()
+    assert np.isfinite(flat).all()
