@@ -24,6 +24,7 @@ struct IgemmParams {
     float* Y;             // output NHWC [imgs][Ho][Wo][Co]
     int dh[9], dw[9];     // per-tap input offsets
     int ntaps;
+    unsigned long long tapcode;   // 4 bits per tap: (dh+1) | (dw+1)<<2  (filled by launch_igemm from dh/dw)
     int tap_minor;        // K walked chunk-major / tap-minor (L2 reuse) instead of tap-major
     int tn_fast;          // tile order: pixel tiles fastest within an M-tile (weight slice stays in L2)
     int stem_kw, stem_pad;

@@ -43,14 +43,14 @@
 
 #include "common.h"
 
-template <int BM, int BN, int WN, bool STEM>
+template <int BM, int BN, int WN, bool STEM, int NS = 4>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__     // the host pass only needs the launch stub (the body uses gfx950-only builtins)
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
     static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
-    constexpr int NS = 4;                       // LDS ring: 4 stages of 16 k
+    constexpr int D = NS - 1;                   // LDS ring of NS stages of 16 k; DMA runs D steps ahead
     constexpr int STG_A = BM * 16, STG_B = BN * 16;   // floats per stage
     constexpr int GA = BM / 64, GB = BN / 64;   // 16-row groups each wave stages per step
     constexpr int PER = GA + GB;                // LDS-DMA instructions per wave per step
@@ -120,43 +120,71 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             iw0[q] = wg * p.sg;
             xb[q] = (grp * p.imgs_per_group + img) * (p.Hi * p.Wi * p.Ci);
         }
-        // Issue the LDS-DMA of K-step s into ring slot (s - k0) & 3.
+        // Non-stem convs: everything a K-step's DMA needs is prepared once per tile segment, so that the
+        // per-step issue path is a handful of scalar ops and 3 VALU ops per DMA (no division, no scalar
+        // memory load, no branch): pixoff = element offset of the lane's (pixel, chunk) at tap (0,0),
+        // vmask bit t = tap t stays inside the image for that pixel.  Tap offsets come from p.tapcode
+        // (4 bits per tap: dh+1 | (dw+1)<<2, all taps of 3x3/1x1 convs and their dgrad classes are in [-1,1]).
+        int pixoff[GB];
+        unsigned vmask[GB];
+        if constexpr (!STEM) {
+#pragma unroll
+            for (int q = 0; q < GB; ++q) {
+                pixoff[q] = xb[q] + (ih0[q] * p.Wi + iw0[q]) * p.Ci + csrc;
+                unsigned vm = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const unsigned f = (unsigned)(p.tapcode >> (4 * t)) & 15u;
+                    const int ih = ih0[q] + (int)(f & 3u) - 1, iw = iw0[q] + (int)(f >> 2) - 1;
+                    if (t < p.ntaps && rv[q] && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi) vm |= 1u << t;
+                }
+                vmask[q] = vm;
+            }
+        }
+        // issue cursor (tap, 16-channel chunk) of the next K-step to be issued: K is walked channel-chunk-
+        // major, tap-minor, so the shifted re-reads of an input pixel hit L1/L2 instead of coming back
+        // from MALL/HBM after the other channels have streamed through.  issue() is called for
+        // s = k0, k0+1, ... in order.
+        int icc = STEM ? 0 : k0 / p.ntaps;
+        int it = STEM ? 0 : k0 - icc * p.ntaps;
+        const long long zoff = reinterpret_cast<const char*>(p.zeros) - reinterpret_cast<const char*>(p.X);
         auto issue = [&](int s) {
-            const int slot = (s - k0) & (NS - 1);
+            const int slot = (s - k0) % NS;
             typedef __attribute__((address_space(3))) void lds_void;
-            // K is walked channel-chunk-major, tap-minor: the taps of one 16-channel chunk are
-            // consecutive steps, so the shifted re-reads of an input pixel hit L1/L2 instead of
-            // coming back from MALL/HBM after the other channels have streamed through.
-            int dh, dw, c0, koff;
-            bool cv = true;
             if constexpr (STEM) {
                 // stem: K = (kh, kw padded to 8 or 4, ci padded to 4); step = (half) a kernel row, chunk = kw
                 const int kw = ((s & p.stem_h2) << 2) + (csrc >> 2);
-                dh = (s >> p.stem_h2) - p.stem_pad; dw = kw - p.stem_pad; c0 = 0; cv = kw < p.stem_kw;
-                koff = s * 16;
-            } else {
-                if (p.tap_minor) {
-                    const int cc = s / p.ntaps;
-                    const int t = s - cc * p.ntaps;
-                    dh = p.dh[t]; dw = p.dw[t]; c0 = cc * 16 + csrc;
-                    koff = t * p.Ci + cc * 16;
-                } else {
-                    const int kk = s * 16;
-                    const int t = kk / p.Ci;
-                    dh = p.dh[t]; dw = p.dw[t]; c0 = kk - t * p.Ci + csrc;
-                    koff = kk;
+                const int dh = (s >> p.stem_h2) - p.stem_pad, dw = kw - p.stem_pad;
+                const bool cv = kw < p.stem_kw;
+                const int koff = s * 16;
+#pragma unroll
+                for (int q = 0; q < GA; ++q)
+                    __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
+                                                     (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const int ih = ih0[q] + dh, iw = iw0[q] + dw;
+                    const bool ok = rv[q] && cv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+                    const float* src = ok ? p.X + (size_t)(xb[q] + (ih * p.Wi + iw) * p.Ci) : p.zeros;
+                    __builtin_amdgcn_global_load_lds(src, (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
                 }
-            }
+            } else {
+                const unsigned f = (unsigned)(p.tapcode >> (4 * it)) & 15u;
+                const int dh = (int)(f & 3u) - 1, dw = (int)(f >> 2) - 1;
+                const int tapoff = (dh * p.Wi + dw) * p.Ci + icc * 16;       // scalar
+                const int koff = it * p.Ci + icc * 16;                        // scalar
 #pragma unroll
-            for (int q = 0; q < GA; ++q)
-                __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
-                                                 (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
+                for (int q = 0; q < GA; ++q)
+                    __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
+                                                     (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
 #pragma unroll
-            for (int q = 0; q < GB; ++q) {
-                const int ih = ih0[q] + dh, iw = iw0[q] + dw;
-                const bool ok = rv[q] && cv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-                const float* src = ok ? p.X + (size_t)(xb[q] + (ih * p.Wi + iw) * p.Ci + c0) : p.zeros;
-                __builtin_amdgcn_global_load_lds(src, (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
+                for (int q = 0; q < GB; ++q) {
+                    const long long xo = (long long)(pixoff[q] + tapoff) * 4;
+                    const long long o = ((vmask[q] >> it) & 1u) ? xo : zoff;
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.X) + o),
+                                                     (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
+                }
+                if (++it == p.ntaps) { it = 0; ++icc; }
             }
         };
 
@@ -167,18 +195,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         issue(k0);
-        if (k0 + 1 < k1) issue(k0 + 1);
-        if (k0 + 2 < k1) issue(k0 + 2);
+#pragma unroll
+        for (int d = 1; d < D; ++d)
+            if (k0 + d < k1) issue(k0 + d);
         for (int s = k0; s < k1; ++s) {
             // my DMA of step s has landed once at most the younger steps' instructions are outstanding
-            const int younger = min(2, k1 - 1 - s);
-            if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            const int younger = min(D - 1, k1 - 1 - s);
+            if (D >= 4 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // everyone's step-s data landed; everyone finished reading step s-1
             asm volatile("" ::: "memory");
-            if (s + 3 < k1) issue(s + 3);      // refill the slot step s-1 just vacated
-            const int slot = (s - k0) & (NS - 1);
+            if (s + D < k1) issue(s + D);      // refill the slot step s-1 just vacated
+            const int slot = (s - k0) % NS;
             const float* A = As + slot * STG_A + aoff;
             const float* B = Bs + slot * STG_B + boff;
             f32x4 a[FR], b[FC];
@@ -334,10 +364,13 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
+    constexpr int LDS_L5 = 5 * (128 + 128) * 16 * 4;    // 80 KB (5-stage ring)
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 5>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L5);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, true>),
@@ -346,9 +379,11 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     }
     const long long T = (long long)p.tilesM * p.tilesN * groups;
     p.total_steps = T * p.nsteps;
-    static const int tap_major = getenv("FM_TAP_MAJOR") ? 1 : 0;
-    p.tap_minor = !tap_major;
-    static const int tn_fast = getenv("FM_TN_FAST") ? atoi(getenv("FM_TN_FAST")) : 0;
+    p.tap_minor = 1;
+    p.tapcode = 0;
+    for (int t = 0; t < p.ntaps; ++t)      // taps of 3x3 / 1x1 convs and of their dgrad parity classes lie in [-1, 1]
+        p.tapcode |= (unsigned long long)(((p.dh[t] + 1) & 3) | (((p.dw[t] + 1) & 3) << 2)) << (4 * t);
+    static const int tn_fast = getenv("FM_TN_FAST") ? atoi(getenv("FM_TN_FAST")) : 2;
     // weights of one M-tile: BM rows x K floats; beyond ~1 MB per M-tile the all-M-tiles working set no longer fits L2
     p.tn_fast = tn_fast == 1 ? 1 : (tn_fast == 2 ? (p.tilesM > 1 && (long long)p.M * p.nsteps * 64 > (2LL << 20)) : 0);
     // persistent grid: every block slot whenever there are >= 4 K-steps for each of them, otherwise
@@ -362,8 +397,11 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     dim3 grid(nblk);
     if (p.stem_kw)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, true>), grid, dim3(256), LDS_S, s, p);
-    else if (p.M >= 128)
-        hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false>), grid, dim3(256), LDS_L, s, p);
+    else if (p.M >= 128) {
+        static const int ring5 = getenv("FM_RING5") ? atoi(getenv("FM_RING5")) : 0;
+        if (ring5) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 5>), grid, dim3(256), LDS_L5, s, p);
+        else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false>), grid, dim3(256), LDS_L, s, p);
+    }
     else
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, false>), grid, dim3(256), LDS_S, s, p);
 }
