@@ -43,32 +43,38 @@
 
 #include "common.h"
 
-template <int BM, int BN, int WN, bool STEM, int NS = 4>
+template <int BM, int BN, int WN, bool STEM, int NS = 4, int KS = 16>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__     // the host pass only needs the launch stub (the body uses gfx950-only builtins)
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
     static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
-    constexpr int D = NS - 1;                   // LDS ring of NS stages of 16 k; DMA runs D steps ahead
-    constexpr int STG_A = BM * 16, STG_B = BN * 16;   // floats per stage
-    constexpr int GA = BM / 64, GB = BN / 64;   // 16-row groups each wave stages per step
-    constexpr int PER = GA + GB;                // LDS-DMA instructions per wave per step
+    static_assert(KS == 16 || (KS == 32 && !STEM), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
+    constexpr int D = NS - 1;                   // LDS ring of NS stages of KS k; DMA runs D steps ahead
+    constexpr int STG_A = BM * KS, STG_B = BN * KS;   // floats per stage
+    constexpr int CPR = KS / 4;                 // 16-B chunks per row of a stage (4 or 8)
+    constexpr int RPI = 64 / CPR;               // rows one LDS-DMA instruction stages (16 or 8)
+    constexpr int SM = CPR - 1;                 // swizzle mask: chunk c of row r lives in slot c ^ ((r>>1)&SM)
+    constexpr int GA = BM / (4 * RPI), GB = BN / (4 * RPI);   // DMA instructions each wave issues per step
+    constexpr int PER = GA + GB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [NS][BM][16]
-    float* Bs = smem + NS * STG_A;    // [NS][BN][16]
+    float* As = smem;                 // [NS][BM][KS]
+    float* Bs = smem + NS * STG_A;    // [NS][BN][KS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
-    const int drow = lane >> 2, dpos = lane & 3;           // LDS-DMA: row inside a 16-row group, 16-B slot
-    // fragment reads: row 16r+i, k-chunk g lives in slot g ^ ((row>>1)&3)  (conflict-free ds_read_b128)
-    const int aoff = (wm * (16 * FR) + li) * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
-    const int boff = (wn * (16 * FC) + li) * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
+    const int drow = lane / CPR, dpos = lane % CPR;        // LDS-DMA: row inside an RPI-row group, 16-B slot
+    // fragment reads: row 16r+i, k-chunk g lives in slot g ^ ((row>>1)&SM)  (conflict-free ds_read_b128);
+    // (row>>1)&SM == (li>>1)&SM for every row tile because 16r/2 is a multiple of 8
+    const int aoff = (wm * (16 * FR) + li) * KS;
+    const int boff = (wn * (16 * FC) + li) * KS;
+    const int fsw = (li >> 1) & SM;
 
-    const int nsteps = p.nsteps;                // steps of 16 k
-    const int Ktot = nsteps * 16;
+    const int nsteps = p.nsteps;                // steps of KS k
+    const int Ktot = nsteps * KS;
     const int HWg = p.Hg * p.Wg;
     const int npix = p.imgs_per_group * HWg;
     const int tiles_pg = p.tilesM * p.tilesN;
@@ -96,20 +102,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- LDS-DMA source state: this lane stages row 16*(wave*G+q)+drow of each operand -------
-        const int csrc = (dpos ^ ((drow >> 1) & 3)) << 2;          // floats; same for every group (16 | group base)
+        // source-side swizzle (floats) of the chunk this lane stages, per row group
+        auto csrc_of = [&](int group) { return (dpos ^ (((RPI * group + drow) >> 1) & SM)) << 2; };
+        const int csrc = csrc_of(0);                               // KS == 16: the same for every group
         const float* asrc[GA];
         bool av[GA];                                               // rows past M (M % BM != 0) read the zero page
 #pragma unroll
         for (int q = 0; q < GA; ++q) {
-            const int m = m0 + 16 * (wave * GA + q) + drow;
+            const int m = m0 + RPI * (wave * GA + q) + drow;
             av[q] = m < p.M;
-            asrc[q] = p.W + (size_t)(av[q] ? m : 0) * Ktot + csrc;
+            asrc[q] = p.W + (size_t)(av[q] ? m : 0) * Ktot + csrc_of(wave * GA + q);
         }
         int ih0[GB], iw0[GB], xb[GB];
         bool rv[GB];
 #pragma unroll
         for (int q = 0; q < GB; ++q) {
-            const int n = n0 + 16 * (wave * GB + q) + drow;
+            const int n = n0 + RPI * (wave * GB + q) + drow;
             rv[q] = n < npix;
             const int nn = rv[q] ? n : 0;
             const int img = nn / HWg;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         if constexpr (!STEM) {
 #pragma unroll
             for (int q = 0; q < GB; ++q) {
-                pixoff[q] = xb[q] + (ih0[q] * p.Wi + iw0[q]) * p.Ci + csrc;
+                pixoff[q] = xb[q] + (ih0[q] * p.Wi + iw0[q]) * p.Ci + csrc_of(wave * GB + q);
                 unsigned vm = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             } else {
                 const unsigned f = (unsigned)(p.tapcode >> (4 * it)) & 15u;
                 const int dh = (int)(f & 3u) - 1, dw = (int)(f >> 2) - 1;
-                const int tapoff = (dh * p.Wi + dw) * p.Ci + icc * 16;       // scalar
-                const int koff = it * p.Ci + icc * 16;                        // scalar
+                const int tapoff = (dh * p.Wi + dw) * p.Ci + icc * KS;       // scalar
+                const int koff = it * p.Ci + icc * KS;                        // scalar
 #pragma unroll
                 for (int q = 0; q < GA; ++q)
                     __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
@@ -209,20 +217,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             asm volatile("" ::: "memory");
             if (s + D < k1) issue(s + D);      // refill the slot step s-1 just vacated
             const int slot = (s - k0) % NS;
-            const float* A = As + slot * STG_A + aoff;
-            const float* B = Bs + slot * STG_B + boff;
-            f32x4 a[FR], b[FC];
 #pragma unroll
-            for (int r = 0; r < FR; ++r) a[r] = *reinterpret_cast<const f32x4*>(A + r * 256);
+            for (int h = 0; h < KS / 16; ++h) {
+                const int sl = ((4 * h + lg) ^ fsw) << 2;
+                const float* A = As + slot * STG_A + aoff + sl;
+                const float* B = Bs + slot * STG_B + boff + sl;
+                f32x4 a[FR], b[FC];
 #pragma unroll
-            for (int c = 0; c < FC; ++c) b[c] = *reinterpret_cast<const f32x4*>(B + c * 256);
+                for (int r = 0; r < FR; ++r) a[r] = *reinterpret_cast<const f32x4*>(A + r * 16 * KS);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int c = 0; c < FC; ++c) b[c] = *reinterpret_cast<const f32x4*>(B + c * 16 * KS);
 #pragma unroll
-                for (int r = 0; r < FR; ++r)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int c = 0; c < FC; ++c)
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
+                    for (int r = 0; r < FR; ++r)
+#pragma unroll
+                        for (int c = 0; c < FC; ++c)
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b[c][j], acc[r][c], 0, 0, 0);
+            }
         }
         __syncthreads();       // all LDS reads done before the fix-up / epilogue reuse the LDS
 
@@ -373,10 +385,19 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L5);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 2, 32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false, 2, 32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
         attr_done = true;
     }
+    // K per LDS stage: 32 (two stages) stages a whole 128-B line per DMA row -- the L1 hands out whole
+    // lines, so the 64-B rows of the 16-k stages use half of what it moves.  Needs Ci % 32 == 0.
+    static const int ks32_mode = getenv("FM_KS32") ? atoi(getenv("FM_KS32")) : 2;
+    const bool ks32 = !p.stem_kw && p.Ci % 32 == 0 && (ks32_mode == 2 || (ks32_mode == 1 && p.M < 128));
+    if (ks32) p.nsteps /= 2;           // the caller counts 16-k steps
     const long long T = (long long)p.tilesM * p.tilesN * groups;
     p.total_steps = T * p.nsteps;
     p.tap_minor = 1;
@@ -399,9 +420,12 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, true>), grid, dim3(256), LDS_S, s, p);
     else if (p.M >= 128) {
         static const int ring5 = getenv("FM_RING5") ? atoi(getenv("FM_RING5")) : 0;
-        if (ring5) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 5>), grid, dim3(256), LDS_L5, s, p);
+        if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 2, 32>), grid, dim3(256), LDS_L, s, p);
+        else if (ring5) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 5>), grid, dim3(256), LDS_L5, s, p);
         else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false>), grid, dim3(256), LDS_L, s, p);
     }
+    else if (ks32)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, false, 2, 32>), grid, dim3(256), LDS_S, s, p);
     else
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, false>), grid, dim3(256), LDS_S, s, p);
 }

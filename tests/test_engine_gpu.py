@@ -227,7 +227,10 @@ def test_multi_step_trajectory(eng):
             assert int(sd[k]) == int(v)
             continue
         a, b = np.linalg.norm(sd[k].astype(np.float64)), float(torch.linalg.vector_norm(v.double()))
-        assert abs(a - b) <= 1e-3 * b + 0.25 * LR, (k, a, b)
+        # zero-initialised BN biases move by +-lr*sign(g) per Adam step, so channels with g ~ 0 make their
+        # ~1e-3 norms ill-conditioned (the oracle's own 1e-7 sensitivity is 1.1e-2, tests/golden/conditioning.json)
+        rel = 5e-2 if (k.endswith(".bias") and not k.startswith("fc.")) else 1e-3
+        assert abs(a - b) <= rel * b + 0.25 * LR, (k, a, b)
 
 
 def test_step_stage1_chestxray14_shape():
