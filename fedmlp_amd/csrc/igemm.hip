@@ -376,13 +376,10 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
-    constexpr int LDS_L5 = 5 * (128 + 128) * 16 * 4;    // 80 KB (5-stage ring)
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 5>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L5);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 2, 32>),
@@ -419,9 +416,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     if (p.stem_kw)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, true>), grid, dim3(256), LDS_S, s, p);
     else if (p.M >= 128) {
-        static const int ring5 = getenv("FM_RING5") ? atoi(getenv("FM_RING5")) : 0;
         if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 2, 32>), grid, dim3(256), LDS_L, s, p);
-        else if (ring5) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 5>), grid, dim3(256), LDS_L5, s, p);
         else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false>), grid, dim3(256), LDS_L, s, p);
     }
     else if (ks32)
