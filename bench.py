@@ -24,8 +24,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-KERNEL_NAMES = {0: "igemm_kernel<128,128,2,false>", 1: "igemm_kernel<64,256,4,false>",
-                2: "igemm_kernel<64,256,4,true>", 3: "wgrad_kernel<128,128,2>", 4: "wgrad_kernel<64,256,4>"}
+# kernel families of fm_profile_read (names as rocprofv3 prints them for the ResNet-18 workload, where every
+# conv has Ci % 32 == 0 and runs the 32-k-stage instantiation)
+KERNEL_NAMES = {0: "igemm_kernel<128,128,2,false,2,32>", 1: "igemm_kernel<64,256,4,false,2,32>",
+                2: "igemm_kernel<64,256,4,true,4,16>", 3: "wgrad_kernel<128,128,2>", 4: "wgrad_kernel<64,256,4>"}
 NFAM = len(KERNEL_NAMES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
