@@ -756,29 +756,6 @@ void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const flo
                        dW2, db2, imgs, C, Cs);
 }
 
-// d_a = dout*gate + ds/HW
-__global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ gate,
-                                    const float* __restrict__ ds, float* __restrict__ da, int64_t n4, int HW, int C)
-{
-    const int Q = C >> 2;
-    const float inv = 1.f / (float)HW;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int cq = (int)(i % Q);
-        const int64_t img = i / Q / HW;
-        *reinterpret_cast<f32x4*>(da + i * 4) =
-            *reinterpret_cast<const f32x4*>(dout + i * 4) * *reinterpret_cast<const f32x4*>(gate + img * C + cq * 4) +
-            *reinterpret_cast<const f32x4*>(ds + img * C + cq * 4) * inv;
-    }
-}
-void k_se_bwd_apply(const float* dout, const float* gate, const float* ds, float* da, int imgs, int HW, int C,
-                    hipStream_t s)
-{
-    const int64_t n4 = (int64_t)imgs * HW * (C / 4);
-    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(std::min(4096, cdiv(n4, 256))), dim3(256), 0, s, dout, gate, ds, da, n4,
-                       HW, C);
-}
-
 // y = a * b, y += a (elementwise helpers: dropout on the feature, residual-gradient accumulation)
 __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n)
 {

@@ -94,8 +94,6 @@ void k_se_bwd(const float* dout, const float* a, const float* scale, const float
               int imgs, int HW, int C, int Cs, hipStream_t s);
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
                 float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s);
-void k_se_bwd_apply(const float* dout, const float* gate, const float* ds, float* da, int imgs, int HW, int C,
-                    hipStream_t s);
 void k_mul(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
 void k_add_inplace(float* y, const float* a, int64_t n, hipStream_t s);
 

@@ -322,3 +322,21 @@ def test_step_bce_tail_batch_of_one(eng):
     assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
     flat, _ = eng.get_state()
     assert np.isfinite(flat).all()
+
+
+def test_step_bce_generic_depthwise_kernels(eng, monkeypatch):
+    """The register-blocked depthwise kernels cover TF-"same" padding of even inputs; any other padding
+    takes the generic per-pixel kernels.  FM_DW_GENERIC=1 forces those, and the step must still match."""
+    monkeypatch.setenv("FM_DW_GENERIC", "1")
+    net = _load(eng)
+    (x,), y = _data(5, 9)
+    pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z = net(x)
+    loss = R.loss_train(z, y, pw, 8, C_)
+    opt.zero_grad(); loss.backward(); opt.step()
+    lo = torch.zeros(1, device="cuda")
+    eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
+    assert abs(lo.item() - loss.item()) < 2e-5 * abs(loss.item()) + 1e-7
+    _cmp_grads(eng, net)
