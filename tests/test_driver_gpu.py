@@ -30,3 +30,32 @@ def test_driver_fedavg_smoke():
     log = _run(["--exp", "FedAVG", "--n_clients", "2", "--n_classes", "4", "--rounds_warmup", "2",
                 "--batch_size", "32", "--n_local", "96", "--hw", "64"])
     assert len(log) == 2 and all(np.isfinite(r["mean_loss"]) for r in log)
+
+
+def test_rccl_allreduce_accepts_engine_state_memory():
+    """bench.py --gpus N / the driver all-reduce the engine's state arena IN PLACE over RCCL.  The arena is
+    hipMalloc'ed by the C library (not by torch's allocator) and reaches torch.distributed as a
+    __cuda_array_interface__ view, so exercise that exact call with the nccl backend (one rank is all a 1-GPU
+    box allows; the N > 1 arithmetic is covered by the world_size-2 gloo test on CPU)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from fedmlp_amd import spec
+    from fedmlp_amd.engine import Engine
+    e = Engine("Resnet18", 5, 64, 64, 8)
+    flat, cnt = spec.init_state("Resnet18", 5, 3)
+    e.set_state(flat, cnt)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        e.state_scale(0.5)
+        st = e.state_tensor()
+        before = st.clone()
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        assert torch.equal(st, before)
+        got, _ = e.get_state()
+        np.testing.assert_allclose(got, flat * np.float32(0.5), rtol=0, atol=0)
+    finally:
+        dist.destroy_process_group()
+        e.close()
