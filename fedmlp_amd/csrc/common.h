@@ -64,6 +64,8 @@ struct WgradParams {
 };
 
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);
+// small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)
+bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
 int igemm_max_blocks();
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s);
 // 1x1 stride-1 convs with min(M, Nw) <= 128: returns the splits written to p.slab, 0 = not handled

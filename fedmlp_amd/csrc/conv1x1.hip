@@ -1,0 +1,198 @@
+// Streaming 1x1 stride-1 convolution on fp32 MFMA for small K (K = input channels <= 256), gfx950.
+//
+// Reference op replaced: the expand / project 1x1 convolutions of EfficientNet-B0's MBConv blocks (and
+// their data gradients, which are 1x1 convolutions with the transposed weights) inside net(images) /
+// loss.backward() (utils/local_training.py:657, 674, 937-947, 965, 1178, 1191 through
+// efficientnet_pytorch 0.7.1, model/efficientnet.py:28-33).
+//
+// Why not igemm.hip: with K = 16..240 a 128x128 tile is 1-8 K-steps long, so the tiled kernel spends its
+// time on per-tile prologues, barriers and epilogues, and these layers are HBM-bound anyway (output 3-6x
+// larger than input).  Here the whole weight slice of an M-tile ([64][K] floats, <= 64 KB) is staged ONCE per
+// block in LDS; every wave then streams its own pixels: B fragments go global -> VGPR directly (16 B per
+// lane, the same K permutation as the A fragments so one b128 feeds 4 MFMAs), 32 pixels per iteration,
+// no barrier and no LDS traffic for the pixel operand in the loop, 16-B NHWC stores straight from the
+// accumulators.  BN statistics are accumulated in registers over the wave's whole pixel range and folded
+// once per block; the partials land in the [group][tilesN][2][M] layout igemm's epilogue uses (a block that
+// covers several virtual tiles writes zeros for the others), so the BN finalize kernel is unchanged.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MT = 64;            // output channels per block
+constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
+
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p, int vt_per_block, int blocks_per_group)
+{
+    extern __shared__ __attribute__((aligned(16))) float As[];     // [K/16][MT][16], chunk c of row r in slot c ^ ((r>>1)&3)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int K = p.Ci, nkk = K >> 4;
+    const int m0 = blockIdx.x * MT;
+    const int grp = blockIdx.y / blocks_per_group, pb_idx = blockIdx.y - grp * blocks_per_group;
+    const int BNv = p.M >= 128 ? 128 : 256;                         // igemm's pixel-tile width for this M (statistics layout)
+    const int npix = p.imgs_per_group * p.Hg * p.Wg;                // pixels per group
+    const int vt0 = pb_idx * vt_per_block;
+    const int pb = vt0 * BNv, pe = min(npix, pb + vt_per_block * BNv);
+    const size_t gbase = (size_t)grp * npix;
+
+    // ---- stage the weight slice once ---------------------------------------------------------------
+    const int cpr = K >> 2;                                         // 16-B chunks per weight row
+    for (int idx = tid; idx < MT * cpr; idx += 256) {
+        const int row = idx / cpr, ch = idx - row * cpr;
+        const int kk = ch >> 2, c4 = ch & 3;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + row < p.M) v = *reinterpret_cast<const f32x4*>(p.W + (size_t)(m0 + row) * K + ch * 4);
+        *reinterpret_cast<f32x4*>(As + (kk * MT + row) * 16 + ((c4 ^ ((row >> 1) & 3)) << 2)) = v;
+    }
+    __syncthreads();
+
+    const int aoff = li * 16 + ((lg ^ ((li >> 1) & 3)) << 2);       // fragment read offset inside a 16-row tile
+    const int nrt = min(4, (p.M - m0 + 15) >> 4);                   // 16-row tiles of this M-tile that hold real rows
+    f32x4 s1[4], s2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int n_iter = (pe - pb + 31) >> 5;
+    // B fragments of KB chunks of one iteration (no explicit prefetch of the next iteration: it measured
+    // slower than the third wave per SIMD that its registers cost)
+    auto load_b = [&](int it, f32x4 (&b0)[KB], f32x4 (&b1)[KB], int kb) {
+        const int pix0 = pb + it * 32;
+        const int px0 = pix0 + li, px1 = pix0 + 16 + li;
+        const bool v0 = it < n_iter && px0 < pe, v1 = it < n_iter && px1 < pe;
+        const float* x0 = p.X + (gbase + (v0 ? px0 : pb)) * K + 4 * lg;
+        const float* x1 = p.X + (gbase + (v1 ? px1 : pb)) * K + 4 * lg;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const bool kv = kb + k < nkk;
+            b0[k] = (kv && v0) ? *reinterpret_cast<const f32x4*>(x0 + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            b1[k] = (kv && v1) ? *reinterpret_cast<const f32x4*>(x1 + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 c0[KB], c1[KB];
+    for (int it = wave; it < n_iter; it += 4) {
+        const int pix0 = pb + it * 32;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int px0 = pix0 + li, px1 = pix0 + 16 + li;
+        const bool v0 = px0 < pe, v1 = px1 < pe;
+        load_b(it, c0, c1, 0);
+        for (int kb = 0; kb < nkk; kb += KB) {
+            f32x4 b0[KB], b1[KB];
+            if (kb == 0) {
+#pragma unroll
+                for (int k = 0; k < KB; ++k) { b0[k] = c0[k]; b1[k] = c1[k]; }
+            } else {
+                load_b(it, b0, b1, kb);
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (kb + k >= nkk) break;
+                const float* A = As + (kb + k) * MT * 16 + aoff;
+                f32x4 a[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const f32x4*>(A + r * 256);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r >= nrt) break;                  // row tiles past M (M = 16, 32, 48 or a partial last M-tile)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b0[k][j], acc[r][0], 0, 0, 0);
+                        acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b1[k][j], acc[r][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- epilogue of the 32 pixels: acc[r][g][q] = D[m0 + 16r + 4lg + q][pix0 + 16g + li] ----------
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int px = g ? px1 : px0;
+            const bool pv = g ? v1 : v0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * r + 4 * lg;
+                f32x4 v = acc[r][g];
+                if (p.stats) { s1[r] += v; s2[r] += v * v; }     // rows of padded pixels are exact zeros
+                if (!pv || m >= p.M) continue;
+                const size_t o = (gbase + px) * p.Co + m;
+                if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + m) + *reinterpret_cast<const f32x4*>(p.shift + m);
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+                if (p.relu == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (p.relu == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + expf(-v[q]));
+                }
+                *reinterpret_cast<f32x4*>(p.Y + o) = v;
+            }
+        }
+    }
+
+    // ---- BN statistics: fold the 16 pixel lanes, then the 4 waves (fixed order) -----------------------
+    if (p.stats) {
+        __syncthreads();                       // every wave is done with the weight slice: reuse the LDS
+        float* red = As;                       // [4 waves][MT][2]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u = s1[r][q], v = s2[r][q];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    u += __shfl_xor(u, d);
+                    v += __shfl_xor(v, d);
+                }
+                if (li == 0) {
+                    const int ml = 16 * r + 4 * lg + q;
+                    red[(wave * MT + ml) * 2 + 0] = u;
+                    red[(wave * MT + ml) * 2 + 1] = v;
+                }
+            }
+        __syncthreads();
+        if (tid < MT && m0 + tid < p.M) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                u += red[(w * MT + tid) * 2 + 0];
+                v += red[(w * MT + tid) * 2 + 1];
+            }
+            // this block's sums go to its first virtual tile, zeros to the others it covers
+            for (int t = 0; t < vt_per_block && vt0 + t < p.tilesN; ++t) {
+                float* st = p.stats + (size_t)(grp * p.tilesN + vt0 + t) * 2 * p.M;
+                st[m0 + tid] = t == 0 ? u : 0.f;
+                st[p.M + m0 + tid] = t == 0 ? v : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Returns false when the conv is not a plain small-K 1x1 stride-1 GEMM (the caller then runs igemm).
+bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
+{
+    static const int enabled = getenv("FM_STREAM1X1") ? atoi(getenv("FM_STREAM1X1")) : 1;
+    if (!enabled || p.stem_kw || p.ntaps != 1 || p.dh[0] != 0 || p.dw[0] != 0) return false;
+    if (p.sg != 1 || p.os != 1 || p.oh0 != 0 || p.ow0 != 0) return false;
+    if (p.Hg != p.Ho || p.Wg != p.Wo || p.Hi != p.Ho || p.Wi != p.Wo) return false;
+    if (p.Ci > 256 || p.Ci % 16 != 0 || p.Co != p.M) return false;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MT * 256 * 4);
+        attr_done = true;
+    }
+    const int tilesM = (p.M + MT - 1) / MT;
+    // ~4096 blocks in flight: each covers vt virtual pixel tiles (igemm's statistics granularity)
+    int vt = std::max(1, (int)(((long long)p.tilesN * groups * tilesM + 4095) / 4096));
+    const int bpg = (p.tilesN + vt - 1) / vt;
+    const size_t lds = std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
+    hipLaunchKernelGGL(conv1x1_stream_kernel, dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+    return true;
+}

@@ -374,6 +374,7 @@ int igemm_max_blocks() { return 512; }    // 2 blocks per CU x 256 CUs (64-80 KB
 
 void launch_igemm(IgemmParams p, int groups, hipStream_t s)
 {
+    if (launch_conv1x1_stream(p, groups, s)) return;      // small-K 1x1 stride-1 convs stream through conv1x1.hip
     static bool attr_done = false;
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
