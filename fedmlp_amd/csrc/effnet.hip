@@ -58,7 +58,7 @@ void k_bnact_apply(const float* y, const float* scale, const float* shift, const
                    float* out, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s)
 {
     const int64_t n4 = (int64_t)pix_per_group * (C / 4);
-    hipLaunchKernelGGL(bnact_apply_kernel, dim3(std::min(2048, cdiv(n4, 256)), groups), dim3(256), 0, s, y, scale,
+    hipLaunchKernelGGL(bnact_apply_kernel, dim3(cdiv(n4, 256), groups), dim3(256), 0, s, y, scale,
                        shift, res, rowscale, out, pix_per_group, HW, C, act);
 }
 
@@ -179,7 +179,7 @@ void k_bnact_bwd_apply(const float* dz, const float* y, const float* ca, const f
                        int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s)
 {
     const int64_t n4 = (int64_t)pix_per_group * (C / 4);
-    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(std::min(2048, cdiv(n4, 256)), groups), dim3(256), 0, s, dz, y,
+    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(cdiv(n4, 256), groups), dim3(256), 0, s, dz, y,
                        ca, cb, cc, scale, shift, rowscale, dy, pix_per_group, HW, C, act, gate, dsv);
 }
 
@@ -667,7 +667,7 @@ void k_se_scale(const float* a, const float* scale, const float* shift, int ipg,
                 int HW, int C, hipStream_t s)
 {
     const int64_t n4 = (int64_t)imgs * HW * (C / 4);
-    hipLaunchKernelGGL(se_scale_kernel, dim3(std::min(4096, cdiv(n4, 256))), dim3(256), 0, s, a, gate, out, n4, HW, C,
+    hipLaunchKernelGGL(se_scale_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, s, a, gate, out, n4, HW, C,
                        scale, shift, ipg);
 }
 
@@ -774,5 +774,5 @@ __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restric
 }
 void k_add_inplace(float* y, const float* a, int64_t n, hipStream_t s)
 {
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(std::min(4096, cdiv(n / 4, 256))), dim3(256), 0, s, y, a, n / 4);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, y, a, n / 4);
 }
