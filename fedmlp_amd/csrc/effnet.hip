@@ -80,8 +80,7 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
     const int P = 256 / QT;                    // pixel lanes
     const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
     const bool active = pl < P;
-    const int chunk = (pix_per_group + nblk - 1) / nblk;
-    const int pb = blockIdx.x * chunk, pe = min(pix_per_group, pb + chunk);
+    const int TP = 8 * P;                     // pixel tiles dealt round-robin to the blocks (DRAM locality)
     const size_t base = (size_t)g * pix_per_group * C;
     for (int cq = cq0; cq < Q; cq += QT) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -95,7 +94,8 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
                     sh = *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
                 }
             }
-            for (int p = pb + pl; p < pe; p += P) {
+            for (int t0 = blockIdx.x * TP; t0 < pix_per_group; t0 += nblk * TP)
+            for (int p = t0 + pl; p < min(pix_per_group, t0 + TP); p += P) {
                 const size_t o = base + (size_t)p * C + cq * 4;
                 if (mode == 0) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
