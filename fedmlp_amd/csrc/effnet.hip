@@ -95,6 +95,7 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
                 }
             }
             for (int t0 = blockIdx.x * TP; t0 < pix_per_group; t0 += nblk * TP)
+#pragma unroll 4
             for (int p = t0 + pl; p < min(pix_per_group, t0 + TP); p += P) {
                 const size_t o = base + (size_t)p * C + cq * 4;
                 if (mode == 0) {
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
             sc = *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4);
             sh = *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
         }
+#pragma unroll 4
         for (int p = pb + pl; p < pe; p += P) {
             const size_t o = ((size_t)img * HW + p) * C + cq * 4;
             f32x4 v = *reinterpret_cast<const f32x4*>(a + o);

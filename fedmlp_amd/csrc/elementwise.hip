@@ -393,6 +393,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* 
     const f32x4 is = *reinterpret_cast<const f32x4*>(istd + g * C + cq * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (int t0 = blockIdx.x * TP; t0 < pix_per_group; t0 += nblk * TP)
+#pragma unroll 4
     for (int p = t0 + pl; p < min(pix_per_group, t0 + TP); p += P) {
         const size_t o = base + (size_t)p * C + cq * 4;
         f32x4 d = *reinterpret_cast<const f32x4*>(dz + o);
