@@ -190,7 +190,13 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     }
     const int tilesM = (p.M + MT - 1) / MT;
     // ~4096 blocks in flight: each covers vt virtual pixel tiles (igemm's statistics granularity)
-    int vt = std::max(1, (int)(((long long)p.tilesN * groups * tilesM + 4095) / 4096));
+    // virtual tiles per block: enough pixels that staging the weight slice (MT*K*4 B) stays ~10 % of the block's
+    // traffic, but no more -- small blocks launched in order keep the concurrently running ones on
+    // neighbouring memory (DRAM locality, tools/ew_bw.hip)
+    static const int vt_env = getenv("FM_STREAM_VT") ? atoi(getenv("FM_STREAM_VT")) : 0;
+    const int bnv = p.M >= 128 ? 128 : 256;
+    int vt = std::max(1, (int)((10LL * MT * p.Ci + (long long)bnv * (p.Ci + MT) - 1) / ((long long)bnv * (p.Ci + MT))));
+    if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;
     const size_t lds = std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
     hipLaunchKernelGGL(conv1x1_stream_kernel, dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);

@@ -176,9 +176,12 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
     const int li = lane & 15, lg = lane >> 4;
     const int l0 = blockIdx.x * 64;
     const int split = blockIdx.y;
-    const int pbeg = split * p.pix_per_split;
-    const int pend = min(p.npix, pbeg + p.pix_per_split);
-    const int nsteps = (pend - pbeg + 31) >> 5;
+    // the 32-pixel steps are dealt round-robin to the splits (step j -> split j % nsplit): the blocks running
+    // together stream neighbouring memory instead of walking nsplit far-apart ranges (DRAM locality)
+    const int nsplit = gridDim.y;
+    const int tsteps = (p.npix + 31) >> 5;
+    const int nsteps = split < tsteps ? (tsteps - split + nsplit - 1) / nsplit : 0;
+    const int pend = p.npix;
 
     // staging: A tile = 32 rows x 16 chunks (2 per thread), Small tile = 32 rows x CB chunks
     const int ca = tid & 15, ra = tid >> 4;       // rows ra, ra+16
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
     };
     const bool big_g = p.gather && p.swap, small_g = p.gather && !p.swap;
     auto gload = [&](int s) {
-        const int pb = pbeg + s * 32;
+        const int pb = (split + s * nsplit) * 32;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int pix = pb + ra + 16 * q;
