@@ -22,11 +22,14 @@
 
 namespace {
 
-constexpr int MT = 64;            // output channels per block
 constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
 
+// RT = 16-row MFMA tiles per block (MT = 16*RT output channels), P = 16-pixel groups per wave iteration:
+// the shipped instantiation is <4,2> = 64 channels x 32 pixels
+template <int RT, int P>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p, int vt_per_block, int blocks_per_group)
 {
+    constexpr int MT = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float As[];     // [K/16][MT][16], chunk c of row r in slot c ^ ((r>>1)&3)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -52,69 +55,59 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
     __syncthreads();
 
     const int aoff = li * 16 + ((lg ^ ((li >> 1) & 3)) << 2);       // fragment read offset inside a 16-row tile
-    const int nrt = min(4, (p.M - m0 + 15) >> 4);                   // 16-row tiles of this M-tile that hold real rows
-    f32x4 s1[4], s2[4];
+    const int nrt = min(RT, (p.M - m0 + 15) >> 4);                   // 16-row tiles of this M-tile that hold real rows
+    f32x4 s1[RT], s2[RT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    const int n_iter = (pe - pb + 31) >> 5;
+    constexpr int PPI = 16 * P;                                     // pixels per wave iteration
+    const int n_iter = (pe - pb + PPI - 1) / PPI;
     // B fragments of KB chunks of one iteration (no explicit prefetch of the next iteration: it measured
     // slower than the third wave per SIMD that its registers cost)
-    auto load_b = [&](int it, f32x4 (&b0)[KB], f32x4 (&b1)[KB], int kb) {
-        const int pix0 = pb + it * 32;
-        const int px0 = pix0 + li, px1 = pix0 + 16 + li;
-        const bool v0 = it < n_iter && px0 < pe, v1 = it < n_iter && px1 < pe;
-        const float* x0 = p.X + (gbase + (v0 ? px0 : pb)) * K + 4 * lg;
-        const float* x1 = p.X + (gbase + (v1 ? px1 : pb)) * K + 4 * lg;
+    auto load_b = [&](int it, f32x4 (&b)[P][KB], int kb) {
 #pragma unroll
-        for (int k = 0; k < KB; ++k) {
-            const bool kv = kb + k < nkk;
-            b0[k] = (kv && v0) ? *reinterpret_cast<const f32x4*>(x0 + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-            b1[k] = (kv && v1) ? *reinterpret_cast<const f32x4*>(x1 + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < P; ++g) {
+            const int px = pb + it * PPI + 16 * g + li;
+            const bool v = px < pe;
+            const float* xp = p.X + (gbase + (v ? px : pb)) * K + 4 * lg;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                b[g][k] = (v && kb + k < nkk) ? *reinterpret_cast<const f32x4*>(xp + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    f32x4 c0[KB], c1[KB];
     for (int it = wave; it < n_iter; it += 4) {
-        const int pix0 = pb + it * 32;
-        f32x4 acc[4][2];
+        const int pix0 = pb + it * PPI;
+        f32x4 acc[RT][P];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[r][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const int px0 = pix0 + li, px1 = pix0 + 16 + li;
-        const bool v0 = px0 < pe, v1 = px1 < pe;
-        load_b(it, c0, c1, 0);
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int g = 0; g < P; ++g) acc[r][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kb = 0; kb < nkk; kb += KB) {
-            f32x4 b0[KB], b1[KB];
-            if (kb == 0) {
-#pragma unroll
-                for (int k = 0; k < KB; ++k) { b0[k] = c0[k]; b1[k] = c1[k]; }
-            } else {
-                load_b(it, b0, b1, kb);
-            }
+            f32x4 b[P][KB];
+            load_b(it, b, kb);
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 if (kb + k >= nkk) break;
                 const float* A = As + (kb + k) * MT * 16 + aoff;
-                f32x4 a[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const f32x4*>(A + r * 256);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < RT; ++r) {
                     if (r >= nrt) break;                  // row tiles past M (M = 16, 32, 48 or a partial last M-tile)
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(A + r * 256);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b0[k][j], acc[r][0], 0, 0, 0);
-                        acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], b1[k][j], acc[r][1], 0, 0, 0);
-                    }
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int g = 0; g < P; ++g)
+                            acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[g][k][j], acc[r][g], 0, 0, 0);
                 }
             }
         }
-        // ---- epilogue of the 32 pixels: acc[r][g][q] = D[m0 + 16r + 4lg + q][pix0 + 16g + li] ----------
+        // ---- epilogue of the iteration: acc[r][g][q] = D[m0 + 16r + 4lg + q][pix0 + 16g + li] ------------
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int px = g ? px1 : px0;
-            const bool pv = g ? v1 : v0;
+        for (int g = 0; g < P; ++g) {
+            const int px = pix0 + 16 * g + li;
+            const bool pv = px < pe;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RT; ++r) {
                 const int m = m0 + 16 * r + 4 * lg;
                 f32x4 v = acc[r][g];
                 if (p.stats) { s1[r] += v; s2[r] += v * v; }     // rows of padded pixels are exact zeros
@@ -139,7 +132,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
         __syncthreads();                       // every wave is done with the weight slice: reuse the LDS
         float* red = As;                       // [4 waves][MT][2]
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float u = s1[r][q], v = s2[r][q];
@@ -184,12 +177,14 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (p.Ci > 256 || p.Ci % 16 != 0 || p.Co != p.M) return false;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, MT * 256 * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 4);
         attr_done = true;
     }
+    // (a 128-channel x 16-pixel instantiation <8,1> for wide outputs measured 2 % slower end to end: the
+    // shorter pixel iterations cost more than reading x once per 128 instead of once per 64 channels saves)
+    const int MT = 64;
     const int tilesM = (p.M + MT - 1) / MT;
-    // ~4096 blocks in flight: each covers vt virtual pixel tiles (igemm's statistics granularity)
     // virtual tiles per block: enough pixels that staging the weight slice (MT*K*4 B) stays ~10 % of the block's
     // traffic, but no more -- small blocks launched in order keep the concurrently running ones on
     // neighbouring memory (DRAM locality, tools/ew_bw.hip)
@@ -199,6 +194,6 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;
     const size_t lds = std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
-    hipLaunchKernelGGL(conv1x1_stream_kernel, dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+    hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
     return true;
 }
