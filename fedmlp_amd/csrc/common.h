@@ -60,6 +60,7 @@ struct WgradParams {
     int npix;             // imgs*Ho*Wo
     int pix_per_split;    // multiple of 32
     int tilesM, tilesN;
+    int bn;               // N-tile width the caller tiled with (wgrad_tile_n)
     int gather_k, gather_pad, gather_kw_p;   // stem form for launch_wgrad_skinny (kernel size, top/left pad, padded width)
 };
 
@@ -68,6 +69,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
 int igemm_max_blocks();
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s);
+int wgrad_tile_n(int M, int Nw);
 // 1x1 stride-1 convs with min(M, Nw) <= 128: returns the splits written to p.slab, 0 = not handled
 int launch_wgrad_skinny(const WgradParams& p, size_t slab_floats, hipStream_t s);
 int igemm_tile_n(int M);   // pixel-tile width the igemm uses for this M

@@ -604,7 +604,8 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
             return;
         }
     }
-    const int bm = c.cout_p >= 128 ? 128 : 64, bn = c.cout_p >= 128 ? 128 : 256;
+    const int bm = c.cout_p >= 128 ? 128 : 64, bn = wgrad_tile_n(c.cout_p, c.Kw);
+    p.bn = bn;
     p.tilesM = (c.cout_p + bm - 1) / bm;
     p.tilesN = (c.Kw + bn - 1) / bn;
     const int tiles = p.tilesM * p.tilesN;

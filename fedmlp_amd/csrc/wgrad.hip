@@ -15,21 +15,26 @@
 // stores of the partial slab.  The pixel axis is split over blockIdx.y; slabs
 // are summed in a fixed order by reduce_slabs (run-to-run deterministic, like
 // the reference's cudnn.deterministic=True, main.py:36-37).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
 
-template <int BM, int BN, int WN>
+// FC = 16-column MFMA tiles per wave: 4 (64x64 wave tile) or 3 (64x48: BN = 192 tiles N = 576 = 9 taps x 64
+// channels of ResNet layer 1 exactly, where 256-wide tiles waste a quarter of the MFMA work)
+template <int BM, int BN, int WN, int FC = 4>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 {
     constexpr int WM = 4 / WN;
-    static_assert(BM == WM * 64 && BN == WN * 64, "wave tile is 64x64");
+    static_assert(BM == WM * 64 && BN == WN * 16 * FC && (FC == 4 || FC == 3), "wave tile is 64 x 16*FC");
+    constexpr int BNP = FC == 4 ? BN : BN + 16;  // LDS row stride of the B tile (the pad keeps the FC = 3 reads conflict-free)
     constexpr int CA = BM / 4, CB = BN / 4;      // 16-B chunks per tile row
     constexpr int RPA = 256 / CA, NA = 32 / RPA; // rows per pass / passes
-    constexpr int RPB = 256 / CB, NB = 32 / RPB;
+    constexpr int RPB = CB > 32 ? 4 : 8, NB = 32 / RPB;   // B staging: RPB*CB threads take part (192 of 256 for CB = 48)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][32][BM]
-    float* Bs = smem + 2 * 32 * BM;   // [2][32][BN]
+    float* Bs = smem + 2 * 32 * BM;   // [2][32][BNP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -46,9 +51,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 
     const int ca = tid % CA, ra0 = tid / CA;
     const int cb = tid % CB, rb0 = tid / CB;
+    const bool bstage = rb0 < RPB;               // this thread stages B rows
     const int gc = (n0 >> 2) + cb;
     int4 e = {0, 0, 0, 0};
-    if (gc < (p.Nw >> 2)) e = p.tab[gc];
+    if (bstage && gc < (p.Nw >> 2)) e = p.tab[gc];
 
     f32x4 ra[NA], rb[NB];
     // Pixel -> (image, oh, ow) of every B row this thread stages: decoded once by division,
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
         for (int q = 0; q < NB; ++q) {
             const int pix = pb + rb0 + RPB * q;
             const int ih = r_oh[q] * p.stride + e.x, iw = r_ow[q] * p.stride + e.y;
-            const bool ok = pix < pend && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+            const bool ok = bstage && pix < pend && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
             const float* src = ok ? p.X + ((size_t)(r_img[q] * p.Hi + ih) * p.Wi + iw) * p.Ci + e.z : p.zeros;
             rb[q] = *reinterpret_cast<const f32x4*>(src);
             int ow = r_ow[q] + dr, oh = r_oh[q] + dq, im = r_img[q] + d_img;
@@ -89,18 +95,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
     };
     auto lstore = [&](int buf) {
         float* a = As + buf * 32 * BM + ra0 * BM + 4 * ca;
-        float* b = Bs + buf * 32 * BN + rb0 * BN + 4 * cb;
+        float* b = Bs + buf * 32 * BNP + rb0 * BNP + 4 * cb;
 #pragma unroll
         for (int q = 0; q < NA; ++q) *reinterpret_cast<f32x4*>(a + q * RPA * BM) = ra[q];
+        if (bstage) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) *reinterpret_cast<f32x4*>(b + q * RPB * BN) = rb[q];
+            for (int q = 0; q < NB; ++q) *reinterpret_cast<f32x4*>(b + q * RPB * BNP) = rb[q];
+        }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][FC];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nsteps > 0) {
         gload(0);
@@ -111,23 +119,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
         const int buf = s & 1;
         if (s + 1 < nsteps) gload(s + 1);
         const float* A = As + buf * 32 * BM + lg * BM + wm * 64 + 4 * li;
-        const float* B = Bs + buf * 32 * BN + lg * BN + wn * 64 + 4 * li;
+        const float* B = Bs + buf * 32 * BNP + lg * BNP + wn * (16 * FC) + FC * li;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(A + kk * 4 * BM);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(B + kk * 4 * BN);
+            float b[FC];
+            if constexpr (FC == 4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(B + kk * 4 * BNP);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[c] = bv[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < FC; ++c) b[c] = B[kk * 4 * BNP + c];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < FC; ++c)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[c], acc[r][c], 0, 0, 0);
         }
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // acc[r][c][q] = dW[m0 + wm*64 + 16*lg + 4*q + r][n0 + wn*64 + 4*li + c]
-    const int n = n0 + wn * 64 + 4 * li;
+    // acc[r][c][q] = dW[m0 + wm*64 + 16*lg + 4*q + r][n0 + wn*16FC + FC*li + c]
+    const int n = n0 + wn * (16 * FC) + FC * li;
     if (n < p.Nw) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -135,8 +151,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + wm * 64 + 16 * lg + 4 * q + r;
                 if (m >= p.M) continue;
-                const f32x4 v = {acc[r][0][q], acc[r][1][q], acc[r][2][q], acc[r][3][q]};
-                *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + m) * p.Nw + n) = v;
+                float* dst = p.slab + ((size_t)split * p.M + m) * p.Nw + n;
+                if constexpr (FC == 4) {
+                    const f32x4 v = {acc[r][0][q], acc[r][1][q], acc[r][2][q], acc[r][3][q]};
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < FC; ++c) dst[c] = acc[r][c][q];
+                }
             }
     }
 }
@@ -301,21 +323,35 @@ int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
     return splits;
 }
 
+// N-tile width for an (M, Nw) weight gradient: 128 with the 128-row tiles; 192 when it tiles Nw exactly
+// (ResNet layer 1: 576 = 3 x 192) and 256 otherwise for the 64-row tiles
+int wgrad_tile_n(int M, int Nw)
+{
+    static const int t192 = getenv("FM_WGRAD192") ? atoi(getenv("FM_WGRAD192")) : 1;
+    if (M >= 128) return 128;
+    return (t192 && Nw % 192 == 0) ? 192 : 256;
+}
+
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
 {
     static bool attr_done = false;
     constexpr int LDS_L = 2 * 32 * (128 + 128) * 4;
     constexpr int LDS_S = 2 * 32 * (64 + 256) * 4;
+    constexpr int LDS_T = 2 * 32 * (64 + 192 + 16) * 4;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T);
         attr_done = true;
     }
     dim3 grid(p.tilesM * p.tilesN, splits);
     if (p.M >= 128)
         hipLaunchKernelGGL((wgrad_kernel<128, 128, 2>), grid, dim3(256), LDS_L, s, p);
+    else if (p.bn == 192)
+        hipLaunchKernelGGL((wgrad_kernel<64, 192, 4, 3>), grid, dim3(256), LDS_T, s, p);
     else
         hipLaunchKernelGGL((wgrad_kernel<64, 256, 4>), grid, dim3(256), LDS_S, s, p);
 }
