@@ -340,3 +340,17 @@ def test_step_bce_generic_depthwise_kernels(eng, monkeypatch):
     eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
     assert abs(lo.item() - loss.item()) < 2e-5 * abs(loss.item()) + 1e-7
     _cmp_grads(eng, net)
+
+
+def test_step_is_run_to_run_deterministic(eng):
+    (x,), y = _data(6, 42)
+    outs = []
+    for _ in range(2):
+        _load(eng)
+        lo = torch.zeros(1, device="cuda")
+        for _ in range(3):
+            eng.step_bce(x.cuda(), y.cuda(), [2.0] * C_, 8, lo)
+        flat, _ = eng.get_state()
+        outs.append((flat.copy(), lo.item()))
+    assert outs[0][1] == outs[1][1]
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])

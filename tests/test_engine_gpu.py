@@ -294,3 +294,21 @@ def test_step_bce_tail_batch_of_one(eng):
         np.testing.assert_allclose(gsd[k], want, rtol=2e-3, atol=2e-3 * np.abs(want).max())
     flat, cnt = eng.get_state()
     assert np.isfinite(flat).all()
+
+
+def test_step_is_run_to_run_deterministic(eng):
+    """main.py:36-37 sets cudnn.deterministic: the same step from the same state must give the same bits
+    (stream-K fix-ups sum in segment order, split-K slabs and BN partials fold in a fixed order)."""
+    (x1, x2), y = _data(6, 41, views=2)
+    mask = [0.0, 1.0, 0.0, 0.0, 0.0]
+    outs = []
+    for _ in range(2):
+        _load(eng)
+        eng.teacher_snapshot()
+        lo = torch.zeros(1, device="cuda")
+        for _ in range(3):
+            eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+        flat, _ = eng.get_state()
+        outs.append((flat.copy(), lo.item()))
+    assert outs[0][1] == outs[1][1]
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
