@@ -724,6 +724,17 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
     k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, 512, e->C, e->st);
 }
 
+// optimizer.step(): one fused kernel over the whole trainable arena (torch Adam with coupled L2)
+void adam_step(fm_engine* e)
+{
+    e->adam_t += 1;
+    const double bc1 = 1.0 - pow((double)e->hp.beta1, (double)e->adam_t);
+    const double bc2 = 1.0 - pow((double)e->hp.beta2, (double)e->adam_t);
+    k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
+           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
+    e->ev_dirty = true;
+}
+
 // backward from e->dlogits through the graph saved by forward_train, then Adam
 void backward_and_step(fm_engine* e, int groups, int B)
 {
@@ -756,13 +767,7 @@ void backward_and_step(fm_engine* e, int groups, int B)
     k_stem_pool_bwd(ga, e->p0, e->idx0, e->dyh0, imgs, c0.hout, c0.wout, 64, e->st);
     bn_bwd(e, 0, e->dyh0, nullptr, e->dyh0, nullptr, groups, B);
     conv_wgrad(e, 0, e->x4, e->dyh0, imgs);
-    // optimizer.step()
-    e->adam_t += 1;
-    const double bc1 = 1.0 - pow((double)e->hp.beta1, (double)e->adam_t);
-    const double bc2 = 1.0 - pow((double)e->hp.beta2, (double)e->adam_t);
-    k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
-           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
-    e->ev_dirty = true;
+    adam_step(e);      // optimizer.step()
 }
 
 // =============================== EfficientNet-B0 graph =================================
@@ -890,15 +895,6 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
     k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, e->D, e->C, e->st);
 }
 
-void adam_step(fm_engine* e)
-{
-    e->adam_t += 1;
-    const double bc1 = 1.0 - pow((double)e->hp.beta1, (double)e->adam_t);
-    const double bc2 = 1.0 - pow((double)e->hp.beta2, (double)e->adam_t);
-    k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
-           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
-    e->ev_dirty = true;
-}
 
 void eff_backward_and_step(fm_engine* e, int groups, int B)
 {
