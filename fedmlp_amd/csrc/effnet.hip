@@ -277,6 +277,90 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const float* __restrict
         *reinterpret_cast<f32x4*>(y + ((size_t)(img * Ho + oh) * Wo + ow0 + j) * C + cq * 4) = v;
     }
 }
+// stride-1 forward, 2 output rows x 4 columns per thread: K+1 input rows serve both output rows (each row of
+// taps is loaded once and used with kernel row ir for the upper output row and ir-1 for the lower one), so a
+// 5x5 costs 6 loads per output instead of 10 and its weights are read once per 8 outputs -- the 5x5 layers are
+// bound by L1 bandwidth (16 float4 of L1 traffic per float4 of output in the one-row form).
+template <int K>
+__global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int imgs, int Hi, int Wi,
+                                                          int Ho, int Wo, int C, int act, int flip)
+{
+    // flip = 1 reads the kernel rotated by 180 degrees: the stride-1 data gradient is this same convolution
+    // of dy with the rotated kernel (same "same" padding), so it runs through this kernel too
+    constexpr int PT = (K - 1) / 2;
+    constexpr int NIN = 3 + K;
+    const int Q = C >> 2, WB = (Wo + 3) >> 2, HB = (Ho + 1) >> 1;
+    const int64_t n = (int64_t)imgs * HB * WB * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int ow0 = (int)(t % WB) * 4; t /= WB;
+    const int oh0 = (int)(t % HB) * 2;
+    const int img = (int)(t / HB);
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int iw0 = ow0 - PT;
+    f32x4 wprev[K];
+#pragma unroll
+    for (int ir = 0; ir <= K; ++ir) {
+        f32x4 wcur[K];
+        if (ir < K) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = flip ? K * K - 1 - (ir * K + kw) : ir * K + kw;
+                wcur[kw] = *reinterpret_cast<const f32x4*>(w + wi * C + cq * 4);
+            }
+        }
+        const int ih = oh0 + ir - PT;
+        if ((unsigned)ih < (unsigned)Hi) {
+            const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            f32x4 xin[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int iw = iw0 + j;
+                xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (ir < K) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) acc[0][j] += xin[j + kw] * wcur[kw];
+            }
+            if (ir >= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) acc[1][j] += xin[j + kw] * wprev[kw];
+            }
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) {
+        sc = *reinterpret_cast<const f32x4*>(scale + cq * 4);
+        sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (oh0 + r >= Ho) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ow0 + j >= Wo) continue;
+            f32x4 v = acc[r][j];
+            if (scale) v = act_fwd(v * sc + sh, act);
+            *reinterpret_cast<f32x4*>(y + ((size_t)(img * Ho + oh0 + r) * Wo + ow0 + j) * C + cq * 4) = v;
+        }
+    }
+}
+
 static inline bool dw_blk_ok(int K, int S, int Hi, int Wi, int pad_t, int pad_l)
 {
     const int pt = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
@@ -293,6 +377,17 @@ static inline bool dw_blk_ok(int K, int S, int Hi, int Wi, int pad_t, int pad_l)
 void k_dw_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
 {
+    static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        const int64_t nb = (int64_t)imgs * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 4);
+        if (K == 3)
+            hipLaunchKernelGGL(dw_fwd_blk2_kernel<3>, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi,
+                               Wi, Ho, Wo, C, act, 0);
+        else
+            hipLaunchKernelGGL(dw_fwd_blk2_kernel<5>, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi,
+                               Wi, Ho, Wo, C, act, 0);
+        return;
+    }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const int64_t nb = (int64_t)imgs * Ho * ((Wo + 3) / 4) * (C / 4);
         DW_DISPATCH(dw_fwd_blk_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo,
@@ -399,6 +494,18 @@ __global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const float* __restri
 void k_dw_dgrad(const float* dy, const float* w, float* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s)
 {
+    static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        // stride 1: dx = dy (*) rot180(w), the forward kernel with the rotated kernel (Hi == Ho, Wi == Wo)
+        const int64_t nb = (int64_t)imgs * ((Hi + 1) / 2) * ((Wi + 3) / 4) * (C / 4);
+        if (K == 3)
+            hipLaunchKernelGGL(dw_fwd_blk2_kernel<3>, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, nullptr, nullptr, imgs,
+                               Ho, Wo, Hi, Wi, C, 0, 1);
+        else
+            hipLaunchKernelGGL(dw_fwd_blk2_kernel<5>, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, nullptr, nullptr, imgs,
+                               Ho, Wo, Hi, Wi, C, 0, 1);
+        return;
+    }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const int64_t nb = (int64_t)imgs * Hi * ((Wi + 3) / 4) * (C / 4);
         DW_DISPATCH(dw_dgrad_blk_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
@@ -517,6 +624,75 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const float* __restri
         }
     }
 }
+// stride-1 wgrad, pixel blocks of 2 output rows x 4 columns: K+1 input rows serve both rows of dy
+template <int K>
+__global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ part, int imgs, int Hi, int Wi,
+                                                            int Ho, int Wo, int C, int QT, int P)
+{
+    constexpr int PT = (K - 1) / 2;
+    constexpr int NIN = 3 + K;
+    __shared__ f32x4 red[256];
+    const int cq = blockIdx.y * QT + threadIdx.x % QT, pl = threadIdx.x / QT;
+    const int WB = (Wo + 3) >> 2, HB = (Ho + 1) >> 1;
+    const int npb = imgs * HB * WB, nblk = gridDim.x;
+    const int chunk = (npb + nblk - 1) / nblk;
+    const int pb = blockIdx.x * chunk, pe = min(npb, pb + chunk);
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = pb + pl; p < pe; p += P) {
+        const int img = p / (HB * WB);
+        const int rem = p - img * HB * WB;
+        const int oh0 = (rem / WB) * 2, ow0 = (rem % WB) * 4;
+        f32x4 d[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float* dr = dy + ((size_t)(img * Ho + min(oh0 + r, Ho - 1)) * Wo) * C + cq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[r][j] = (oh0 + r < Ho && ow0 + j < Wo) ? *reinterpret_cast<const f32x4*>(dr + (size_t)(ow0 + j) * C)
+                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int iw0 = ow0 - PT;
+#pragma unroll
+        for (int ir = 0; ir <= K; ++ir) {
+            const int ih = oh0 + ir - PT;
+            if ((unsigned)ih >= (unsigned)Hi) continue;
+            const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            f32x4 xin[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int iw = iw0 + j;
+                xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (ir < K) {                     // kernel row ir against the upper dy row
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ir * K + kw] += d[0][j] * xin[j + kw];
+            }
+            if (ir >= 1) {                    // kernel row ir-1 against the lower dy row
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[(ir - 1) * K + kw] += d[1][j] * xin[j + kw];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        __syncthreads();
+        red[threadIdx.x] = acc[t];
+        __syncthreads();
+        if (pl == 0) {
+            f32x4 v = red[threadIdx.x];
+            for (int k = 1; k < P; ++k) v += red[k * QT + threadIdx.x];
+            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
+        }
+    }
+}
 // QT = channel quads per block (a divisor of Q, <= 256), P = pixel lanes
 static inline void dw_map(int C, int& QT, int& P, int& ytiles)
 {
@@ -533,6 +709,14 @@ void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, 
     int QT, P, yt;
     dw_map(C, QT, P, yt);
     dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt);
+    static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        if (K == 3)
+            hipLaunchKernelGGL(dw_wgrad_blk2_kernel<3>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        else
+            hipLaunchKernelGGL(dw_wgrad_blk2_kernel<5>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        return;
+    }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         DW_DISPATCH(dw_wgrad_blk_kernel, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
         return;
