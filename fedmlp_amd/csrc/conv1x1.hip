@@ -181,8 +181,9 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 4);
         attr_done = true;
     }
-    // (a 128-channel x 16-pixel instantiation <8,1> for wide outputs measured 2 % slower end to end: the
-    // shorter pixel iterations cost more than reading x once per 128 instead of once per 64 channels saves)
+    // (128-channel instantiations for wide outputs measured 2 % slower end to end, both <8,1> -- shorter pixel
+    // iterations -- and <8,2> -- 252 VGPRs, two waves per SIMD: reading x once per 128 instead of once per 64
+    // channels does not pay for either)
     const int MT = 64;
     const int tilesM = (p.M + MT - 1) / MT;
     // virtual tiles per block: enough pixels that staging the weight slice (MT*K*4 B) stays ~10 % of the block's
