@@ -354,3 +354,22 @@ def test_step_is_run_to_run_deterministic(eng):
         outs.append((flat.copy(), lo.item()))
     assert outs[0][1] == outs[1][1]
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
+
+
+def test_build_model_call_surface():
+    """net = build_model(args); net.eval(); feature, logits = net(x) -- the eval-mode call of
+    utils/evaluations.py:25 -- for --model Efficient_b0 (feature width 1280)."""
+    from fedmlp_amd.model import build_model
+    from tests.helpers import make_args
+    args = make_args(n_classes=C_, model=M, seed=4, feature_dim=1280)
+    net = build_model(args)
+    ref = EfficientNetB0Ref(C_)
+    ref.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in net.state_dict().items()})
+    ref.eval(); net.eval()
+    x = torch.randn((3, 3, HW, HW), generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        f, z = ref(x)
+    fe, ze = net(x.cuda())
+    assert fe.shape == (3, 1280) and ze.shape == (3, C_)
+    np.testing.assert_allclose(fe.cpu().numpy(), f.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ze.cpu().numpy(), z.numpy(), rtol=2e-4, atol=2e-5)

@@ -181,3 +181,22 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     net2.load_state_dict(torch.load(path))
     np.testing.assert_array_equal(net2.flat, flat)
     np.testing.assert_array_equal(net2.counters, cnt)
+
+
+def test_checkpoint_roundtrip_efficient_b0(tmp_path):
+    """The same torch.save(state_dict()) file format for --model Efficient_b0: efficientnet-pytorch key names
+    (_conv_stem.weight ... _fc.bias), accepted strictly by the oracle module and read back bit-exactly."""
+    from fedmlp_amd.model import HipNet
+    from oracle.efficientnet_ref import EfficientNetB0Ref
+    flat, cnt = spec.init_state("Efficient_b0", 5, 11)
+    cnt[:] = 3
+    net = HipNet("Efficient_b0", 5, flat, cnt)
+    path = tmp_path / "model_eff.pth"
+    torch.save(net.state_dict(), path)
+    ref = EfficientNetB0Ref(5)
+    ref.load_state_dict(torch.load(path))
+    assert ref._bn0.num_batches_tracked.item() == 3
+    net2 = HipNet("Efficient_b0", 5, np.zeros_like(flat), np.zeros_like(cnt))
+    net2.load_state_dict(torch.load(path))
+    np.testing.assert_array_equal(net2.flat, flat)
+    np.testing.assert_array_equal(net2.counters, cnt)
