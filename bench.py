@@ -6,11 +6,20 @@ Workload (BASELINE.json configs[1]): ICH-shaped synthetic batches, fp32
 train-mode forwards + 2 frozen-teacher forwards + backward through both views +
 Adam (utils/local_training.py:920-967; 28.55 GFLOP/sample).  One client per GPU;
 FedAvg (utils/FedAvg.py:7-14) is an RCCL all-reduce of the device-resident state
-once per `--round-steps` steps and once at the end of the timed region.
-"image" = one dataset sample consumed by the step (it carries two views).
+once per `--round-steps` steps and once at the end of the timed region
+(`fm_fedavg_allreduce` of the C ABI).  "image" = one dataset sample consumed by
+the step (it carries two views).
 
-usage: python bench.py --gpus N --steps K --warmup W   (N>1: launched by torchrun)
-Prints ONE JSON line on rank 0.
+usage: python bench.py --gpus N --steps K --warmup W
+  N > 1 without a torchrun environment: this process starts the N ranks itself
+  (python -m torch.distributed.run ... bench.py, one rank per GPU) before touching
+  the GPU and exits with their code.  Rank 0 prints ONE JSON line.
+
+Other legs (same JSON contract, named in config.workload):
+  --workload conv_fwd --batch 256     eval-mode forward only: the north-star "conv forward at
+                                       bs=256" MFMA-roofline number (928.5 GFLOP per pass)
+  --model Efficient_b0 --batch 256    BASELINE configs[3] (fp32, HBM-bound)
+  --model Efficient_b0 --precision bf16 --batch 512   configs[4]
 """
 import argparse
 import json
@@ -30,32 +39,52 @@ KERNEL_NAMES = {0: "igemm_kernel<128,128,2,false,2,32>", 1: "igemm_kernel<64,256
                 2: "igemm_kernel<64,256,4,true,4,16>", 3: "wgrad_kernel<128,128,2>", 4: "wgrad_kernel<64,256,4>"}
 NFAM = len(KERNEL_NAMES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+# minimum activation bytes per image of one EfficientNet-B0 forward
+EFFNET_FWD_BYTES = {"fp32": 73.8e6, "bf16": 36.9e6}
+RESNET_FWD_FLOP = 3.627e9             # 2 x 1 813 561 344 conv MACs per 224x224 image
+PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps (default ~5 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--classes", type=int, default=5)
     ap.add_argument("--hw", type=int, default=224)
-    ap.add_argument("--workload", default="stage1", choices=["stage1", "train", "stage2"])
+    ap.add_argument("--workload", default="stage1", choices=["stage1", "train", "stage2", "conv_fwd"])
     ap.add_argument("--model", default="Resnet18", choices=["Resnet18", "Efficient_b0"],
                     help="Efficient_b0 = BASELINE configs[3] (use --batch 256)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="activation storage of the Efficient_b0 path (configs[4]: bf16, --batch 512)")
     ap.add_argument("--round-steps", type=int, default=40, help="steps per FL round (5000/128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
 
 
 def cpu_baseline(args):
-    """The oracle (torch CPU fp32 restatement) timed on this host: a bounded sample
-    of the same step (small batch at the full 224x224 size), ~10-30 s of CPU work."""
+    """The oracle (torch CPU fp32 restatement of the same step arithmetic) timed on this host: a
+    bounded sample, ~10-30 s of CPU work.  The micro-batch is the reference's own CPU-runnable
+    batch (configs[0]: bs 32) unless --batch is smaller; the rate is per image, so it compares
+    directly with `value`."""
     from oracle import steps_ref as R
     from tests.helpers import oracle_net
     import copy
-    B = 8
+    B = min(32, args.batch)
     if args.model == "Efficient_b0":
         from oracle.efficientnet_ref import EfficientNetB0Ref
         net = EfficientNetB0Ref(args.classes)
@@ -71,6 +100,10 @@ def cpu_baseline(args):
     act, neg = [0], list(range(1, args.classes))
 
     def step():
+        if args.workload == "conv_fwd":
+            with torch.no_grad():
+                glob(x1)
+            return
         if args.workload == "stage1":
             _, z1 = net(x1); _, z2 = net(x2)
             with torch.no_grad():
@@ -88,18 +121,47 @@ def cpu_baseline(args):
         dt = time.perf_counter() - t0
         if dt > 12.0 or n >= 20:
             break
-    return {"value": round(n * B / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{n} oracle {args.workload} steps, batch {B} at 3x{args.hw}x{args.hw} "
-                      f"(torch CPU fp32, same step arithmetic, no DataLoader)"}
+    return {"value": round(n * B / dt, 3), "unit": "images/sec", "cores": physical_cores(),
+            "threads": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} oracle {args.workload} steps at micro-batch {B} (config batch {args.batch}; the loss "
+                      f"normaliser is the config batch), 3x{args.hw}x{args.hw}, torch CPU fp32, same step "
+                      f"arithmetic, no DataLoader; {dt:.1f} s"}
+
+
+def measured_traffic(kernel_name, args):
+    """HBM-side bytes per launch of the dominant kernel.  NOT measured in this run: read from the
+    committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate passes over this
+    same command, FETCH_SIZE doubled per MI355X_MICROARCH.md); null when the workload differs from
+    the profiled one."""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            doc = json.load(f)
+        if doc.get("workload") != workload_key(args):
+            return None
+        key = kernel_name.replace(" ", "")
+        for k, v in doc["kernels"].items():
+            if key in k.replace(" ", ""):
+                return v["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return None
+
+
+def workload_key(args):
+    return f"{args.model}/{args.precision}/{args.workload}/bs{args.batch}/hw{args.hw}/C{args.classes}"
 
 
 def main():
     args = parse()
+    from fedmlp_amd.launch import launched_by_torchrun, spawn_ranks
+    if args.gpus > 1 and not launched_by_torchrun():
+        # the parent never touches the GPU: its children are the ranks
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -109,22 +171,24 @@ def main():
 
     from fedmlp_amd.engine import Engine
     from fedmlp_amd import spec
-    from fedmlp_amd.fedavg import fedavg_allreduce
+    from fedmlp_amd.fedavg import fedavg_allreduce, comm_init
 
     B, C = args.batch, args.classes
     views = 2 if args.workload == "stage1" else 1
-    eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev))
+    eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev), precision=args.precision)
     flat, cnt = spec.init_state(args.model, C, 1037)
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
     eng.adam_reset(3e-5)
+    rccl_ranks = comm_init(eng) if world > 1 else 1      # RCCL communicator inside the C-ABI library
     # Efficient_b0: the engine draws drop-connect / dropout multipliers before every train step
 
     # synthetic client data resident in HBM (seed = reference default, utils/options.py:10)
     g = torch.Generator(device=dev).manual_seed(1037 + rank)
     npool = 4
     x1 = [torch.randn((B, 3, args.hw, args.hw), device=dev, generator=g) for _ in range(npool)]
-    x2 = [torch.randn((B, 3, args.hw, args.hw), device=dev, generator=g) for _ in range(npool)]
+    x2 = [torch.randn((B, 3, args.hw, args.hw), device=dev, generator=g) for _ in range(npool)] \
+        if views == 2 else x1
     active = rank % C                       # 8 clients on 5 classes: class = i mod C
     mask = [1.0 if c == active else 0.0 for c in range(C)]
     ys = []
@@ -132,9 +196,11 @@ def main():
         y = (torch.rand((B, C), device=dev, generator=g) < 0.15).float()
         y = y * torch.tensor(mask, device=dev)
         ys.append(y.contiguous())
-    dist_mask = [(torch.rand((B, C), device=dev, generator=g) < 0.5).float() * (1 - torch.tensor(mask, device=dev))
-                 for _ in range(npool)]
+    dist_mask = [((torch.rand((B, C), device=dev, generator=g) < 0.5).float()
+                  * (1 - torch.tensor(mask, device=dev))).contiguous() for _ in range(npool)]
     losses = torch.zeros(args.steps + args.warmup, device=dev)
+    feat_out = torch.empty((B, eng.feature_dim), device=dev)
+    logit_out = torch.empty((B, C), device=dev)
 
     def step(i, k):
         lo = losses[k:k + 1]
@@ -143,11 +209,13 @@ def main():
             eng.step_stage1(x1[j], x2[j], ys[j], mask, 1, B, lo)
         elif args.workload == "train":
             eng.step_bce(x1[j], ys[j], [1.0] * C, B, lo)
+        elif args.workload == "stage2":
+            eng.step_stage2(x1[j], ys[j], dist_mask[j], lo)
         else:
-            eng.step_stage2(x1[j], ys[j], dist_mask[j].contiguous(), lo)
+            eng.forward_eval_into(x1[j], feat_out, logit_out)
 
     def fedavg():
-        if world > 1:
+        if world > 1 and args.workload != "conv_fwd":
             fedavg_allreduce(eng, 1.0 / world)
 
     for i in range(args.warmup):
@@ -176,52 +244,62 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    def measured_traffic(kernel_name):
-        """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC
-        passes (profiles/r01/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
-        passes over this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md); null when the
-        workload differs from the profiled one."""
-        try:
-            if args.workload != "stage1" or args.batch != 128 or args.hw != 224 or args.model != "Resnet18":
-                return None
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-                ks = json.load(f)["kernels"]
-            key = "void " + kernel_name.replace(",", ", ") + "(IgemmParams)"
-            for k, v in ks.items():
-                if k.replace(" ", "") == key.replace(" ", ""):
-                    return v["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            pass
-        return None
-
     roof = None
     if not args.no_profile:
         fams = [eng.profile_read(f) for f in range(NFAM)]
         eng.profile_enable(False)
-        dom = max(range(NFAM), key=lambda f: fams[f][1])
-        n, ms, fl = fams[dom]
-        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(KERNEL_NAMES[dom]),
-                "kernel": KERNEL_NAMES[dom], "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
-                "all_kernels": {KERNEL_NAMES[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
-                                                  "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
-                                for f in range(NFAM)}}
+        allk = {KERNEL_NAMES[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
+                                  "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
+                for f in range(NFAM)}
+        if args.model == "Efficient_b0":
+            # HBM-bound model: whole-step algorithmic activation bytes over the step time
+            n_fwd = {"stage1": 4 * B, "train": B, "stage2": B, "conv_fwd": B}[args.workload]
+            n_bwd = {"stage1": 2 * B, "train": B, "stage2": B, "conv_fwd": 0}[args.workload]
+            alg = (n_fwd + 2 * n_bwd) * EFFNET_FWD_BYTES[args.precision]
+            gbs = alg / (dt / args.steps) / 1e9
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("whole_step", args),
+                    "traffic_source": PMC_FILE + " (separate rocprofv3 --pmc passes, not this run)",
+                    "kernel": "whole step (all kernels of one step; no single kernel dominates)",
+                    "algorithmic_bytes_per_step": alg, "mfma_kernels": allk}
+        else:
+            if args.workload == "conv_fwd":
+                use = [0, 1, 2]
+                n = sum(fams[f][0] for f in use); ms = sum(fams[f][1] for f in use)
+                fl = sum(fams[f][2] for f in use)
+                name = "igemm_kernel<*> (all 20 conv forwards of the eval pass)"
+            else:
+                dom = max(range(NFAM), key=lambda f: fams[f][1])
+                n, ms, fl = fams[dom]
+                name = KERNEL_NAMES[dom]
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(name, args),
+                    "traffic_source": PMC_FILE + " (separate rocprofv3 --pmc passes, not this run)",
+                    "kernel": name, "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
+                    "all_kernels": allk}
+            if args.workload == "conv_fwd":
+                roof["algorithmic_flop_per_pass"] = RESNET_FWD_FLOP * B
+                roof["whole_pass_tflops"] = round(RESNET_FWD_FLOP * B / (dt / args.steps) / 1e12, 3)
     lv = losses.cpu().numpy()
     assert np.isfinite(lv).all(), "non-finite loss in the benchmark"
 
     if rank == 0:
         total = world * B * args.steps
+        desc = {"stage1": "FedMLP stage1 step", "train": "LocalUpdate.train step", "stage2": "FedMLP stage2 step",
+                "conv_fwd": "eval-mode forward pass (conv forward)"}[args.workload]
         out = {"metric": "images/sec/client (ICH 224x224 bs=128) at 1/2/4/8 GPUs; mAP vs ref",
                "value": round(total / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if (args.model == "Efficient_b0" and args.precision == "bf16") else "f32",
                "data": "synthetic",
-               "config": {"workload": f"FedMLP {args.workload} step, {args.model}, ICH-shaped synthetic "
+               "config": {"workload": f"{desc}, {args.model}, ICH-shaped synthetic "
                                       f"3x{args.hw}x{args.hw}, C={C}, bs={B}, one client per GPU, "
                                       f"FedAvg all-reduce every {args.round_steps} steps + once at end",
                           "images_per_sec_per_client": round(B * args.steps / dt, 3),
-                          "views_per_sec": round(views * total / dt, 3), "parallelism": f"clients{world}"},
+                          "views_per_sec": round(views * total / dt, 3), "parallelism": f"clients{world}",
+                          "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3)},
                "roofline": roof,
                "last_loss": float(lv[-1])}
         if not args.no_cpu_baseline and world == 1:

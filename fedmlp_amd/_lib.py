@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEDMLP_HIP_LIB") or os.path.join(_HERE, "libfedmlp_hip.so")
 
 FM_MAX_CLASSES = 32
+FM_COMM_ID_BYTES = 128
 
 
 class FmConfig(C.Structure):
@@ -65,6 +66,13 @@ SYMBOLS = {
     "fm_profile_enable": (C.c_int, [_P, _I32]),
     "fm_profile_read": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),
+    "fm_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "fm_comm_init": (C.c_int, [_P, C.POINTER(C.c_uint8), _I32, _I32]),
+    "fm_comm_destroy": (C.c_int, [_P]),
+    "fm_comm_size": (C.c_int, [_P]),
+    "fm_fedavg_allreduce": (C.c_int, [_P, C.c_float]),
+    "fm_fedavg_tao": (C.c_int, [_P, C.POINTER(C.c_double), C.c_double, _F, C.POINTER(C.c_double)]),
+    "fm_fedavg_proto": (C.c_int, [_P, _P, C.c_double, _F, _P]),
     "fm_debug_num_convs": (C.c_int, [_P]),
     "fm_debug_conv_info": (C.c_int, [_P, _I32, C.POINTER(_I32)]),
     "fm_debug_conv": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I32, _I32, _P]),

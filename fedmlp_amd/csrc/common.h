@@ -74,3 +74,12 @@ int wgrad_tile_n(int M, int Nw);
 int launch_wgrad_skinny(const WgradParams& p, size_t slab_floats, hipStream_t s);
 int igemm_tile_n(int M);   // pixel-tile width the igemm uses for this M
 int igemm_tile_m(int M);
+
+// hipFuncSetAttribute with the failure reported (a kernel whose dynamic-LDS limit was not raised fails at its
+// first launch; fm_step_* then return FM_ERR_HIP through hipGetLastError)
+#include <stdio.h>
+inline void set_max_dyn_lds(const void* fn, int bytes, const char* what)
+{
+    const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc != hipSuccess) fprintf(stderr, "fedmlp_hip: hipFuncSetAttribute(%s, %d B) failed: %s\n", what, bytes, hipGetErrorString(rc));
+}

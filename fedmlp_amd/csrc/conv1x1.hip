@@ -177,8 +177,7 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (p.Ci > 256 || p.Ci % 16 != 0 || p.Co != p.M) return false;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 256 * 4);
+        set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2>), 64 * 256 * 4, "conv1x1_stream_kernel<4, 2>");
         attr_done = true;
     }
     // (128-channel instantiations for wide outputs measured 2 % slower end to end, both <8,1> -- shorter pixel

@@ -75,6 +75,26 @@ void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList tap
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w, out, Co, T, Ci, taps);
 }
 
+// every (conv, parity class) pack of the step in ONE launch; a block finds its job from the jobs' first-block table
+__global__ void pack_dgrad_all_kernel(const float* __restrict__ state, const PackJob* __restrict__ jobs, int njobs)
+{
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+    const PackJob jb = jobs[j];
+    const int64_t n = (int64_t)jb.Ci * jb.ntaps * jb.Co;
+    const int64_t i = (int64_t)((int)blockIdx.x - jb.blk0) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % jb.Co);
+    const int64_t t = i / jb.Co;
+    const int tj = (int)(t % jb.ntaps);
+    const int ci = (int)(t / jb.ntaps);
+    jb.out[i] = state[jb.w_off + ((int64_t)co * jb.T + jb.taps[tj]) * jb.Ci + ci];
+}
+void k_pack_dgrad_all(const float* state, const PackJob* jobs, int njobs, int nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_dgrad_all_kernel, dim3(nblocks), dim3(256), 0, s, state, jobs, njobs);
+}
+
 __global__ void scale_kernel(float* __restrict__ x, float w, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

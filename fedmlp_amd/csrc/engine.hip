@@ -20,12 +20,13 @@
 #include <vector>
 
 #include "../../include/fedmlp_hip.h"
+#include "comm.h"
 #include "common.h"
 #include "kernels.h"
 
 static thread_local std::string g_err;
 const char* fm_last_error(void) { return g_err.c_str(); }
-const char* fm_version(void) { return "fedmlp_hip 0.1 (gfx950)"; }
+const char* fm_version(void) { return "fedmlp_hip 0.2 (gfx950)"; }
 
 #define HIPCHK(x)                                                                              \
     do {                                                                                       \
@@ -152,12 +153,23 @@ struct fm_engine {
     int *sel_counts = nullptr, *sel_top = nullptr, *sel_bot = nullptr, *cls_dev = nullptr;
     int sel_cap = 0;
     // profiling
-    bool prof = false;
+    bool prof = false, prof_fail = false;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ev_free;
     double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
     int64_t prof_n[5] = {0, 0, 0, 0, 0};
     std::vector<void*> allocs;
+    // dgrad weight packs: rebuilt by ONE launch after every optimizer step (and lazily after any
+    // external change of the state), not per convolution call
+    PackJob* pack_jobs = nullptr;
+    int n_pack_jobs = 0, n_pack_blocks = 0;
+    bool wpack_dirty = true;
+    // RCCL (comm.hip)
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    double* comm_buf = nullptr;       // device scratch of the small all-reduces
+    size_t comm_buf_n = 0;
+    int precision = 0;                // 0 fp32 activations, 1 bf16 activations (EfficientNet-B0 only)
 };
 
 namespace {
@@ -248,6 +260,25 @@ int build_tables(fm_engine* e)
                 c.cls[c.ncls++] = d;
             }
     }
+    // one job per (conv, parity class) for the batched pack kernel
+    std::vector<PackJob> jobs;
+    int blk = 0;
+    for (auto& c : e->convs)
+        for (int k = 0; k < c.ncls; ++k) {
+            const DgradClass& d = c.cls[k];
+            PackJob j{};
+            j.w_off = (long long)c.w_off; j.out = d.wpack; j.Co = c.cout_p; j.T = c.k * c.k; j.Ci = c.cin_p;
+            j.ntaps = d.taps.n;
+            for (int t = 0; t < d.taps.n; ++t) j.taps[t] = d.taps.t[t];
+            j.blk0 = blk;
+            blk += (int)(((size_t)c.cin_p * d.taps.n * c.cout_p + 255) / 256);
+            jobs.push_back(j);
+        }
+    e->n_pack_jobs = (int)jobs.size();
+    e->n_pack_blocks = blk;
+    DALLOC(e->pack_jobs, jobs.size());
+    if (!jobs.empty())
+        HIPCHK(hipMemcpy(e->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
     return FM_OK;
 }
 
@@ -504,17 +535,26 @@ int alloc_workspaces(fm_engine* e)
 hipEvent_t get_ev(fm_engine* e)
 {
     if (!e->ev_free.empty()) { hipEvent_t v = e->ev_free.back(); e->ev_free.pop_back(); return v; }
-    hipEvent_t v; (void)hipEventCreate(&v); return v;
+    hipEvent_t v = nullptr;
+    if (hipEventCreate(&v) != hipSuccess) { e->prof_fail = true; return nullptr; }
+    return v;
 }
 struct ProfScope {
     fm_engine* e; hipEvent_t a{}, b{}; int fam; double fl; bool on;
     ProfScope(fm_engine* e_, int family, double flops) : e(e_), fam(family), fl(flops), on(e_->prof)
     {
-        if (on) { a = get_ev(e); b = get_ev(e); (void)hipEventRecord(a, e->st); }
+        if (on) {
+            a = get_ev(e); b = get_ev(e);
+            on = a && b;
+            if (on && hipEventRecord(a, e->st) != hipSuccess) { e->prof_fail = true; on = false; }
+        }
     }
     ~ProfScope()
     {
-        if (on) { (void)hipEventRecord(b, e->st); e->evs.push_back({a, b, fam, fl}); }
+        if (on) {
+            if (hipEventRecord(b, e->st) != hipSuccess) e->prof_fail = true;
+            e->evs.push_back({a, b, fam, fl});
+        }
     }
 };
 
@@ -561,7 +601,6 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
     Conv& c = e->convs[ci];
     for (int k = 0; k < c.ncls; ++k) {
         DgradClass& d = c.cls[k];
-        k_pack_dgrad(S + c.w_off, d.wpack, c.cout_p, c.k * c.k, c.cin_p, d.taps, e->st);
         IgemmParams p{};
         p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
         p.ntaps = d.taps.n;
@@ -724,6 +763,14 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
     k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, 512, e->C, e->st);
 }
 
+// transposed weight packs of every data-gradient GEMM, all in ONE launch
+void ensure_packed(fm_engine* e)
+{
+    if (!e->wpack_dirty) return;
+    if (e->n_pack_jobs) k_pack_dgrad_all(e->state, e->pack_jobs, e->n_pack_jobs, e->n_pack_blocks, e->st);
+    e->wpack_dirty = false;
+}
+
 // optimizer.step(): one fused kernel over the whole trainable arena (torch Adam with coupled L2)
 void adam_step(fm_engine* e)
 {
@@ -733,6 +780,8 @@ void adam_step(fm_engine* e)
     k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
            e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
     e->ev_dirty = true;
+    e->wpack_dirty = true;
+    ensure_packed(e);        // the next step's data gradients read the packed (transposed) weights
 }
 
 // backward from e->dlogits through the graph saved by forward_train, then Adam
@@ -972,6 +1021,7 @@ void net_forward_eval(fm_engine* e, bool teacher, int imgs)
 }
 void net_backward_and_step(fm_engine* e, int groups, int B)
 {
+    ensure_packed(e);
     if (e->model == 1) eff_backward_and_step(e, groups, B);
     else backward_and_step(e, groups, B);
 }
@@ -996,7 +1046,10 @@ int fm_create(const fm_config* cfg, fm_engine** out)
     ARGCHK(cfg->in_h >= 32 && cfg->in_w >= 32 && cfg->in_h % 32 == 0 && cfg->in_w % 32 == 0,
            "in_h/in_w must be multiples of 32");
     ARGCHK(cfg->max_images >= 1, "max_images");
+    ARGCHK(cfg->reserved[0] == 0 || (cfg->reserved[0] == 1 && cfg->model == 1),
+           "precision (reserved[0]) must be 0 (fp32) or, for EfficientNet-B0, 1 (bf16 activations)");
     fm_engine* e = new fm_engine();
+    e->precision = cfg->reserved[0];
     e->cfg = *cfg;
     e->st = reinterpret_cast<hipStream_t>(cfg->stream);
     e->C = cfg->n_classes; e->H = cfg->in_h; e->W = cfg->in_w; e->maxB = cfg->max_images;
@@ -1013,6 +1066,7 @@ int fm_destroy(fm_engine* e)
 {
     if (!e) return FM_OK;
     (void)hipStreamSynchronize(e->st);
+    if (e->comm) { (void)fmcomm_destroy(e->comm); e->comm = nullptr; }
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& p : e->evs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto v : e->ev_free) (void)hipEventDestroy(v);
@@ -1056,6 +1110,7 @@ int fm_set_state(fm_engine* e, const float* host_f32, const int64_t* host_i64)
     }
     HIPCHK(hipStreamSynchronize(e->st));
     e->ev_dirty = true;
+    e->wpack_dirty = true;
     return FM_OK;
 }
 
@@ -1087,6 +1142,7 @@ int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel)
     *dev_ptr = e->state;
     *numel = (int64_t)e->NS;
     e->ev_dirty = true;       // the caller is about to overwrite it (all-reduce)
+    e->wpack_dirty = true;
     return FM_OK;
 }
 
@@ -1108,6 +1164,104 @@ int fm_state_scale(fm_engine* e, float w)
     ARGCHK(e, "null engine");
     k_scale(e->state, w, (int64_t)e->NS, e->st);
     e->ev_dirty = true;
+    e->wpack_dirty = true;
+    return FM_OK;
+}
+
+/* ---- RCCL inside the library ------------------------------------------------------------- */
+#define COMMCHK(x)                                       \
+    do {                                                 \
+        if (!(x)) { g_err = fmcomm_error(); return FM_ERR_HIP; } \
+    } while (0)
+
+int fm_comm_unique_id(uint8_t* id128)
+{
+    ARGCHK(id128, "null id");
+    COMMCHK(fmcomm_unique_id(id128));
+    return FM_OK;
+}
+
+int fm_comm_init(fm_engine* e, const uint8_t* id128, int32_t rank, int32_t world)
+{
+    ARGCHK(e && id128 && world >= 1 && rank >= 0 && rank < world, "comm arguments");
+    if (e->comm) { COMMCHK(fmcomm_destroy(e->comm)); e->comm = nullptr; }
+    COMMCHK(fmcomm_init(&e->comm, id128, rank, world));
+    e->comm_rank = rank; e->comm_world = world;
+    const size_t need = std::max<size_t>((size_t)2 * e->C * e->D + 2 * e->C, e->counters.size()) + 64;
+    if (e->comm_buf_n < need) { DALLOC(e->comm_buf, need); e->comm_buf_n = need; }
+    return FM_OK;
+}
+
+int fm_comm_destroy(fm_engine* e)
+{
+    ARGCHK(e, "null engine");
+    if (e->comm) { HIPCHK(hipStreamSynchronize(e->st)); COMMCHK(fmcomm_destroy(e->comm)); }
+    e->comm = nullptr; e->comm_world = 0;
+    return FM_OK;
+}
+
+int fm_comm_size(fm_engine* e) { return (e && e->comm) ? e->comm_world : 0; }
+
+int fm_fedavg_allreduce(fm_engine* e, float w)
+{
+    ARGCHK(e, "null engine");
+    k_scale(e->state, w, (int64_t)e->NS, e->st);
+    e->ev_dirty = true; e->wpack_dirty = true;
+    if (!e->comm) return FM_OK;       // no communicator: a single client, FedAvg of one = w * state
+    // (1) the whole fp32 arena, in place, on the engine stream: the next round's first kernels queue behind it
+    COMMCHK(fmcomm_allreduce_sum(e->comm, e->state, e->NS, false, e->st));
+    // (2) num_batches_tracked: weighted mean in float64, truncated on load like utils/FedAvg.py:13 + load_state_dict
+    const size_t nb = e->counters.size();
+    std::vector<double> h(nb);
+    for (size_t i = 0; i < nb; ++i) h[i] = (double)w * (double)e->counters[i];
+    HIPCHK(hipMemcpyAsync(e->comm_buf, h.data(), nb * 8, hipMemcpyHostToDevice, e->st));
+    COMMCHK(fmcomm_allreduce_sum(e->comm, e->comm_buf, nb, true, e->st));
+    HIPCHK(hipMemcpyAsync(h.data(), e->comm_buf, nb * 8, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (size_t i = 0; i < nb; ++i) e->counters[i] = (int64_t)trunc(h[i] + 1e-9);
+    return FM_OK;
+}
+
+int fm_fedavg_tao(fm_engine* e, const double* t_host, double n_i, const float* negative_mask_host, double* out_host)
+{
+    ARGCHK(e && t_host && negative_mask_host && out_host, "null");
+    const int C = e->C;
+    std::vector<double> h(2 * C);
+    for (int c = 0; c < C; ++c) {
+        const double m = negative_mask_host[c] != 0.f ? 1.0 : 0.0;
+        h[c] = t_host[c] * n_i * m;
+        h[C + c] = n_i * m;
+    }
+    if (e->comm) {
+        HIPCHK(hipMemcpyAsync(e->comm_buf, h.data(), h.size() * 8, hipMemcpyHostToDevice, e->st));
+        COMMCHK(fmcomm_allreduce_sum(e->comm, e->comm_buf, h.size(), true, e->st));
+        HIPCHK(hipMemcpyAsync(h.data(), e->comm_buf, h.size() * 8, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipStreamSynchronize(e->st));
+    }
+    for (int c = 0; c < C; ++c) out_host[c] = h[C + c] == 0.0 ? 1.0 : h[c] / h[C + c];   // no active client: 1.0 (:66-67)
+    return FM_OK;
+}
+
+int fm_fedavg_proto(fm_engine* e, const float* proto_host, double n_i, const float* active_mask_host, float* out_host)
+{
+    ARGCHK(e && proto_host && active_mask_host && out_host, "null");
+    const int C = e->C, D = e->D;
+    const size_t np = (size_t)2 * C * D;
+    std::vector<float> h(np + 2 * C);
+    for (int r = 0; r < 2 * C; ++r) {
+        const bool m = active_mask_host[r / 2] != 0.f;
+        for (int d = 0; d < D; ++d) h[(size_t)r * D + d] = m ? proto_host[(size_t)r * D + d] * (float)n_i : 0.f;
+        h[np + r] = m ? (float)n_i : 0.f;
+    }
+    if (e->comm) {
+        float* buf = reinterpret_cast<float*>(e->comm_buf);
+        HIPCHK(hipMemcpyAsync(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice, e->st));
+        COMMCHK(fmcomm_allreduce_sum(e->comm, buf, h.size(), false, e->st));
+        HIPCHK(hipMemcpyAsync(h.data(), buf, h.size() * 4, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipStreamSynchronize(e->st));
+    }
+    for (int r = 0; r < 2 * C; ++r)
+        for (int d = 0; d < D; ++d) out_host[(size_t)r * D + d] = h[(size_t)r * D + d] / h[np + r];   // 0/0 = NaN row (:85-86)
     return FM_OK;
 }
 
@@ -1144,6 +1298,7 @@ int fm_forward_eval(fm_engine* e, const float* x_dev, int32_t B, int32_t use_tea
     if (logits_dev)
         HIPCHK(hipMemcpyAsync(logits_dev, use_teacher ? e->tlogits : e->logits, (size_t)B * e->C * 4,
                               hipMemcpyDeviceToDevice, e->st));
+    HIPCHK(hipGetLastError());
     return FM_OK;
 }
 
@@ -1158,6 +1313,7 @@ int fm_step_bce(fm_engine* e, const float* x_dev, const float* y_dev, int32_t B,
     k_loss_bce(e->logits, y_dev, to_cv(pos_weight_host, e->C), B, e->C, 1.f / ((float)bs_norm * (float)e->C),
                e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 1, B);
+    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
     return FM_OK;
 }
 
@@ -1177,6 +1333,7 @@ int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const
                   1.f / ((float)bs_norm * (float)annotation_num),
                   n_neg ? 1.f / ((float)bs_norm * (float)n_neg) : 0.f, e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 2, B);
+    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
     return FM_OK;
 }
 
@@ -1190,6 +1347,7 @@ int fm_step_stage2(fm_engine* e, const float* x_dev, const float* y_dev, const f
     net_forward_train(e, 1, B);
     k_loss_stage2(e->logits, y_dev, distill_dev, B, e->C, e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 1, B);
+    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
     return FM_OK;
 }
 
@@ -1209,6 +1367,7 @@ int fm_step_fixmatch(fm_engine* e, const float* xw_dev, const float* xs_dev, con
                     to_cv(active_mask_host, e->C), B, e->C, n_neg, 1.f / ((float)bs_norm * (float)annotation_num),
                     e->C - annotation_num, e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 2, B);
+    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
     return FM_OK;
 }
 
@@ -1314,6 +1473,7 @@ int fm_forward_train(fm_engine* e, const float* x1_dev, const float* x2_dev, int
     if (logits_dev)
         HIPCHK(hipMemcpyAsync(logits_dev, e->logits, (size_t)views * B * e->C * 4, hipMemcpyDeviceToDevice, e->st));
     e->pending_views = views; e->pending_B = B;
+    HIPCHK(hipGetLastError());
     return FM_OK;
 }
 
@@ -1325,6 +1485,7 @@ int fm_backward_step(fm_engine* e, const float* dlogits_dev)
     HIPCHK(hipMemcpyAsync(e->dlogits, dlogits_dev, (size_t)views * B * e->C * 4, hipMemcpyDeviceToDevice, e->st));
     net_backward_and_step(e, views, B);
     e->pending_views = 0;
+    HIPCHK(hipGetLastError());
     return FM_OK;
 }
 
@@ -1347,6 +1508,7 @@ int fm_teacher_swap(fm_engine* e)
     std::swap(e->ev_shift, e->tev_shift);
     std::swap(e->ev_dirty, e->tev_dirty);
     std::swap(e->counters, e->tcounters);
+    e->wpack_dirty = true;
     return FM_OK;
 }
 
@@ -1371,6 +1533,7 @@ int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms,
 {
     ARGCHK(e && family >= 0 && family < 5, "family");
     HIPCHK(hipStreamSynchronize(e->st));
+    if (e->prof_fail) { e->prof_fail = false; g_err = "a profiling event could not be created/recorded"; return FM_ERR_HIP; }
     for (auto& p : e->evs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
@@ -1445,6 +1608,7 @@ int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, co
         }
     } else if (op == 1) {
         ARGCHK(dy_dev && c.ncls > 0, "dgrad unavailable for this conv");
+        ensure_packed(e);
         conv_dgrad(e, conv, e->state, dy_dev, out_dev, imgs, nullptr, false);
     } else if (op == 2) {
         ARGCHK(x_dev && dy_dev, "x/dy");

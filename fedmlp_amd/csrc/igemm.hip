@@ -379,16 +379,11 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 2, 32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false, 2, 32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false>), LDS_L, "igemm_kernel<128, 128, 2, false>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>), LDS_S, "igemm_kernel<64, 256, 4, false>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 2, 32>), LDS_L, "igemm_kernel<128, 128, 2, false, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false, 2, 32>), LDS_S, "igemm_kernel<64, 256, 4, false, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, true>), LDS_S, "igemm_kernel<64, 256, 4, true>");
         attr_done = true;
     }
     // K per LDS stage: 32 (two stages) stages a whole 128-B line per DMA row -- the L1 hands out whole

@@ -16,6 +16,9 @@ void k_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, in
 void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s);
 // dgrad pack: out[ci][j][co] = w[co][taps.t[j]][ci]   (w is [Co][T][Ci])
 void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList taps, hipStream_t s);
+// all data-gradient weight packs of a step in one launch: job j fills jobs[j].out from state + jobs[j].w_off
+struct PackJob { long long w_off; float* out; int Co, T, Ci, ntaps; int taps[9]; int blk0; };
+void k_pack_dgrad_all(const float* state, const PackJob* jobs, int njobs, int nblocks, hipStream_t s);
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
 void k_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);   // y = a*y + b*x
 

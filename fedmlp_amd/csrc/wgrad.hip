@@ -339,12 +339,9 @@ void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
     constexpr int LDS_S = 2 * 32 * (64 + 256) * 4;
     constexpr int LDS_T = 2 * 32 * (64 + 192 + 16) * 4;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_L);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_S);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T);
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>), LDS_L, "wgrad_kernel<128, 128, 2>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4>), LDS_S, "wgrad_kernel<64, 256, 4>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3>), LDS_T, "wgrad_kernel<64, 192, 4, 3>");
         attr_done = true;
     }
     dim3 grid(p.tilesM * p.tilesN, splits);

@@ -11,6 +11,7 @@ import torch
 from . import _lib, spec
 
 MODEL_IDS = {"Resnet18": 0, "Efficient_b0": 1}
+PRECISION_IDS = {"fp32": 0, "bf16": 1}
 
 
 def _ptr(t):
@@ -25,16 +26,22 @@ class Engine:
     """One per process/GPU. Owns the device-resident model state, optimiser
     moments, teacher snapshot and activation workspaces for `max_images`."""
 
-    def __init__(self, model, n_classes, in_h, in_w, max_images, device="cuda:0"):
+    def __init__(self, model, n_classes, in_h, in_w, max_images, device=None, precision="fp32"):
         if not torch.cuda.is_available():
             raise RuntimeError("fedmlp_amd.Engine needs a GPU (no CPU fallback)")
         self.lib = _lib.load()
         self.model, self.n_classes = model, int(n_classes)
         self.in_h, self.in_w, self.max_images = int(in_h), int(in_w), int(max_images)
+        if device is None:                       # the rank's own GPU, never a hard-coded cuda:0
+            from .launch import default_device
+            device = default_device()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
+        self.precision = precision
+        if precision != "fp32" and model != "Efficient_b0":
+            raise ValueError("precision 'bf16' is built for Efficient_b0 only (BASELINE configs[4])")
         cfg = _lib.FmConfig(MODEL_IDS[model], self.n_classes, self.in_h, self.in_w,
-                            self.max_images, (C.c_int32 * 3)(0, 0, 0), None)
+                            self.max_images, (C.c_int32 * 3)(PRECISION_IDS[precision], 0, 0), None)
         h = C.c_void_p()
         _lib.check(self.lib.fm_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -125,8 +132,44 @@ class Engine:
         B = x.shape[0]
         feat = torch.empty((B, self.feature_dim), device=self.device, dtype=torch.float32)
         logits = torch.empty((B, self.n_classes), device=self.device, dtype=torch.float32)
-        _lib.check(self.lib.fm_forward_eval(self.h, _ptr(x), B, int(teacher), _ptr(feat), _ptr(logits)))
+        return self.forward_eval_into(x, feat, logits, teacher)
+
+    def forward_eval_into(self, x, feat, logits, teacher=False):
+        """net(x) in eval mode into caller-owned [B,D] / [B,C] device buffers (no allocation)."""
+        _lib.check(self.lib.fm_forward_eval(self.h, _ptr(x), x.shape[0], int(teacher), _ptr(feat), _ptr(logits)))
         return feat, logits
+
+    # ---- RCCL inside the C-ABI library (utils/FedAvg.py:7-14, 51-93 across ranks) ---------
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * _lib.FM_COMM_ID_BYTES)()
+        _lib.check(self.lib.fm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * _lib.FM_COMM_ID_BYTES)(*unique_id)
+        _lib.check(self.lib.fm_comm_init(self.h, buf, int(rank), int(world)))
+
+    def comm_size(self):
+        return int(self.lib.fm_comm_size(self.h))
+
+    def fedavg_allreduce(self, w):
+        """state <- sum_ranks w_rank * state_rank on the engine stream (ncclAllReduce in the library)."""
+        _lib.check(self.lib.fm_fedavg_allreduce(self.h, C.c_float(w)))
+
+    def fedavg_tao(self, t, n_i, negative_mask):
+        n = self.n_classes
+        tt = (C.c_double * n)(*[float(v) for v in t])
+        out = (C.c_double * n)()
+        _lib.check(self.lib.fm_fedavg_tao(self.h, tt, C.c_double(float(n_i)), _lib.fvec(negative_mask, n), out))
+        return np.array(out[:], dtype=np.float64)
+
+    def fedavg_proto(self, proto, n_i, active_mask):
+        n, D = self.n_classes, self.feature_dim
+        p = np.ascontiguousarray(proto, dtype=np.float32).reshape(2 * n, D)
+        out = np.empty((2 * n, D), np.float32)
+        _lib.check(self.lib.fm_fedavg_proto(self.h, p.ctypes.data_as(C.c_void_p), C.c_double(float(n_i)),
+                                            _lib.fvec(active_mask, n), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def _draw(self, imgs):
         if self.stochastic:
@@ -270,14 +313,24 @@ def _device_view(ptr, n, device):
 _ENGINES = {}
 
 
-def get_engine(model, n_classes, in_h, in_w, max_images, device="cuda:0"):
+def get_engine(model, n_classes, in_h, in_w, max_images, device=None, precision="fp32"):
     """Process-wide engine cache (engines own GBs of workspace; the reference's
     cheap deepcopy(net) objects map onto ONE engine whose state is swapped)."""
-    key = (model, int(n_classes), int(in_h), int(in_w), str(device))
+    if device is None:
+        from .launch import default_device
+        device = default_device()
+    key = (model, int(n_classes), int(in_h), int(in_w), str(device), precision)
     e = _ENGINES.get(key)
     if e is None or e.max_images < max_images:
         if e is not None:
+            # a larger workspace replaces the engine: first pull the resident net's device-only
+            # trained state to its host copy (and unbind it), or it would be lost with the handle
+            owner = getattr(e, "_owner", None)
+            if owner is not None:
+                owner._pull()
+                owner._engine = None
+            e._owner = None
             e.close()
-        e = Engine(model, n_classes, in_h, in_w, max_images, device)
+        e = Engine(model, n_classes, in_h, in_w, max_images, device, precision)
         _ENGINES[key] = e
     return e

@@ -69,7 +69,8 @@ def globaltest(net, test_dataset, args):
     net.eval()
     n = len(test_dataset)
     bs = args.batch_size * 4
-    views = test_dataset.device_views("cuda:0") if hasattr(test_dataset, "device_views") else None
+    from .launch import default_device
+    views = test_dataset.device_views(default_device()) if hasattr(test_dataset, "device_views") else None
     probs = []
     for i in range(0, n, bs):
         idx = list(range(i, min(n, i + bs)))

@@ -90,9 +90,27 @@ def allreduce_weighted_(tensor, w):
     return tensor
 
 
+def comm_init(engine):
+    """Create the library's own RCCL communicator (fm_comm_init) over the ranks of the current
+    torch.distributed job: rank 0 draws the ncclUniqueId, torch.distributed only carries those
+    128 bytes.  Returns the communicator's rank count."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return 1
+    box = [engine.comm_unique_id() if d.get_rank() == 0 else None]
+    d.broadcast_object_list(box, src=0)
+    engine.comm_init(box[0], d.get_rank(), d.get_world_size())
+    return engine.comm_size()
+
+
 def fedavg_allreduce(engine, w):
     """FedAvg of the device-resident model over all ranks: state <- sum_i w_i state_i with
-    w_i = n_i / sum(n).  The pre-scale is the engine's HIP kernel, the sum is RCCL."""
+    w_i = n_i / sum(n).  With a library communicator (comm_init) the pre-scale, the
+    ncclAllReduce of the arena and the counter mean all run inside the C ABI on the engine's
+    stream (fm_fedavg_allreduce); otherwise the sum goes through torch.distributed."""
+    if engine.comm_size() >= 1:
+        engine.fedavg_allreduce(float(w))
+        return engine.state_tensor()
     d = _dist()
     engine.state_scale(float(w))
     st = engine.state_tensor()
@@ -104,9 +122,11 @@ def fedavg_allreduce(engine, w):
     return st
 
 
-def tao_allreduce(t, n_i, is_negative_client_mask, device="cpu"):
+def tao_allreduce(t, n_i, is_negative_client_mask, device="cpu", engine=None):
     """FedAvg_tao over ranks: t[C] local, mask[c] = 1 if this client has class c missing
     (it is in class_negative_client_list[c], main.py:206-210, 223)."""
+    if engine is not None and engine.comm_size() >= 1:
+        return engine.fedavg_tao(t, n_i, is_negative_client_mask)
     m = np.asarray(is_negative_client_mask, dtype=np.float64)
     buf = torch.from_numpy(np.concatenate([np.asarray(t, np.float64) * n_i * m, n_i * m])).to(device)
     d = _dist()
@@ -118,8 +138,10 @@ def tao_allreduce(t, n_i, is_negative_client_mask, device="cpu"):
     return np.where(den == 0, 1.0, num / np.where(den == 0, 1.0, den))
 
 
-def proto_allreduce(proto, n_i, is_active_client_mask, device="cpu"):
+def proto_allreduce(proto, n_i, is_active_client_mask, device="cpu", engine=None):
     """FedAvg_proto over ranks: proto[2C,D] local, mask[c] = 1 if this client annotates c."""
+    if engine is not None and engine.comm_size() >= 1:
+        return torch.from_numpy(engine.fedavg_proto(_np(proto), n_i, is_active_client_mask))
     m = np.repeat(np.asarray(is_active_client_mask, dtype=np.float32), 2)[:, None]
     P = np.asarray(_np(proto), dtype=np.float32) * np.float32(n_i)     # NaN rows of an active class propagate
     num = torch.from_numpy(np.where(m > 0, P, 0.0).astype(np.float32)).to(device)

@@ -432,6 +432,13 @@ class LocalUpdate(object):
                 self.traindata_idx[2 * k + 1].extend(noise)
         for k, cls in enumerate(negetive_class_list):                      # :1117-1120
             self.class_num_list[cls] = len(self.traindata_idx[2 * k + 1])
+        # :1150-1156: `loss_w = self.loss_w` aliases the list, so the per-class clean/noise ratio (or
+        # 5.0) permanently replaces the pos_weight of every missing class.  Stage 2 itself trains with
+        # un-weighted BCE (:1184), but a later train / train_FixMatch / train_RSCFed / train_CBAFed on
+        # this LocalUpdate sees the mutated weights, exactly like the reference.
+        for k, cls in enumerate(negetive_class_list):
+            n_noise = len(self.traindata_idx[2 * k + 1])
+            self.loss_w[cls] = len(self.traindata_idx[2 * k]) / n_noise if n_noise != 0 else 5.0
         # (d) training on pseudo-labelled targets (DatasetSplit_pseudo :1456-1477; loop :1164-1196)
         yp, dist = pseudo_targets(self._targets_local, self.idxs, active_class_list_client_i,
                                   negetive_class_list, self.traindata_idx)

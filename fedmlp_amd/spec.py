@@ -183,3 +183,42 @@ def state_dict_to_flat(model, n_classes, sd):
             assert tuple(v.shape) == tuple(shape), (key, v.shape, shape)
             fl.append(v.astype(np.float32).reshape(-1))
     return np.concatenate(fl), np.array(cnt, dtype=np.int64)
+
+
+def merge_state_dict(model, n_classes, sd, flat, counters):
+    """load_state_dict(strict=False): entries of `sd` whose key exists and whose shape matches
+    replace the current value; missing keys and shape-mismatched entries (an ImageNet fc
+    [1000, D] loaded into a C-class model, model/all_models.py:117-124) keep the current
+    value.  Returns (flat, counters, missing_keys, unexpected_keys, mismatched_keys)."""
+    flat = np.array(flat, dtype=np.float32, copy=True)
+    counters = np.array(counters, dtype=np.int64, copy=True)
+    missing, mismatched = [], []
+    known = set()
+    of = oc = 0
+    for key, shape, dt in entries(model, n_classes):
+        known.add(key)
+        n = int(np.prod(shape)) if shape else 1
+        v = sd.get(key) if hasattr(sd, "get") else None
+        if v is None:
+            missing.append(key)
+        else:
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            v = np.asarray(v)
+            if dt == "i64":
+                counters[oc] = int(np.trunc(float(v.reshape(-1)[0])))
+            elif tuple(v.shape) != tuple(shape):
+                mismatched.append(key)
+            else:
+                flat[of:of + n] = v.astype(np.float32).reshape(-1)
+        if dt == "i64":
+            oc += 1
+        else:
+            of += n
+    unexpected = [k for k in sd.keys() if k not in known]
+    return flat, counters, missing, unexpected, mismatched
+
+
+def classifier_keys(model):
+    """The layer modify_last_layer replaces (model/all_models.py:117-124)."""
+    return ("fc.weight", "fc.bias") if model == "Resnet18" else ("_fc.weight", "_fc.bias")

@@ -48,7 +48,11 @@ typedef struct fm_config {
     int32_t in_h, in_w;   /* input spatial size (224 in the reference, >= 32)        */
     int32_t max_images;   /* max images in ONE forward call (views x batch; eval     */
                           /* passes use 4*batch_size, utils/local_training.py:977)   */
-    int32_t reserved[3];
+    int32_t reserved[3];  /* reserved[0] = activation precision: 0 fp32 (the reference's arithmetic,
+                             utils/local_training.py:14 imports autocast and never uses it);
+                             1 bf16 activation storage + bf16 MFMA for the 1x1 convolutions, fp32
+                             accumulation / BN statistics / master weights / Adam -- EfficientNet-B0
+                             only (BASELINE configs[4]).  reserved[1..2] must be 0. */
     void*   stream;       /* hipStream_t; NULL = null stream                         */
 } fm_config;
 
@@ -82,6 +86,33 @@ int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel);
 int fm_counters(fm_engine* e, int64_t* host_i64, int32_t set);
 /* state *= w  (the n_i / sum(n) pre-scale before the all-reduce SUM). */
 int fm_state_scale(fm_engine* e, float w);
+/* ---- FedAvg across ranks as RCCL calls inside the library (one client per GPU) --------------
+ * utils/FedAvg.py:7-14 (FedAvg), :51-70 (FedAvg_tao), :72-93 (FedAvg_proto) walk a Python list of
+ * client results in one process.  With one process per GPU the same weighted sums are
+ * ncclAllReduce(SUM) calls over xGMI, enqueued on the engine's stream.  RCCL is resolved at run
+ * time (dlopen); the communicator is the library's own, so a C caller needs no Python:
+ *   rank 0: fm_comm_unique_id(id)  -> ship the 128 bytes to every rank (any transport)
+ *   all   : fm_comm_init(e, id, rank, world)
+ * fm_comm_size returns the rank count (0 = no communicator).  Without a communicator (or with a
+ * world of 1) the fm_fedavg_* calls compute the single-client result locally. */
+#define FM_COMM_ID_BYTES 128
+int fm_comm_unique_id(uint8_t* id128);
+int fm_comm_init(fm_engine* e, const uint8_t* id128, int32_t rank, int32_t world);
+int fm_comm_destroy(fm_engine* e);
+int fm_comm_size(fm_engine* e);
+/* FedAvg: state <- sum_ranks w_rank * state_rank, w_rank = n_rank / sum(n): the pre-scale kernel,
+ * ONE in-place all-reduce of the whole fp32 state arena (44.8 MB for ResNet-18) and the float64
+ * weighted mean of the num_batches_tracked counters (truncated on load like utils/FedAvg.py:13). */
+int fm_fedavg_allreduce(fm_engine* e, float w);
+/* FedAvg_tao over ranks: out[c] = sum_r t_r[c] n_r m_r[c] / sum_r n_r m_r[c] with m_r = this
+ * rank's negative_mask (1 = class c is missing on this client); 1.0 where no rank has it (:66-67). */
+int fm_fedavg_tao(fm_engine* e, const double* t_host, double n_i, const float* negative_mask_host,
+                  double* out_host);
+/* FedAvg_proto over ranks: rows 2c, 2c+1 averaged over the ranks whose active_mask[c] = 1,
+ * NaN rows where no rank annotates c (0/0 like :85-86).  proto/out: host [2C*D] fp32. */
+int fm_fedavg_proto(fm_engine* e, const float* proto_host, double n_i, const float* active_mask_host,
+                    float* out_host);
+
 /* glob_model = deepcopy(net) at round start (utils/local_training.py:909, 1017):
  * snapshot the current state as the frozen eval-mode teacher. */
 int fm_teacher_snapshot(fm_engine* e);

@@ -537,6 +537,9 @@ class RefClient:
                 self.traindata_idx[2 * k + 1].extend(noise)
         for k, cls in enumerate(negative_param):
             self.class_num_list[cls] = len(self.traindata_idx[2 * k + 1])
+        for k, cls in enumerate(negative_param):         # :1150-1156 (`loss_w = self.loss_w` aliases the list)
+            n_noise = len(self.traindata_idx[2 * k + 1])
+            self.loss_w[cls] = len(self.traindata_idx[2 * k]) / n_noise if n_noise != 0 else 5.0
         # training on pseudo-labelled targets
         y, dist = pseudo_targets(self.targets, self.idxs, self.active, negative_param,
                                  self.traindata_idx)

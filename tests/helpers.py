@@ -58,3 +58,39 @@ def assert_norms_close(got, want, rtol, atol=1e-7, what=""):
     for k, w in want.items():
         g = got[k]
         assert abs(g - w) <= atol + rtol * abs(w), f"{what} {k}: got {g} want {w}"
+
+
+def relu_margin(net, xs, max_count=64):
+    """Smallest |pre-activation| over the ReLUs whose BN statistics are thin (<= max_count values per
+    channel) in a train-mode forward of `net` (a copy: running stats untouched) on the views `xs`.
+    A pre-activation within rounding distance of 0 gets its ReLU mask from the summation order of the
+    conv that produced it; where a channel holds only a few dozen values, one flipped mask moves that
+    channel's BN-backward sums by percents.  Parity tests use this ORACLE-side number to pick
+    well-conditioned inputs up front (never by looking at which inputs the HIP path happens to pass)."""
+    import copy
+    import torch.nn.functional as F
+    probe = copy.deepcopy(net).train()
+    worst = [float("inf")]
+    orig = F.relu
+
+    def spy(t, *a, **k):
+        if t.dim() == 4 and t.shape[0] * t.shape[2] * t.shape[3] <= max_count:
+            worst[0] = min(worst[0], float(t.detach().abs().min()))
+        return orig(t, *a, **k)
+    F.relu = spy
+    try:
+        with torch.no_grad():
+            for x in xs:
+                probe(x)
+    finally:
+        F.relu = orig
+    return worst[0]
+
+
+def conditioned_seed(net, make_views, seeds, margin=1e-5):
+    """First seed whose inputs keep every thin-statistics ReLU pre-activation of the oracle at least
+    `margin` away from 0 (fp32 conv sums differ by ~1e-6 between summation orders)."""
+    for sd in seeds:
+        if relu_margin(net, make_views(sd)) > margin:
+            return sd
+    raise AssertionError(f"no seed in {list(seeds)} is {margin}-conditioned")

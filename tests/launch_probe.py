@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""CPU stand-in for `python bench.py --gpus N`: same launch logic (fedmlp_amd.launch), gloo instead
+of RCCL, so the self-launch path (parent spawns N ranks, rank 0 prints ONE JSON line, the parent
+exits with the children's code) is covered without a GPU."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--fail-rank", type=int, default=-1)
+    args = ap.parse_args()
+    from fedmlp_amd.launch import launched_by_torchrun, spawn_ranks
+    if args.gpus > 1 and not launched_by_torchrun():
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus
+    if world > 1:
+        dist.init_process_group("gloo")
+    if rank == args.fail_rank:
+        sys.exit(3)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "sum": t.item(), "local_rank": os.environ.get("LOCAL_RANK")}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@ import torch
 
 from fedmlp_amd import spec
 from oracle import steps_ref as R
-from tests.helpers import oracle_net
+from tests.helpers import oracle_net, conditioned_seed
 
 pytestmark = pytest.mark.gpu
 
@@ -81,19 +81,12 @@ def _cmp_state(e, net, atol_w):
         np.testing.assert_allclose(sd[k], want, rtol=1e-4, atol=tol, err_msg=k)
 
 
-def _majority_of_seeds(fn, seeds):
-    """Run a one-step parity check on several data seeds and require a majority to pass.
-    Why: a single ReLU input within ~1e-7 of zero (seen once: layer4.1 channel 458, pre-activation
-    = bn2(y2) + a dead identity) gets its mask from the rounding of the conv summation order; the
-    flipped mask changes that channel's BN-backward sums and spreads a ~1 % error to every upstream
-    gradient.  That is a knife-edge of the comparison, not of the kernels; a real bug fails every seed."""
-    errs = []
-    for sd in seeds:
-        try:
-            fn(sd)
-        except AssertionError as ex:
-            errs.append(f"seed {sd}: {str(ex)[:300]}")
-    assert len(errs) * 2 < len(seeds), " | ".join(errs)
+def _seed(views, B, seeds):
+    """Data seed picked by the ORACLE's ReLU margins (tests/helpers.conditioned_seed): a pre-activation
+    within rounding distance of zero in layer 4 (32 values per channel here) takes its mask from the conv
+    summation order and would turn a 1e-6 difference into a percent-level one for that channel."""
+    net = oracle_net(C_, 1037)
+    return conditioned_seed(net, lambda sd: _data(B, sd, views)[0], seeds)
 
 
 def test_forward_eval(eng):
@@ -108,10 +101,7 @@ def test_forward_eval(eng):
 
 
 def test_step_bce(eng):
-    _majority_of_seeds(lambda sd: _step_bce(eng, sd), (2, 12, 22))
-
-
-def _step_bce(eng, seed):
+    seed = _seed(1, 6, range(2, 40))
     net = _load(eng)
     (x,), y = _data(6, seed)
     pw = [3.0, 1.5, 4.0, 2.0, 2.5]
@@ -128,10 +118,7 @@ def _step_bce(eng, seed):
 
 
 def test_step_stage1(eng):
-    _majority_of_seeds(lambda sd: _step_stage1(eng, sd), (3, 13, 23))
-
-
-def _step_stage1(eng, seed):
+    seed = _seed(2, 6, range(3, 40))
     net = _load(eng)
     (x1, x2), y = _data(6, seed, views=2)
     act, neg = [1], [0, 2, 3, 4]
@@ -153,10 +140,7 @@ def _step_stage1(eng, seed):
 
 
 def test_step_stage2(eng):
-    _majority_of_seeds(lambda sd: _step_stage2(eng, sd), (4, 14, 24))
-
-
-def _step_stage2(eng, seed):
+    seed = _seed(1, 7, range(4, 40))
     net = _load(eng)
     (x,), y = _data(7, seed)
     g = torch.Generator().manual_seed(44)

@@ -24,6 +24,9 @@ class FakeEngine:
     def __init__(self, state, counters):
         self.state, self.cnt = state, counters
 
+    def comm_size(self):
+        return 0                      # no library communicator: the sums go through torch.distributed (gloo here)
+
     def state_scale(self, w):
         self.state.mul_(w)
 

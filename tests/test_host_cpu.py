@@ -200,3 +200,62 @@ def test_checkpoint_roundtrip_efficient_b0(tmp_path):
     net2.load_state_dict(torch.load(path))
     np.testing.assert_array_equal(net2.flat, flat)
     np.testing.assert_array_equal(net2.counters, cnt)
+
+
+# ---- checkpoints: ImageNet-pretrained load with the classifier swap (model/all_models.py:99-130) -------
+def _imagenet_like_sd(model, seed=3):
+    flat, cnt = spec.init_state(model, 1000, seed)
+    sd = spec.flat_to_state_dict(model, 1000, flat, cnt + 5)
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("model", ["Resnet18", "Efficient_b0"])
+def test_load_state_dict_nonstrict_keeps_classifier_and_takes_backbone(model):
+    from fedmlp_amd.model import build_model
+    args = make_args(model=model, n_classes=5, pretrained=0)
+    net = build_model(args)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    sd = _imagenet_like_sd(model)
+    with pytest.raises((RuntimeError, AssertionError)):
+        net.load_state_dict(sd)                      # strict: the 1000-class classifier does not fit
+    res = net.load_state_dict(sd, strict=False)
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    assert tuple(res.mismatched_keys) == spec.classifier_keys(model)
+    after = net.state_dict()
+    for k in after:
+        if k in spec.classifier_keys(model):
+            assert torch.equal(after[k], before[k]), k          # fresh Linear(D, C) kept (modify_last_layer)
+        elif "num_batches_tracked" in k:
+            assert int(after[k]) == int(sd[k])
+        else:
+            assert torch.equal(after[k], sd[k]), k
+    # a partial dict (missing keys) leaves the rest alone
+    some = {k: sd[k] for k in list(sd)[:7]}
+    res = net.load_state_dict(some, strict=False)
+    assert len(res.missing_keys) == len(after) - 7
+
+
+def test_build_model_pretrained_flag(tmp_path, monkeypatch):
+    """args.pretrained defaults to 1 in the reference (utils/options.py:26): without a local checkpoint
+    build_model must say so loudly; with one it loads the backbone and re-inits the classifier."""
+    from fedmlp_amd.model import build_model, PRETRAINED_FILES
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nohub"))
+    monkeypatch.delenv("FEDMLP_PRETRAINED_DIR", raising=False)
+    args = make_args(model="Resnet18", n_classes=5, pretrained=1)
+    with pytest.warns(RuntimeWarning, match="no ImageNet checkpoint"):
+        scratch = build_model(args)
+    sd = _imagenet_like_sd("Resnet18")
+    torch.save(sd, tmp_path / PRETRAINED_FILES["Resnet18"])
+    monkeypatch.setenv("FEDMLP_PRETRAINED_DIR", str(tmp_path))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net = build_model(args)
+    got = net.state_dict()
+    assert torch.equal(got["layer3.1.conv2.weight"], sd["layer3.1.conv2.weight"])
+    assert got["fc.weight"].shape == (5, 512)
+    assert torch.equal(got["fc.weight"], scratch.state_dict()["fc.weight"])
+    # an explicit path wins
+    args.pretrained_path = str(tmp_path / PRETRAINED_FILES["Resnet18"])
+    monkeypatch.delenv("FEDMLP_PRETRAINED_DIR")
+    assert torch.equal(build_model(args).state_dict()["conv1.weight"], sd["conv1.weight"])

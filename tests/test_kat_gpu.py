@@ -1,0 +1,167 @@
+"""Known-answer tests of the index / selection / prototype work ON THE GPU, through the C ABI,
+straight from the reference-generated vectors of tests/golden/kat.json (made by
+tests/golden/make_golden.py importing /root/reference): stable top-/bottom-k with ties
+(utils/utils.py:24-35 via utils/local_training.py:1061-1087) bit-exact, CosineSimilarityFast
+(:1417-1435) to 1e-6, the prototype + t pass (:971-1002, :1208-1250) at D = 512 including the
+0/0 = NaN and zero-guard cases.  Plus the library's own RCCL entry points on a world of one."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import steps_ref as R
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+C_, HW, D = 5, 64, 512
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fedmlp_amd.engine import Engine
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return load_golden("kat.json")
+
+
+def _select(eng, values, clean_thr, noise_thr):
+    sim = torch.tensor(values, dtype=torch.float32, device=eng.device)
+    return eng.select_topk(sim, clean_thr, noise_thr)
+
+
+def test_select_topk_reference_kat_with_ties(eng, kat):
+    """kat.topk.lst = [.1, .5, .5, -1, .5, -1, 3, .1]: three-way and two-way ties.  n_clean = 6,
+    n_noise = 2; thresholds are chosen so that int(thr * n) walks every k the golden holds."""
+    g = kat["topk"]
+    lst = g["lst"]
+    n_clean = sum(v >= 0 for v in lst)
+    n_noise = sum(v < 0 for v in lst)
+    for kt in range(n_clean + 1):
+        for kb in range(n_noise + 1):
+            top, bot = _select(eng, lst, (kt + 0.5) / n_clean, (kb + 0.5) / n_noise)
+            assert top == g["max"][str(kt)], (kt, top)
+            assert bot == g["min"][str(kb)], (kb, bot)
+
+
+def test_select_topk_heavy_ties_matches_reference_semantics(eng):
+    """N = 5 000 similarities quantised to 41 levels (every value tied ~120 times) and an
+    all-equal row: positions must equal Python's stable sorted() order exactly."""
+    rs = np.random.RandomState(5)
+    for vals in (np.round(rs.uniform(-1, 1, 5000) * 20) / 20, np.zeros(777), -np.ones(300)):
+        vals = vals.astype(np.float32)
+        lst = vals.tolist()
+        n_clean = int((vals >= 0).sum()); n_noise = int((vals < 0).sum())
+        for ct, nt in ((0.005, 0.01), (0.25, 0.5), (1.0, 1.0)):
+            kt, kb = int(1 * ct * n_clean), int(1 * nt * n_noise)
+            top, bot = _select(eng, lst, ct, nt)
+            assert top == R.max_m_indices(lst, kt)
+            assert bot == R.min_n_indices(lst, kb)
+
+
+def test_select_topk_empty_and_single(eng):
+    assert _select(eng, [0.25], 0.005, 0.01) == ([], [])
+    assert _select(eng, [0.25], 1.0, 1.0) == ([0], [])
+    assert _select(eng, [-0.25], 1.0, 1.0) == ([], [0])
+    sim = torch.empty(0, dtype=torch.float32, device=eng.device)
+    assert eng.select_topk(sim, 1.0, 1.0) == ([], [])
+
+
+def _pad(a, width):
+    out = np.zeros((a.shape[0], width), np.float32)
+    out[:, :a.shape[1]] = a
+    return out
+
+
+def test_cos_tag_reference_kat(eng, kat):
+    """kat.cosine (D = 16, embedded in the engine's D = 512 with zero columns, which leaves every
+    dot product and norm unchanged): sim = cos(f, P0) - cos(f, P1) to 1e-6."""
+    g = kat["cosine"]
+    f = _pad(np.asarray(g["f"], np.float32), D)
+    proto = np.zeros((2 * C_, D), np.float32)
+    cls = 3
+    proto[2 * cls, :16] = np.asarray(g["p0"], np.float32)
+    proto[2 * cls + 1, :16] = np.asarray(g["p1"], np.float32)
+    sim = eng.cos_tag(torch.from_numpy(f).to(eng.device), torch.from_numpy(proto).to(eng.device), [cls])
+    np.testing.assert_allclose(sim[0].cpu().numpy(), np.asarray(g["sim"], np.float32), rtol=0, atol=1e-6)
+    # SURVEY's hand-checkable triple
+    f3 = _pad(np.array([[1., 2, 3], [0, -1, .5], [2, 0, 0]], np.float32), D)
+    p3 = np.zeros((2 * C_, D), np.float32)
+    p3[0, :3] = [1., 0, 0]; p3[1, :3] = [0., 1, 1]
+    sim = eng.cos_tag(torch.from_numpy(f3).to(eng.device), torch.from_numpy(p3).to(eng.device), [0])
+    np.testing.assert_allclose(sim[0].cpu().numpy(), np.asarray(kat["cosine_survey"]["sim"], np.float32), atol=1e-6)
+
+
+def test_cos_tag_nan_prototype_disables_class(eng):
+    """FedAvg_proto leaves NaN rows for a class without an active client (utils/FedAvg.py:85-86):
+    sim is NaN, counts as neither >= 0 nor < 0, so nothing is selected."""
+    rs = np.random.RandomState(1)
+    f = torch.from_numpy(rs.standard_normal((300, D)).astype(np.float32)).to(eng.device)
+    proto = torch.from_numpy(rs.standard_normal((2 * C_, D)).astype(np.float32))
+    proto[4:6] = float("nan")
+    sim = eng.cos_tag(f, proto.to(eng.device), [2, 1])
+    assert torch.isnan(sim[0]).all() and torch.isfinite(sim[1]).all()
+    assert eng.select_topk(sim[0].contiguous(), 1.0, 1.0) == ([], [])
+    want = R.cosine_diff(f.cpu(), proto[2], proto[3])
+    np.testing.assert_allclose(sim[1].cpu().numpy(), np.asarray(want), atol=1e-6)
+
+
+def test_proto_pass_d512_matches_oracle_incl_nan_and_zero_guard(eng):
+    """Two accumulate calls over ragged batches at D = 512; class 0 has positives and negatives,
+    class 2 is active with NO positives: unguarded finalisation gives a 0/0 = NaN row
+    (utils/local_training.py:997-999), the guarded one leaves the zero row (:1240-1248)."""
+    rs = np.random.RandomState(9)
+    batches = []
+    for b in (7, 3):
+        f = torch.from_numpy(rs.standard_normal((b, D)).astype(np.float32))
+        z = torch.from_numpy(rs.standard_normal((b, C_)).astype(np.float32) * 2)
+        y = torch.from_numpy((rs.uniform(size=(b, C_)) < 0.4).astype(np.float32))
+        y[:, 2] = 0.0
+        batches.append((f, z, y))
+    act_list, neg_list = [0, 2], [1, 3, 4]
+    act = [1.0 if c in act_list else 0.0 for c in range(C_)]
+    neg = [1.0 if c in neg_list else 0.0 for c in range(C_)]
+    n_local = 10
+    for guard in (False, True):
+        eng.proto_reset()
+        for f, z, y in batches:
+            eng.proto_accumulate(f.to(eng.device), z.to(eng.device), y.to(eng.device), act, neg, 0.3, 0.7)
+        t, proto = eng.proto_finalize(guard, n_local, act)
+        want_t, want_p = R.prototype_pass(batches, C_, act_list, neg_list, 0.3, 0.7, n_local, guard)
+        np.testing.assert_array_equal(t, want_t)                       # integer counts / n: exact
+        np.testing.assert_allclose(proto, want_p.numpy(), rtol=1e-6, atol=1e-6, equal_nan=True)
+        assert np.isnan(proto[5]).all() != guard                       # row 2*2+1: NaN unguarded, zeros guarded
+        assert (proto[2] == 0).all() and (proto[6:] == 0).all()        # non-active rows stay zero
+
+
+def test_library_rccl_world_of_one(eng):
+    """fm_comm_unique_id / fm_comm_init / fm_fedavg_* through the C ABI with one rank: RCCL loads,
+    the communicator forms, and the all-reduce of the state arena is the identity on w = 1."""
+    from fedmlp_amd import spec
+    flat, cnt = spec.init_state("Resnet18", C_, 11)
+    cnt = cnt + 3
+    eng.set_state(flat, cnt)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(uid, 0, 1)
+    assert eng.comm_size() == 1
+    eng.fedavg_allreduce(1.0)
+    got, gcnt = eng.get_state()
+    np.testing.assert_array_equal(got, flat)
+    np.testing.assert_array_equal(gcnt, cnt)
+    eng.fedavg_allreduce(0.5)
+    got, _ = eng.get_state()
+    np.testing.assert_array_equal(got, flat * np.float32(0.5))
+    t = eng.fedavg_tao([0.1, 0.2, 0.3, 0.4, 0.5], 300, [0, 1, 1, 0, 1])
+    np.testing.assert_allclose(t, [1.0, 0.2, 0.3, 1.0, 0.5], rtol=1e-15)
+    p = np.arange(2 * C_ * D, dtype=np.float32).reshape(2 * C_, D)
+    out = eng.fedavg_proto(p, 300, [1, 0, 0, 0, 0])
+    np.testing.assert_allclose(out[:2], p[:2], rtol=1e-6)
+    assert np.isnan(out[2:]).all()
