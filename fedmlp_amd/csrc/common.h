@@ -5,6 +5,25 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- activation storage types -------------------------------------------------------------------
+// The EfficientNet-B0 path stores its NHWC activations either as fp32 (the reference's arithmetic)
+// or as bf16 (BASELINE configs[4]); every kernel computes in fp32 registers.  ld4 / st4 move 4
+// consecutive channels: 16 B (fp32) or 8 B (bf16) per lane.  The float -> bf16 cast is the
+// compiler's (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN).
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+enum { DT_F32 = 0, DT_BF16 = 1 };
+#if defined(__HIPCC__)
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16* p)
+{
+    return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
+#endif
+
 // ---------------------------------------------------------------------------
 // Implicit-GEMM convolution (forward and data-gradient), fp32 MFMA.
 //   D[m][n] = sum_k Wp[m][k] * Xg[n][k]

@@ -32,9 +32,10 @@ __device__ __forceinline__ float swish_grad(float v)
 
 // ------------------------------------------------------------ BN(+act) apply ---
 // out = act(y*scale+shift) * rowscale[img] + res      (per group scale/shift, any C % 4 == 0)
-__global__ void bnact_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                   const float* __restrict__ shift, const float* __restrict__ res,
-                                   const float* __restrict__ rowscale, float* __restrict__ out, int pix_per_group,
+template <typename TY, typename TA>
+__global__ void bnact_apply_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, const TA* __restrict__ res,
+                                   const float* __restrict__ rowscale, TA* __restrict__ out, int pix_per_group,
                                    int HW, int C, int act)
 {
     const int g = blockIdx.y;
@@ -46,27 +47,41 @@ __global__ void bnact_apply_kernel(const float* __restrict__ y, const float* __r
         const int cq = (int)(i % Q);
         const int64_t pix = i / Q;
         const size_t o = base + (size_t)i * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(y + o) * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
-                  *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+        f32x4 v = ld4(y + o) * ld4(scale + g * C + cq * 4) +
+                  ld4(shift + g * C + cq * 4);
         v = act_fwd(v, act);
         if (rowscale) v = v * rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
-        if (res) v += *reinterpret_cast<const f32x4*>(res + o);
-        *reinterpret_cast<f32x4*>(out + o) = v;
+        if (res) v += ld4(res + o);
+        st4(out + o, v);
     }
 }
-void k_bnact_apply(const float* y, const float* scale, const float* shift, const float* res, const float* rowscale,
-                   float* out, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s)
+// ty / ta: storage type of the raw conv output y and of the activations (res, out): DT_F32 or DT_BF16
+// (the stem's y stays fp32 in the bf16 configuration: it comes from the fp32 implicit-GEMM kernel)
+template <typename T> static inline const T* cp(const void* p) { return reinterpret_cast<const T*>(p); }
+template <typename T> static inline T* mp(void* p) { return reinterpret_cast<T*>(p); }
+
+void k_bnact_apply(const void* y, int ty, const float* scale, const float* shift, const void* res, const float* rowscale,
+                   void* out, int ta, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s)
 {
     const int64_t n4 = (int64_t)pix_per_group * (C / 4);
-    hipLaunchKernelGGL(bnact_apply_kernel, dim3(cdiv(n4, 256), groups), dim3(256), 0, s, y, scale,
-                       shift, res, rowscale, out, pix_per_group, HW, C, act);
+    const dim3 grid(cdiv(n4, 256), groups);
+    if (ty == DT_F32 && ta == DT_F32)
+        hipLaunchKernelGGL((bnact_apply_kernel<float, float>), grid, dim3(256), 0, s, cp<float>(y), scale, shift, cp<float>(res),
+                           rowscale, mp<float>(out), pix_per_group, HW, C, act);
+    else if (ty == DT_F32)
+        hipLaunchKernelGGL((bnact_apply_kernel<float, bf16>), grid, dim3(256), 0, s, cp<float>(y), scale, shift, cp<bf16>(res),
+                           rowscale, mp<bf16>(out), pix_per_group, HW, C, act);
+    else
+        hipLaunchKernelGGL((bnact_apply_kernel<bf16, bf16>), grid, dim3(256), 0, s, cp<bf16>(y), scale, shift, cp<bf16>(res),
+                           rowscale, mp<bf16>(out), pix_per_group, HW, C, act);
 }
 
 // ------------------------------------------------------------ channel reductions
 // mode 0: (sum y, sum y^2)                        -> forward BN statistics
 // mode 1: (sum dyh, sum dyh*xhat), dyh = dz * act'(v) * rowscale   -> BN backward sums
 // part layout [groups][nblk][2][C] (what bn_finalize / bn_bwd_finalize consume)
-__global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y,
+template <typename TY, typename TA>
+__global__ void chan_reduce_kernel(const TA* __restrict__ a, const TY* __restrict__ y,
                                    const float* __restrict__ mean, const float* __restrict__ istd,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ rowscale, float* __restrict__ part, int pix_per_group,
@@ -87,11 +102,11 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
         if (active) {
             f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
             if (mode == 1) {
-                mu = *reinterpret_cast<const f32x4*>(mean + g * C + cq * 4);
-                is = *reinterpret_cast<const f32x4*>(istd + g * C + cq * 4);
+                mu = ld4(mean + g * C + cq * 4);
+                is = ld4(istd + g * C + cq * 4);
                 if (act == 2) {
-                    sc = *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4);
-                    sh = *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+                    sc = ld4(scale + g * C + cq * 4);
+                    sh = ld4(shift + g * C + cq * 4);
                 }
             }
             for (int t0 = blockIdx.x * TP; t0 < pix_per_group; t0 += nblk * TP)
@@ -99,16 +114,16 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
             for (int p = t0 + pl; p < min(pix_per_group, t0 + TP); p += P) {
                 const size_t o = base + (size_t)p * C + cq * 4;
                 if (mode == 0) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+                    const f32x4 v = ld4(y + o);
                     s1 += v;
                     s2 += v * v;
                 } else {
-                    f32x4 d = *reinterpret_cast<const f32x4*>(a + o);
-                    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+                    f32x4 d = ld4(a + o);
+                    const f32x4 yy = ld4(y + o);
                     if (gate) {          // squeeze-excite backward folded in: d(a_d) = d(a_s)*gate + ds/HW
                         const size_t io = ((size_t)g * (pix_per_group / HW) + p / HW) * C + cq * 4;
-                        d = d * *reinterpret_cast<const f32x4*>(gate + io) +
-                            *reinterpret_cast<const f32x4*>(dsv + io) * (1.f / (float)HW);
+                        d = d * ld4(gate + io) +
+                            ld4(dsv + io) * (1.f / (float)HW);
                     }
                     if (act == 2) {
                         const f32x4 v = yy * sc + sh;
@@ -127,25 +142,34 @@ __global__ void chan_reduce_kernel(const float* __restrict__ a, const float* __r
         if (pl == 0) {
             for (int k = 1; k < P; ++k) { s1 += red[0][k * QT + cq0]; s2 += red[1][k * QT + cq0]; }
             float* o = part + ((size_t)(g * nblk + blockIdx.x) * 2) * C + cq * 4;
-            *reinterpret_cast<f32x4*>(o) = s1;
-            *reinterpret_cast<f32x4*>(o + C) = s2;
+            st4(o, s1);
+            st4(o + C, s2);
         }
     }
 }
-void k_chan_reduce(const float* a, const float* y, const float* mean, const float* istd, const float* scale,
+void k_chan_reduce(const void* a, int ta, const void* y, int ty, const float* mean, const float* istd, const float* scale,
                    const float* shift, const float* rowscale, float* part, int groups, int pix_per_group, int HW,
                    int C, int mode, int act, const float* gate, const float* dsv, hipStream_t s)
 {
-    hipLaunchKernelGGL(chan_reduce_kernel, dim3(bn_bwd_blocks(pix_per_group), groups), dim3(256), 0, s, a, y, mean,
-                       istd, scale, shift, rowscale, part, pix_per_group, HW, C, mode, act, gate, dsv);
+    const dim3 grid(bn_bwd_blocks(pix_per_group), groups);
+    if (ty == DT_F32 && ta == DT_F32)
+        hipLaunchKernelGGL((chan_reduce_kernel<float, float>), grid, dim3(256), 0, s, cp<float>(a), cp<float>(y), mean, istd,
+                           scale, shift, rowscale, part, pix_per_group, HW, C, mode, act, gate, dsv);
+    else if (ty == DT_F32)
+        hipLaunchKernelGGL((chan_reduce_kernel<float, bf16>), grid, dim3(256), 0, s, cp<bf16>(a), cp<float>(y), mean, istd,
+                           scale, shift, rowscale, part, pix_per_group, HW, C, mode, act, gate, dsv);
+    else
+        hipLaunchKernelGGL((chan_reduce_kernel<bf16, bf16>), grid, dim3(256), 0, s, cp<bf16>(a), cp<bf16>(y), mean, istd,
+                           scale, shift, rowscale, part, pix_per_group, HW, C, mode, act, gate, dsv);
 }
 
 // dy = ca*dyh + cb*y + cc with dyh = dz * act'(v) * rowscale
-__global__ void bnact_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+template <typename TY, typename TA>
+__global__ void bnact_bwd_apply_kernel(const TA* __restrict__ dz, const TY* __restrict__ y,
                                        const float* __restrict__ ca, const float* __restrict__ cb,
                                        const float* __restrict__ cc, const float* __restrict__ scale,
                                        const float* __restrict__ shift, const float* __restrict__ rowscale,
-                                       float* __restrict__ dy, int pix_per_group, int HW, int C, int act,
+                                       TY* __restrict__ dy, int pix_per_group, int HW, int C, int act,
                                        const float* __restrict__ gate, const float* __restrict__ dsv)
 {
     const int g = blockIdx.y;
@@ -157,38 +181,47 @@ __global__ void bnact_bwd_apply_kernel(const float* __restrict__ dz, const float
         const int cq = (int)(i % Q);
         const int64_t pix = i / Q;
         const size_t o = base + (size_t)i * 4;
-        f32x4 d = *reinterpret_cast<const f32x4*>(dz + o);
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+        f32x4 d = ld4(dz + o);
+        const f32x4 yy = ld4(y + o);
         if (gate) {
             const size_t io = ((size_t)g * (pix_per_group / HW) + pix / HW) * C + cq * 4;
-            d = d * *reinterpret_cast<const f32x4*>(gate + io) + *reinterpret_cast<const f32x4*>(dsv + io) * (1.f / (float)HW);
+            d = d * ld4(gate + io) + ld4(dsv + io) * (1.f / (float)HW);
         }
         if (act == 2) {
-            const f32x4 v = yy * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
-                            *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+            const f32x4 v = yy * ld4(scale + g * C + cq * 4) +
+                            ld4(shift + g * C + cq * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] *= swish_grad(v[k]);
         }
         if (rowscale) d = d * rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
-        *reinterpret_cast<f32x4*>(dy + o) = *reinterpret_cast<const f32x4*>(ca + g * C + cq * 4) * d +
-                                            *reinterpret_cast<const f32x4*>(cb + g * C + cq * 4) * yy +
-                                            *reinterpret_cast<const f32x4*>(cc + g * C + cq * 4);
+        st4(dy + o, ld4(ca + g * C + cq * 4) * d +
+                                            ld4(cb + g * C + cq * 4) * yy +
+                                            ld4(cc + g * C + cq * 4));
     }
 }
-void k_bnact_bwd_apply(const float* dz, const float* y, const float* ca, const float* cb, const float* cc,
-                       const float* scale, const float* shift, const float* rowscale, float* dy, int groups,
+// dz is stored as the activations are (ta), y and the result dy as the raw conv output is (ty)
+void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const float* ca, const float* cb, const float* cc,
+                       const float* scale, const float* shift, const float* rowscale, void* dy, int groups,
                        int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s)
 {
     const int64_t n4 = (int64_t)pix_per_group * (C / 4);
-    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(cdiv(n4, 256), groups), dim3(256), 0, s, dz, y,
-                       ca, cb, cc, scale, shift, rowscale, dy, pix_per_group, HW, C, act, gate, dsv);
+    const dim3 grid(cdiv(n4, 256), groups);
+    if (ty == DT_F32 && ta == DT_F32)
+        hipLaunchKernelGGL((bnact_bwd_apply_kernel<float, float>), grid, dim3(256), 0, s, cp<float>(dz), cp<float>(y), ca, cb, cc,
+                           scale, shift, rowscale, mp<float>(dy), pix_per_group, HW, C, act, gate, dsv);
+    else if (ty == DT_F32)
+        hipLaunchKernelGGL((bnact_bwd_apply_kernel<float, bf16>), grid, dim3(256), 0, s, cp<bf16>(dz), cp<float>(y), ca, cb, cc,
+                           scale, shift, rowscale, mp<float>(dy), pix_per_group, HW, C, act, gate, dsv);
+    else
+        hipLaunchKernelGGL((bnact_bwd_apply_kernel<bf16, bf16>), grid, dim3(256), 0, s, cp<bf16>(dz), cp<bf16>(y), ca, cb, cc,
+                           scale, shift, rowscale, mp<bf16>(dy), pix_per_group, HW, C, act, gate, dsv);
 }
 
 // ------------------------------------------------------------ depthwise conv ---
 // x [imgs][Hi][Wi][C], w [K*K][C], y [imgs][Ho][Wo][C]; pad_t/pad_l = TF-same top/left padding.
 // Optional fused eval epilogue: y = act(y*scale+shift).
-template <int K>
-__global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+template <int K, typename T>
+__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                               const float* __restrict__ scale, const float* __restrict__ shift, int imgs, int Hi,
                               int Wi, int Ho, int Wo, int C, int stride, int pad_t, int pad_l, int act)
 {
@@ -210,23 +243,23 @@ __global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restri
         for (int kw = 0; kw < K; ++kw) {
             const int iw = ow * stride + kw - pad_l;
             if ((unsigned)iw >= (unsigned)Wi) continue;
-            acc += *reinterpret_cast<const f32x4*>(x + ((size_t)(img * Hi + ih) * Wi + iw) * C + cq * 4) *
-                   *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+            acc += ld4(x + ((size_t)(img * Hi + ih) * Wi + iw) * C + cq * 4) *
+                   ld4(w + (kh * K + kw) * C + cq * 4);
         }
     }
     if (scale) {
-        acc = acc * *reinterpret_cast<const f32x4*>(scale + cq * 4) + *reinterpret_cast<const f32x4*>(shift + cq * 4);
+        acc = acc * ld4(scale + cq * 4) + ld4(shift + cq * 4);
         acc = act_fwd(acc, act);
     }
-    *reinterpret_cast<f32x4*>(y + i * 4) = acc;
+    st4(y + i * 4, acc);
 }
 // Register-blocked forms (the ones that run for EfficientNet-B0's shapes): one thread computes 4
 // consecutive output columns of one channel quad, so a K-wide row of taps costs 3*S+K loads
 // instead of 4*K.  Compile-time TF-"same" padding of an even input: (K-1)/2 at stride 1,
 // (K-2)/2 at stride 2; other paddings take the generic kernels above.
-template <int K, int S>
-__global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ y, const float* __restrict__ scale,
+template <int K, int S, typename T>
+__global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         T* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int imgs, int Hi, int Wi,
                                                          int Ho, int Wo, int C, int act)
 {
@@ -249,16 +282,16 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const float* __restrict
     for (int kh = 0; kh < K; ++kh) {
         const int ih = oh * S + kh - PT;
         if ((unsigned)ih >= (unsigned)Hi) continue;
-        const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+        const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
         f32x4 xin[NIN], wr[K];
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
             const int iw = iw0 + j;
-            xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+            xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) wr[kw] = *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+        for (int kw = 0; kw < K; ++kw) wr[kw] = ld4(w + (kh * K + kw) * C + cq * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -266,24 +299,24 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const float* __restrict
     }
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) {
-        sc = *reinterpret_cast<const f32x4*>(scale + cq * 4);
-        sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+        sc = ld4(scale + cq * 4);
+        sh = ld4(shift + cq * 4);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (ow0 + j >= Wo) continue;
         f32x4 v = acc[j];
         if (scale) v = act_fwd(v * sc + sh, act);
-        *reinterpret_cast<f32x4*>(y + ((size_t)(img * Ho + oh) * Wo + ow0 + j) * C + cq * 4) = v;
+        st4(y + ((size_t)(img * Ho + oh) * Wo + ow0 + j) * C + cq * 4, v);
     }
 }
 // stride-1 forward, 2 output rows x 4 columns per thread: K+1 input rows serve both output rows (each row of
 // taps is loaded once and used with kernel row ir for the upper output row and ir-1 for the lower one), so a
 // 5x5 costs 6 loads per output instead of 10 and its weights are read once per 8 outputs -- the 5x5 layers are
 // bound by L1 bandwidth (16 float4 of L1 traffic per float4 of output in the one-row form).
-template <int K>
-__global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, const float* __restrict__ scale,
+template <int K, typename T>
+__global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          T* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int imgs, int Hi, int Wi,
                                                           int Ho, int Wo, int C, int act, int flip)
 {
@@ -314,17 +347,17 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const float* __restric
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
                 const int wi = flip ? K * K - 1 - (ir * K + kw) : ir * K + kw;
-                wcur[kw] = *reinterpret_cast<const f32x4*>(w + wi * C + cq * 4);
+                wcur[kw] = ld4(w + wi * C + cq * 4);
             }
         }
         const int ih = oh0 + ir - PT;
         if ((unsigned)ih < (unsigned)Hi) {
-            const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
             f32x4 xin[NIN];
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int iw = iw0 + j;
-                xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (ir < K) {
@@ -345,8 +378,8 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const float* __restric
     }
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) {
-        sc = *reinterpret_cast<const f32x4*>(scale + cq * 4);
-        sh = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+        sc = ld4(scale + cq * 4);
+        sh = ld4(shift + cq * 4);
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -356,7 +389,7 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const float* __restric
             if (ow0 + j >= Wo) continue;
             f32x4 v = acc[r][j];
             if (scale) v = act_fwd(v * sc + sh, act);
-            *reinterpret_cast<f32x4*>(y + ((size_t)(img * Ho + oh0 + r) * Wo + ow0 + j) * C + cq * 4) = v;
+            st4(y + ((size_t)(img * Ho + oh0 + r) * Wo + ow0 + j) * C + cq * 4, v);
         }
     }
 }
@@ -366,45 +399,40 @@ static inline bool dw_blk_ok(int K, int S, int Hi, int Wi, int pad_t, int pad_l)
     const int pt = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
     return (K == 3 || K == 5) && (S == 1 || S == 2) && pad_t == pt && pad_l == pt && !getenv("FM_DW_GENERIC");
 }
-#define DW_DISPATCH(KERN, ...)                                                              \
-    do {                                                                                    \
-        if (K == 3 && stride == 1) hipLaunchKernelGGL((KERN<3, 1>), __VA_ARGS__);           \
-        else if (K == 3) hipLaunchKernelGGL((KERN<3, 2>), __VA_ARGS__);                     \
-        else if (stride == 1) hipLaunchKernelGGL((KERN<5, 1>), __VA_ARGS__);                \
-        else hipLaunchKernelGGL((KERN<5, 2>), __VA_ARGS__);                                 \
-    } while (0)
-
-void k_dw_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift, int imgs, int Hi,
-              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
+template <typename T>
+static void dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
+                     int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    const dim3 blk(256);
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const int64_t nb = (int64_t)imgs * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 4);
-        if (K == 3)
-            hipLaunchKernelGGL(dw_fwd_blk2_kernel<3>, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi,
-                               Wi, Ho, Wo, C, act, 0);
-        else
-            hipLaunchKernelGGL(dw_fwd_blk2_kernel<5>, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi,
-                               Wi, Ho, Wo, C, act, 0);
+        const dim3 grid(cdiv((int64_t)imgs * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 4), 256));
+        if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
+        else hipLaunchKernelGGL((dw_fwd_blk2_kernel<5, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
         return;
     }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const int64_t nb = (int64_t)imgs * Ho * ((Wo + 3) / 4) * (C / 4);
-        DW_DISPATCH(dw_fwd_blk_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo,
-                    C, act);
+        const dim3 grid(cdiv((int64_t)imgs * Ho * ((Wo + 3) / 4) * (C / 4), 256));
+        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_blk_kernel<3, 1, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
+        else if (K == 3) hipLaunchKernelGGL((dw_fwd_blk_kernel<3, 2, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
+        else if (stride == 1) hipLaunchKernelGGL((dw_fwd_blk_kernel<5, 1, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
+        else hipLaunchKernelGGL((dw_fwd_blk_kernel<5, 2, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
         return;
     }
-    const int64_t n = (int64_t)imgs * Ho * Wo * (C / 4);
-    if (K == 3)
-        hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi,
-                           Ho, Wo, C, stride, pad_t, pad_l, act);
-    else
-        hipLaunchKernelGGL(dw_fwd_kernel<5>, dim3(cdiv(n, 256)), dim3(256), 0, s, x, w, y, scale, shift, imgs, Hi, Wi,
-                           Ho, Wo, C, stride, pad_t, pad_l, act);
+    const dim3 grid(cdiv((int64_t)imgs * Ho * Wo * (C / 4), 256));
+    if (K == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, act);
+    else hipLaunchKernelGGL((dw_fwd_kernel<5, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, act);
+}
+// dt: storage type of x and y (DT_F32 / DT_BF16); weights and the BN affine are fp32
+void k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
+              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
+{
+    if (dt == DT_F32) dw_fwd_t(cp<float>(x), w, mp<float>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s);
+    else dw_fwd_t(cp<bf16>(x), w, mp<bf16>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s);
 }
 
-template <int K>
-__global__ void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+template <int K, typename T>
+__global__ void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
                                 int imgs, int Hi, int Wi, int Ho, int Wo, int C, int stride, int pad_t, int pad_l)
 {
     const int Q = C >> 2;
@@ -429,18 +457,18 @@ __global__ void dw_dgrad_kernel(const float* __restrict__ dy, const float* __res
             if (b < 0 || b % stride) continue;
             const int ow = b / stride;
             if (ow >= Wo) continue;
-            acc += *reinterpret_cast<const f32x4*>(dy + ((size_t)(img * Ho + oh) * Wo + ow) * C + cq * 4) *
-                   *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+            acc += ld4(dy + ((size_t)(img * Ho + oh) * Wo + ow) * C + cq * 4) *
+                   ld4(w + (kh * K + kw) * C + cq * 4);
         }
     }
-    *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+    st4(dx + i * 4, acc);
 }
 // dgrad, register-blocked: 4 consecutive input columns per thread.  For input column iw0+j and tap
 // kw the output column is (iw0 + j + PT - kw)/S when that is an exact division; iw0 is a multiple
 // of 4, so which (j, kw) pairs are exact and their column offsets are compile-time.
-template <int K, int S>
-__global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                           float* __restrict__ dx, int imgs, int Hi, int Wi, int Ho,
+template <int K, int S, typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                           T* __restrict__ dx, int imgs, int Hi, int Wi, int Ho,
                                                            int Wo, int C)
 {
     constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
@@ -466,16 +494,16 @@ __global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const float* __restri
         if (a < 0 || (a % S) != 0) continue;
         const int oh = a / S;
         if (oh >= Ho) continue;
-        const float* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
+        const T* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
         f32x4 din[NC], wr[K];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int ow = cbase + c;
-            din[c] = (unsigned)ow < (unsigned)Wo ? *reinterpret_cast<const f32x4*>(dr + (size_t)ow * C)
+            din[c] = (unsigned)ow < (unsigned)Wo ? ld4(dr + (size_t)ow * C)
                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) wr[kw] = *reinterpret_cast<const f32x4*>(w + (kh * K + kw) * C + cq * 4);
+        for (int kw = 0; kw < K; ++kw) wr[kw] = ld4(w + (kh * K + kw) * C + cq * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -488,44 +516,48 @@ __global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (iw0 + j < Wi)
-            *reinterpret_cast<f32x4*>(dx + ((size_t)(img * Hi + ih) * Wi + iw0 + j) * C + cq * 4) = acc[j];
+            st4(dx + ((size_t)(img * Hi + ih) * Wi + iw0 + j) * C + cq * 4, acc[j]);
 }
 
-void k_dw_dgrad(const float* dy, const float* w, float* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
-                int stride, int pad_t, int pad_l, hipStream_t s)
+template <typename T>
+static void dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                       int stride, int pad_t, int pad_l, hipStream_t s)
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    const dim3 blk(256);
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         // stride 1: dx = dy (*) rot180(w), the forward kernel with the rotated kernel (Hi == Ho, Wi == Wo)
-        const int64_t nb = (int64_t)imgs * ((Hi + 1) / 2) * ((Wi + 3) / 4) * (C / 4);
-        if (K == 3)
-            hipLaunchKernelGGL(dw_fwd_blk2_kernel<3>, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, nullptr, nullptr, imgs,
-                               Ho, Wo, Hi, Wi, C, 0, 1);
-        else
-            hipLaunchKernelGGL(dw_fwd_blk2_kernel<5>, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, nullptr, nullptr, imgs,
-                               Ho, Wo, Hi, Wi, C, 0, 1);
+        const dim3 grid(cdiv((int64_t)imgs * ((Hi + 1) / 2) * ((Wi + 3) / 4) * (C / 4), 256));
+        const float* nul = nullptr;
+        if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, dy, w, dx, nul, nul, imgs, Ho, Wo, Hi, Wi, C, 0, 1);
+        else hipLaunchKernelGGL((dw_fwd_blk2_kernel<5, T>), grid, blk, 0, s, dy, w, dx, nul, nul, imgs, Ho, Wo, Hi, Wi, C, 0, 1);
         return;
     }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const int64_t nb = (int64_t)imgs * Hi * ((Wi + 3) / 4) * (C / 4);
-        DW_DISPATCH(dw_dgrad_blk_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
+        const dim3 grid(cdiv((int64_t)imgs * Hi * ((Wi + 3) / 4) * (C / 4), 256));
+        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_dgrad_blk_kernel<3, 1, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
+        else if (K == 3) hipLaunchKernelGGL((dw_dgrad_blk_kernel<3, 2, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
+        else if (stride == 1) hipLaunchKernelGGL((dw_dgrad_blk_kernel<5, 1, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
+        else hipLaunchKernelGGL((dw_dgrad_blk_kernel<5, 2, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
         return;
     }
-    const int64_t n = (int64_t)imgs * Hi * Wi * (C / 4);
-    if (K == 3)
-        hipLaunchKernelGGL(dw_dgrad_kernel<3>, dim3(cdiv(n, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C,
-                           stride, pad_t, pad_l);
-    else
-        hipLaunchKernelGGL(dw_dgrad_kernel<5>, dim3(cdiv(n, 256)), dim3(256), 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C,
-                           stride, pad_t, pad_l);
+    const dim3 grid(cdiv((int64_t)imgs * Hi * Wi * (C / 4), 256));
+    if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l);
+    else hipLaunchKernelGGL((dw_dgrad_kernel<5, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l);
+}
+void k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                int stride, int pad_t, int pad_l, hipStream_t s)
+{
+    if (dt == DT_F32) dw_dgrad_t(cp<float>(dy), w, mp<float>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
+    else dw_dgrad_t(cp<bf16>(dy), w, mp<bf16>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
 }
 
 // dw[kh][kw][c] = sum over output pixels of dy * x(shifted).  Thread = (channel quad, pixel lane):
 // QT quads x P lanes per block (QT*P <= 256 threads, see dw_map), each block owns a chunk of output
 // pixels; K*K float4 accumulators per thread, folded over the pixel lanes through LDS; partial
 // [nblk][K*K][C], summed later in a fixed order (reduce_slabs) -> run-to-run deterministic.
-template <int K>
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int K, typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                        float* __restrict__ part, int imgs, int Hi, int Wi, int Ho,
                                                        int Wo, int C, int stride, int pad_t, int pad_l, int QT, int P)
 {
@@ -541,8 +573,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         const int img = p / (Ho * Wo);
         const int rem = p - img * Ho * Wo;
         const int oh = rem / Wo, ow = rem - oh * Wo;
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)p * C + cq * 4);
-        const float* xi = x + (size_t)img * Hi * Wi * C + cq * 4;
+        const f32x4 d = ld4(dy + (size_t)p * C + cq * 4);
+        const T* xi = x + (size_t)img * Hi * Wi * C + cq * 4;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
             const int ih = oh * stride + kh - pad_t;
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
             for (int kw = 0; kw < K; ++kw) {
                 const int iw = ow * stride + kw - pad_l;
                 if ((unsigned)iw >= (unsigned)Wi) continue;
-                acc[kh * K + kw] += d * *reinterpret_cast<const f32x4*>(xi + (size_t)(ih * Wi + iw) * C);
+                acc[kh * K + kw] += d * ld4(xi + (size_t)(ih * Wi + iw) * C);
             }
         }
     }
@@ -563,13 +595,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         if (pl == 0) {
             f32x4 v = red[threadIdx.x];
             for (int k = 1; k < P; ++k) v += red[k * QT + threadIdx.x];
-            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
+            st4(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4, v);
         }
     }
 }
 // wgrad, register-blocked: the pixel loop walks blocks of 4 consecutive output columns
-template <int K, int S>
-__global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int K, int S, typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            float* __restrict__ part, int imgs, int Hi, int Wi,
                                                            int Ho, int Wo, int C, int QT, int P)
 {
@@ -588,22 +620,22 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const float* __restri
         const int img = p / (Ho * WB);
         const int rem = p - img * Ho * WB;
         const int oh = rem / WB, ow0 = (rem - oh * WB) * 4;
-        const float* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
+        const T* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
         f32x4 d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            d[j] = ow0 + j < Wo ? *reinterpret_cast<const f32x4*>(dr + (size_t)(ow0 + j) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[j] = ow0 + j < Wo ? ld4(dr + (size_t)(ow0 + j) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
         const int iw0 = ow0 * S - PT;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
             const int ih = oh * S + kh - PT;
             if ((unsigned)ih >= (unsigned)Hi) continue;
-            const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
             f32x4 xin[NIN];
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int iw = iw0 + j;
-                xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -620,13 +652,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const float* __restri
         if (pl == 0) {
             f32x4 v = red[threadIdx.x];
             for (int k = 1; k < P; ++k) v += red[k * QT + threadIdx.x];
-            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
+            st4(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4, v);
         }
     }
 }
 // stride-1 wgrad, pixel blocks of 2 output rows x 4 columns: K+1 input rows serve both rows of dy
-template <int K>
-__global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int K, typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             float* __restrict__ part, int imgs, int Hi, int Wi,
                                                             int Ho, int Wo, int C, int QT, int P)
 {
@@ -648,10 +680,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const float* __restr
         f32x4 d[2][4];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const float* dr = dy + ((size_t)(img * Ho + min(oh0 + r, Ho - 1)) * Wo) * C + cq * 4;
+            const T* dr = dy + ((size_t)(img * Ho + min(oh0 + r, Ho - 1)) * Wo) * C + cq * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                d[r][j] = (oh0 + r < Ho && ow0 + j < Wo) ? *reinterpret_cast<const f32x4*>(dr + (size_t)(ow0 + j) * C)
+                d[r][j] = (oh0 + r < Ho && ow0 + j < Wo) ? ld4(dr + (size_t)(ow0 + j) * C)
                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int iw0 = ow0 - PT;
@@ -659,12 +691,12 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const float* __restr
         for (int ir = 0; ir <= K; ++ir) {
             const int ih = oh0 + ir - PT;
             if ((unsigned)ih >= (unsigned)Hi) continue;
-            const float* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
             f32x4 xin[NIN];
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int iw = iw0 + j;
-                xin[j] = (unsigned)iw < (unsigned)Wi ? *reinterpret_cast<const f32x4*>(xr + (size_t)iw * C)
+                xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (ir < K) {                     // kernel row ir against the upper dy row
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const float* __restr
         if (pl == 0) {
             f32x4 v = red[threadIdx.x];
             for (int k = 1; k < P; ++k) v += red[k * QT + threadIdx.x];
-            *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4) = v;
+            st4(part + ((size_t)blockIdx.x * K * K + t) * C + cq * 4, v);
         }
     }
 }
@@ -703,36 +735,41 @@ static inline void dw_map(int C, int& QT, int& P, int& ytiles)
     P = std::max(1, 256 / QT);
 }
 int dw_wgrad_blocks(int npix) { return std::max(1, std::min(2048, npix / 128)); }
-void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
-                int stride, int pad_t, int pad_l, hipStream_t s)
+template <typename T>
+static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                       int stride, int pad_t, int pad_l, hipStream_t s)
 {
     int QT, P, yt;
     dw_map(C, QT, P, yt);
-    dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt);
+    const dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt), blk(QT * P);
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        if (K == 3)
-            hipLaunchKernelGGL(dw_wgrad_blk2_kernel<3>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
-        else
-            hipLaunchKernelGGL(dw_wgrad_blk2_kernel<5>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        if (K == 3) hipLaunchKernelGGL((dw_wgrad_blk2_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        else hipLaunchKernelGGL((dw_wgrad_blk2_kernel<5, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
         return;
     }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        DW_DISPATCH(dw_wgrad_blk_kernel, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_blk_kernel<3, 1, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        else if (K == 3) hipLaunchKernelGGL((dw_wgrad_blk_kernel<3, 2, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_blk_kernel<5, 1, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+        else hipLaunchKernelGGL((dw_wgrad_blk_kernel<5, 2, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
         return;
     }
-    if (K == 3)
-        hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride,
-                           pad_t, pad_l, QT, P);
-    else
-        hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(QT * P), 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride,
-                           pad_t, pad_l, QT, P);
+    if (K == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, QT, P);
+    else hipLaunchKernelGGL((dw_wgrad_kernel<5, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, QT, P);
+}
+void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                int stride, int pad_t, int pad_l, hipStream_t s)
+{
+    if (dt == DT_F32) dw_wgrad_t(cp<float>(dy), cp<float>(x), part, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
+    else dw_wgrad_t(cp<bf16>(dy), cp<bf16>(x), part, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
 }
 
 // per-image channel sums over a chunk of pixels: part[img][chunk][C] = sum_p a[p][c] (* b[p][c]).
 // `tsel` 1 / 2: operand a / b is a raw BN input and is read as swish(v*scale[g]+shift[g]), g = img/ipg
 // (the post-BN activation is never materialised).
-__global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename T>
+__global__ __launch_bounds__(256) void chan_pool_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         float* __restrict__ part, int HW, int C, int QT, int P,
                                                         int tsel, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int ipg)
@@ -748,16 +785,16 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (tsel) {
-            sc = *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4);
-            sh = *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4);
+            sc = ld4(scale + g * C + cq * 4);
+            sh = ld4(shift + g * C + cq * 4);
         }
 #pragma unroll 4
         for (int p = pb + pl; p < pe; p += P) {
             const size_t o = ((size_t)img * HW + p) * C + cq * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
+            f32x4 v = ld4(a + o);
             if (tsel == 1) v = act_fwd(v * sc + sh, 2);
             if (b) {
-                f32x4 w = *reinterpret_cast<const f32x4*>(b + o);
+                f32x4 w = ld4(b + o);
                 if (tsel == 2) w = act_fwd(w * sc + sh, 2);
                 v = v * w;
             }
@@ -768,18 +805,21 @@ __global__ __launch_bounds__(256) void chan_pool_kernel(const float* __restrict_
         __syncthreads();
         if (pl == 0) {
             for (int k = 1; k < P; ++k) s1 += red[k * QT + cq0];
-            *reinterpret_cast<f32x4*>(part + ((size_t)img * nch + blockIdx.x) * C + cq * 4) = s1;
+            st4(part + ((size_t)img * nch + blockIdx.x) * C + cq * 4, s1);
         }
     }
 }
 int chan_pool_chunks(int HW) { return std::max(1, std::min(16, HW / 64)); }
-void k_chan_pool(const float* a, const float* b, float* part, int imgs, int HW, int C, int tsel, const float* scale,
+void k_chan_pool(const void* a, const void* b, int dt, float* part, int imgs, int HW, int C, int tsel, const float* scale,
                  const float* shift, int ipg, hipStream_t s)
 {
     int QT, P, yt;
     dw_map(C, QT, P, yt);
-    hipLaunchKernelGGL(chan_pool_kernel, dim3(chan_pool_chunks(HW), imgs), dim3(QT * P), 0, s, a, b, part, HW, C, QT, P,
-                       tsel, scale, shift, ipg);
+    const dim3 grid(chan_pool_chunks(HW), imgs), blk(QT * P);
+    if (dt == DT_F32)
+        hipLaunchKernelGGL((chan_pool_kernel<float>), grid, blk, 0, s, cp<float>(a), cp<float>(b), part, HW, C, QT, P, tsel, scale, shift, ipg);
+    else
+        hipLaunchKernelGGL((chan_pool_kernel<bf16>), grid, blk, 0, s, cp<bf16>(a), cp<bf16>(b), part, HW, C, QT, P, tsel, scale, shift, ipg);
 }
 
 // ------------------------------------------------------------ squeeze-excite ---
@@ -821,17 +861,18 @@ __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const flo
         gate[(size_t)img * C + c] = sigm(t);
     }
 }
-void k_se_fwd(const float* a, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
+void k_se_fwd(const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
               const float* b1, const float* W2, const float* b2, float* sq, float* rpre, float* gate, int imgs, int HW,
               int C, int Cs, hipStream_t s)
 {
-    k_chan_pool(a, nullptr, pool_ws, imgs, HW, C, scale ? 1 : 0, scale, shift, ipg, s);
+    k_chan_pool(a, nullptr, dt, pool_ws, imgs, HW, C, scale ? 1 : 0, scale, shift, ipg, s);
     hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
                        W1, b1, W2, b2, sq, rpre, gate, HW, C, Cs);
 }
 
 // out = A * gate[img][c], A = a or (scale != null) swish(a*scale[g]+shift[g]) with g = img/ipg
-__global__ void se_scale_kernel(const float* __restrict__ a, const float* __restrict__ gate, float* __restrict__ out,
+template <typename T>
+__global__ void se_scale_kernel(const T* __restrict__ a, const float* __restrict__ gate, T* __restrict__ out,
                                 int64_t n4, int HW, int C, const float* __restrict__ scale,
                                 const float* __restrict__ shift, int ipg)
 {
@@ -840,21 +881,24 @@ __global__ void se_scale_kernel(const float* __restrict__ a, const float* __rest
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const int cq = (int)(i % Q);
         const int64_t img = i / Q / HW;
-        f32x4 v = *reinterpret_cast<const f32x4*>(a + i * 4);
+        f32x4 v = ld4(a + i * 4);
         if (scale) {
             const int g = (int)(img / ipg);
-            v = act_fwd(v * *reinterpret_cast<const f32x4*>(scale + g * C + cq * 4) +
-                            *reinterpret_cast<const f32x4*>(shift + g * C + cq * 4), 2);
+            v = act_fwd(v * ld4(scale + g * C + cq * 4) +
+                            ld4(shift + g * C + cq * 4), 2);
         }
-        *reinterpret_cast<f32x4*>(out + i * 4) = v * *reinterpret_cast<const f32x4*>(gate + img * C + cq * 4);
+        st4(out + i * 4, v * ld4(gate + img * C + cq * 4));
     }
 }
-void k_se_scale(const float* a, const float* scale, const float* shift, int ipg, const float* gate, float* out, int imgs,
+void k_se_scale(const void* a, int dt, const float* scale, const float* shift, int ipg, const float* gate, void* out, int imgs,
                 int HW, int C, hipStream_t s)
 {
     const int64_t n4 = (int64_t)imgs * HW * (C / 4);
-    hipLaunchKernelGGL(se_scale_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, s, a, gate, out, n4, HW, C,
-                       scale, shift, ipg);
+    const dim3 grid(cdiv(n4, 256));
+    if (dt == DT_F32)
+        hipLaunchKernelGGL((se_scale_kernel<float>), grid, dim3(256), 0, s, cp<float>(a), gate, mp<float>(out), n4, HW, C, scale, shift, ipg);
+    else
+        hipLaunchKernelGGL((se_scale_kernel<bf16>), grid, dim3(256), 0, s, cp<bf16>(a), gate, mp<bf16>(out), n4, HW, C, scale, shift, ipg);
 }
 
 // backward, one block per image:  dgs[c] = sum_hw dout*a ; dgp = dgs*g(1-g) ; dr = W2^T dgp ;
@@ -895,11 +939,11 @@ __global__ void se_bwd_kernel(const float* __restrict__ pool, int nch,
         ds[(size_t)img * C + c] = t;
     }
 }
-void k_se_bwd(const float* dout, const float* a, const float* scale, const float* shift, int ipg, float* pool_ws,
+void k_se_bwd(const void* dout, const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws,
               const float* gate, const float* rpre, const float* W1, const float* W2, float* dgp, float* drp, float* ds,
               int imgs, int HW, int C, int Cs, hipStream_t s)
 {
-    k_chan_pool(dout, a, pool_ws, imgs, HW, C, scale ? 2 : 0, scale, shift, ipg, s);
+    k_chan_pool(dout, a, dt, pool_ws, imgs, HW, C, scale ? 2 : 0, scale, shift, ipg, s);
     hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
                        gate, rpre, W1, W2, dgp, drp, ds, HW, C, Cs);
 }
@@ -952,13 +996,15 @@ void k_mul(const float* a, const float* b, float* y, int64_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(mul_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, y, n);
 }
-__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ a, int64_t n4)
+template <typename T>
+__global__ void add_inplace_kernel(T* __restrict__ y, const T* __restrict__ a, int64_t n4)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
-        reinterpret_cast<f32x4*>(y)[i] += reinterpret_cast<const f32x4*>(a)[i];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) st4(y + 4 * i, ld4(y + 4 * i) + ld4(a + 4 * i));
 }
-void k_add_inplace(float* y, const float* a, int64_t n, hipStream_t s)
+void k_add_inplace(void* y, const void* a, int dt, int64_t n, hipStream_t s)
 {
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, y, a, n / 4);
+    const dim3 grid(cdiv(n / 4, 256));
+    if (dt == DT_F32) hipLaunchKernelGGL((add_inplace_kernel<float>), grid, dim3(256), 0, s, mp<float>(y), cp<float>(a), n / 4);
+    else hipLaunchKernelGGL((add_inplace_kernel<bf16>), grid, dim3(256), 0, s, mp<bf16>(y), cp<bf16>(a), n / 4);
 }

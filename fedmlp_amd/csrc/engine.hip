@@ -1228,8 +1228,8 @@ int fm_fedavg_tao(fm_engine* e, const double* t_host, double n_i, const float* n
     const int C = e->C;
     std::vector<double> h(2 * C);
     for (int c = 0; c < C; ++c) {
-        const double m = negative_mask_host[c] != 0.f ? 1.0 : 0.0;
-        h[c] = t_host[c] * n_i * m;
+        const double m = (double)negative_mask_host[c];      // 0/1 for one client; a weight when a rank folds several
+        h[c] = m != 0.0 ? t_host[c] * n_i * m : 0.0;
         h[C + c] = n_i * m;
     }
     if (e->comm) {
@@ -1249,9 +1249,9 @@ int fm_fedavg_proto(fm_engine* e, const float* proto_host, double n_i, const flo
     const size_t np = (size_t)2 * C * D;
     std::vector<float> h(np + 2 * C);
     for (int r = 0; r < 2 * C; ++r) {
-        const bool m = active_mask_host[r / 2] != 0.f;
-        for (int d = 0; d < D; ++d) h[(size_t)r * D + d] = m ? proto_host[(size_t)r * D + d] * (float)n_i : 0.f;
-        h[np + r] = m ? (float)n_i : 0.f;
+        const float wr = (float)(n_i * (double)active_mask_host[r / 2]);   // mask 0/1, or a per-class weight
+        for (int d = 0; d < D; ++d) h[(size_t)r * D + d] = wr != 0.f ? proto_host[(size_t)r * D + d] * wr : 0.f;
+        h[np + r] = wr;
     }
     if (e->comm) {
         float* buf = reinterpret_cast<float*>(e->comm_buf);
@@ -1426,9 +1426,10 @@ int fm_cos_tag(fm_engine* e, const float* feat_dev, int64_t N, const float* prot
 int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_thr, double noise_thr, int32_t cap,
                    int32_t* top_host, int32_t* n_top, int32_t* bot_host, int32_t* n_bot)
 {
-    ARGCHK(e && sim_dev && top_host && n_top && bot_host && n_bot, "null");
+    ARGCHK(e && top_host && n_top && bot_host && n_bot, "null");
     *n_top = *n_bot = 0;
-    if (N == 0) return FM_OK;
+    if (N == 0) return FM_OK;              // an empty pool selects nothing (sim_dev may be NULL then)
+    ARGCHK(sim_dev, "null sim_dev");
     int counts[2];
     k_count_sign(sim_dev, N, e->sel_counts, e->st);
     HIPCHK(hipMemcpyAsync(counts, e->sel_counts, 8, hipMemcpyDeviceToHost, e->st));
@@ -1571,6 +1572,22 @@ int fm_debug_get_grads(fm_engine* e, float* host_f32)
 }
 
 int fm_debug_num_convs(fm_engine* e) { return e ? (int)e->convs.size() : 0; }
+
+int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs, float* host_nhwc, int32_t* dims4)
+{
+    ARGCHK(e && dims4 && e->model == 0, "ResNet-18 engine only");
+    ARGCHK(block >= 0 && block < (int)e->blocks.size() && (kind == 0 || kind == 1), "kind/block");
+    ARGCHK(imgs >= 1 && imgs <= e->maxB, "imgs");
+    const Block& b = e->blocks[block];
+    const Conv& c = e->convs[b.c1];
+    dims4[0] = imgs; dims4[1] = c.hout; dims4[2] = c.wout; dims4[3] = c.cout;
+    if (host_nhwc) {
+        HIPCHK(hipMemcpyAsync(host_nhwc, kind == 0 ? b.z1 : b.out, (size_t)imgs * c.hout * c.wout * c.cout * 4,
+                              hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipStreamSynchronize(e->st));
+    }
+    return FM_OK;
+}
 
 int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info16)
 {

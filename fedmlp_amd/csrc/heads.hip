@@ -38,18 +38,22 @@ __device__ __forceinline__ float block_sum(float v, float* sh /*[4]*/)
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
 // ------------------------------------------------------------ avgpool / fc -----
-__global__ void avgpool_kernel(const float* __restrict__ x, float* __restrict__ feat, int HW, int C)
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ feat, int HW, int C)
 {
     const int img = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += x[((size_t)img * HW + p) * C + c];
+        for (int p = 0; p < HW; ++p) s += (float)x[((size_t)img * HW + p) * C + c];
         feat[(size_t)img * C + c] = s / (float)HW;
     }
 }
-void k_avgpool(const float* x, float* feat, int imgs, int HW, int C, hipStream_t s)
+void k_avgpool(const void* x, int dt, float* feat, int imgs, int HW, int C, hipStream_t s)
 {
-    hipLaunchKernelGGL(avgpool_kernel, dim3(imgs), dim3(256), 0, s, x, feat, HW, C);
+    if (dt == DT_F32)
+        hipLaunchKernelGGL(avgpool_kernel<float>, dim3(imgs), dim3(256), 0, s, reinterpret_cast<const float*>(x), feat, HW, C);
+    else
+        hipLaunchKernelGGL(avgpool_kernel<bf16>, dim3(imgs), dim3(256), 0, s, reinterpret_cast<const bf16*>(x), feat, HW, C);
 }
 
 __global__ void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W,
@@ -84,8 +88,9 @@ __global__ void fc_bwd_w_kernel(const float* __restrict__ dz, const float* __res
         db[k] = s;
     }
 }
+template <typename T>
 __global__ void fc_bwd_x_kernel(const float* __restrict__ dz, const float* __restrict__ W,
-                                const float* __restrict__ mask, float* __restrict__ dout, int D, int C, int HW)
+                                const float* __restrict__ mask, T* __restrict__ dout, int D, int C, int HW)
 {
     const int img = blockIdx.x;
     const float inv = 1.f / (float)HW;
@@ -94,14 +99,17 @@ __global__ void fc_bwd_x_kernel(const float* __restrict__ dz, const float* __res
         for (int k = 0; k < C; ++k) s += dz[(size_t)img * C + k] * W[(size_t)k * D + d];
         s *= inv;
         if (mask) s *= mask[(size_t)img * D + d];      // dropout multiplier on the pooled feature
-        for (int p = 0; p < HW; ++p) dout[((size_t)img * HW + p) * D + d] = s;
+        for (int p = 0; p < HW; ++p) dout[((size_t)img * HW + p) * D + d] = (T)s;
     }
 }
 void k_fc_bwd(const float* dz, const float* feat, const float* W, const float* mask, float* dW, float* db,
-              float* dout, int imgs, int D, int C, int HW, hipStream_t s)
+              void* dout, int dt, int imgs, int D, int C, int HW, hipStream_t s)
 {
     hipLaunchKernelGGL(fc_bwd_w_kernel, dim3(C), dim3(256), 0, s, dz, feat, dW, db, imgs, D, C);
-    hipLaunchKernelGGL(fc_bwd_x_kernel, dim3(imgs), dim3(256), 0, s, dz, W, mask, dout, D, C, HW);
+    if (dt == DT_F32)
+        hipLaunchKernelGGL(fc_bwd_x_kernel<float>, dim3(imgs), dim3(256), 0, s, dz, W, mask, reinterpret_cast<float*>(dout), D, C, HW);
+    else
+        hipLaunchKernelGGL(fc_bwd_x_kernel<bf16>, dim3(imgs), dim3(256), 0, s, dz, W, mask, reinterpret_cast<bf16*>(dout), D, C, HW);
 }
 
 // ------------------------------------------------------------ losses -----------

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 #define FM_MAXC 32
 
 struct ClassVec { float v[FM_MAXC]; };
@@ -62,51 +64,54 @@ void k_bn_bwd_apply(const float* dz, const float* z, const float* y, const float
                     hipStream_t s);
 
 // ---- EfficientNet-B0 path (effnet.hip): any C % 4 == 0, act 0 none / 1 relu / 2 swish ---------
+// Activation tensors are fp32 or bf16 in HBM (DT_F32 / DT_BF16, common.h); arithmetic is fp32.  `ty` is the
+// storage type of raw conv outputs (y, dy), `ta` / `dt` that of activations and their gradients; per-channel
+// and per-image vectors (scale, shift, gate, statistics, partial sums) are always fp32.
 // out = act(y*scale+shift) * rowscale[img] + res
-void k_bnact_apply(const float* y, const float* scale, const float* shift, const float* res, const float* rowscale,
-                   float* out, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s);
+void k_bnact_apply(const void* y, int ty, const float* scale, const float* shift, const void* res, const float* rowscale,
+                   void* out, int ta, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s);
 // mode 0: (sum y, sum y^2); mode 1: (sum dyh, sum dyh*xhat), dyh = a*act'(y*scale+shift)*rowscale
 // part [groups][bn_bwd_blocks(pix_per_group)][2][C]
-void k_chan_reduce(const float* a, const float* y, const float* mean, const float* istd, const float* scale,
+void k_chan_reduce(const void* a, int ta, const void* y, int ty, const float* mean, const float* istd, const float* scale,
                    const float* shift, const float* rowscale, float* part, int groups, int pix_per_group, int HW,
                    int C, int mode, int act, const float* gate, const float* dsv, hipStream_t s);
-void k_bnact_bwd_apply(const float* dz, const float* y, const float* ca, const float* cb, const float* cc,
-                       const float* scale, const float* shift, const float* rowscale, float* dy, int groups,
+void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const float* ca, const float* cb, const float* cc,
+                       const float* scale, const float* shift, const float* rowscale, void* dy, int groups,
                        int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s);
 // gate/dsv (optional, [imgs][C]): the incoming gradient is d(a_s); d(a_d) = d(a_s)*gate + dsv/HW is formed on load
 // depthwise KxK (K 3 or 5): x [imgs][Hi][Wi][C], w [K*K][C]; optional fused y = act(y*scale+shift)
-void k_dw_fwd(const float* x, const float* w, float* y, const float* scale, const float* shift, int imgs, int Hi,
+void k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s);
-void k_dw_dgrad(const float* dy, const float* w, float* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+void k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
 int dw_wgrad_blocks(int npix);
 // part [dw_wgrad_blocks][K*K][C]; sum with k_reduce_slabs
-void k_dw_wgrad(const float* dy, const float* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
 // squeeze-excite: W1 [Cs][C], W2 [C][Cs]
 // pool_ws: [imgs][16][C] scratch for the per-image channel sums
 // scale/shift (optional, [groups][C], ipg images per group): `a` is the raw depthwise output and is read
 // as swish(a*scale+shift) -- the post-BN activation is not materialised in the train path
-void k_se_fwd(const float* a, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
+void k_se_fwd(const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
               const float* b1, const float* W2, const float* b2, float* sq, float* rpre, float* gate, int imgs, int HW,
               int C, int Cs, hipStream_t s);
-void k_se_scale(const float* a, const float* scale, const float* shift, int ipg, const float* gate, float* out, int imgs,
+void k_se_scale(const void* a, int dt, const float* scale, const float* shift, int ipg, const float* gate, void* out, int imgs,
                 int HW, int C, hipStream_t s);
-void k_se_bwd(const float* dout, const float* a, const float* scale, const float* shift, int ipg, float* pool_ws,
+void k_se_bwd(const void* dout, const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws,
               const float* gate, const float* rpre, const float* W1, const float* W2, float* dgp, float* drp, float* ds,
               int imgs, int HW, int C, int Cs, hipStream_t s);
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
                 float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s);
 void k_mul(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
-void k_add_inplace(float* y, const float* a, int64_t n, hipStream_t s);
+void k_add_inplace(void* y, const void* a, int dt, int64_t n, hipStream_t s);
 
 // ---- head ---------------------------------------------------------------------
-void k_avgpool(const float* x, float* feat, int imgs, int HW, int C, hipStream_t s);
+void k_avgpool(const void* x, int dt, float* feat, int imgs, int HW, int C, hipStream_t s);
 void k_fc_fwd(const float* feat, const float* W, const float* b, float* logits, int imgs, int D, int C,
               hipStream_t s);
 // dW[k][d], db[k] written; dout[img][hw][d] = (sum_k dz[img][k] W[k][d]) * mask[img][d] / HW  (mask optional)
 void k_fc_bwd(const float* dz, const float* feat, const float* W, const float* mask, float* dW, float* db,
-              float* dout, int imgs, int D, int C, int HW, hipStream_t s);
+              void* dout, int dt, int imgs, int D, int C, int HW, hipStream_t s);
 
 // ---- losses (one block; deterministic) -------------------------------------------
 void k_loss_bce(const float* z, const float* y, ClassVec pos_w, int B, int C, float inv_norm,

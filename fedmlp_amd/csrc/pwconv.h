@@ -1,0 +1,47 @@
+// bf16 pointwise (1x1) convolution kernels of the EfficientNet-B0 bf16 configuration (pwconv_bf16.hip).
+#pragma once
+#include "common.h"
+
+// D[pix][m] = sum_k Xe[pix][k] * W[m][k]   (forward: W = conv weight [Cout][Cin];
+//                                            data gradient: W = its transpose [Cin][Cout], X = dY)
+// Xe = X, or with a prologue (squeeze-excite gate fused into the project conv's operand load)
+//   Xe = swish(X*psc[g][k] + psh[g][k]) * gate[img][k]     (psc == null: Xe = X * gate[img][k])
+struct PwParams {
+    const bf16* W;        // [M][K] row-major
+    const bf16* X;        // [groups*npix][K]
+    bf16* Y;              // [groups*npix][M]
+    int M, K;             // multiples of 16
+    int npix;             // pixels per BN-statistics group
+    int groups;
+    int ppb, nblk;        // pixels per block (multiple of 32), blocks per group
+    const float* scale;   // optional per-m affine (eval-mode BN folded)
+    const float* shift;
+    const bf16* res;      // optional residual, indexed like Y
+    int act;              // 0 none, 2 swish (after the affine)
+    float* stats;         // optional BN partials [groups][nblk][2][M] (from the fp32 accumulators)
+    const float* psc;     // prologue: [groups][K] or null
+    const float* psh;
+    const float* gate;    // prologue: [imgs][K] or null (no prologue at all)
+    int HW;               // pixels per image (gate row = global pixel / HW)
+};
+int pw_blocks(int npix_per_group, int groups, int M, int K);   // nblk the launcher will use (statistics layout)
+void launch_pw_conv(PwParams p, hipStream_t s);
+
+// dW[m][k] = sum_pix dY[pix][m] * Xe[pix][k]  -> fp32 partial slabs [splits][M][K]
+struct PwWgradParams {
+    const bf16* dY;       // [npix][M]
+    const bf16* X;        // [npix][K]
+    float* slab;
+    int M, K, npix;
+    const float* psc;     // prologue on X as above ([groups][K], groups of pix_per_group pixels)
+    const float* psh;
+    const float* gate;
+    int HW, pix_per_group;
+};
+// returns the number of splits written (reduce with k_reduce_slabs), 0 = shape not handled
+int launch_pw_wgrad(const PwWgradParams& p, size_t slab_floats, hipStream_t s);
+
+// fp32 master weights -> bf16 shadows, all 1x1 convolutions in one launch:
+// wb[w_off ...] = bf16(W[m][k]) row-major and wbt[t_off ...] = its transpose [K][M]
+struct CastJob { long long src_off, w_off, t_off; int M, K, blk0; };
+void launch_cast_weights(const float* state, bf16* shadow, const CastJob* jobs, int njobs, int nblocks, hipStream_t s);

@@ -1,0 +1,531 @@
+// Pointwise (1x1) convolutions of EfficientNet-B0 in bf16 storage on the bf16 matrix pipe, gfx950.
+//
+// Reference ops replaced: the expand / project / head 1x1 convolutions of efficientnet-pytorch's
+// MBConvBlock, their data gradients and their weight gradients, inside net(images) and
+// loss.backward() (utils/local_training.py:657, 674, 937-947, 965, 1178, 1191; the model is built at
+// model/efficientnet.py:28-33).  This is the bf16 configuration (BASELINE configs[4]); the reference
+// itself never enables AMP (utils/local_training.py:14 imports autocast and does not use it), so the
+// yardstick is the fp32 oracle with a stated bf16 tolerance.
+//
+// Roofline: HBM.  EfficientNet-B0 moves ~20 FLOP per byte in bf16 and the bf16 matrix pipe
+// is 16x the fp32 one, so these kernels are built to touch every activation byte once:
+//  * forward / data gradient (pw_conv_bf16_kernel): the weight slice of an M-tile is staged ONCE per
+//    block in LDS, already in MFMA fragment order (each lane's 16 B are contiguous: conflict-free
+//    ds_read_b128 with no swizzle); every wave then streams its own pixels: the pixel operand goes
+//    global -> VGPR as 16-B fragments (v_mfma_f32_16x16x32_bf16: lane (li, lg) holds x[pixel li][8 lg .. 8 lg+7],
+//    i.e. 16 contiguous bytes of an NHWC row), no LDS traffic and no barrier in the loop.  K % 32 == 16
+//    (channel counts are padded to 16) ends with one v_mfma_f32_16x16x16_bf16 on 8-B fragments.
+//    Output rows are permuted between the two MFMA row tiles of a pair so that a lane ends up with 8
+//    consecutive channels of one pixel: one 16-B NHWC store.  Train-mode BN statistics come from the
+//    fp32 accumulators (registers, folded once per block, fixed order).  Optional prologue on the pixel
+//    operand: BN1 + Swish + squeeze-excite gate applied on load (the gated activation a_s is never
+//    written to HBM).
+//  * weight gradient (pw_wgrad_bf16_kernel): dW = dY^T X sums over PIXELS, the slow axis of both NHWC
+//    operands, so both MFMA operands are "transposed".  Tiles of 32 pixels are staged row-major in LDS
+//    and read with ds_read_b64_tr_b16 (hardware transpose: 4 pixels x 16 channels per lane group);
+//    row strides are 32 B x odd so that the 8 row segments a half-wave touches fall on distinct banks.
+//    Block tile = 64 channels of the larger channel count x ALL of the smaller one (<= 320): the large
+//    operand is read exactly once; split over pixels, fp32 slabs, fixed-order reduction (deterministic).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "pwconv.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma32(uint4 a, uint4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(uint2 a, uint2 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 lo4(uint4 v) { return __builtin_convertvector(__builtin_bit_cast(bf16x4, make_uint2(v.x, v.y)), f32x4); }
+__device__ __forceinline__ f32x4 hi4(uint4 v) { return __builtin_convertvector(__builtin_bit_cast(bf16x4, make_uint2(v.z, v.w)), f32x4); }
+__device__ __forceinline__ f32x4 cvt4(uint2 v) { return __builtin_convertvector(__builtin_bit_cast(bf16x4, v), f32x4); }
+__device__ __forceinline__ uint2 pack4(f32x4 v) { return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4)); }
+__device__ __forceinline__ uint4 pack8(f32x4 a, f32x4 b)
+{
+    const uint2 x = pack4(a), y = pack4(b);
+    return make_uint4(x.x, x.y, y.x, y.y);
+}
+__device__ __forceinline__ f32x4 swish4(f32x4 v)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.f + __expf(-v[k]));
+    return v;
+}
+// prologue: Xe = swish(x*sc+sh)*gate (sc == null: x*gate) on 4 channels
+__device__ __forceinline__ f32x4 pro4(f32x4 x, const float* sc, const float* sh, const float* gate, bool affine)
+{
+    if (affine) x = swish4(x * ld4(sc) + ld4(sh));
+    return x * ld4(gate);
+}
+
+// channel (relative to the M-tile) of MFMA row i of row tile r: tiles of a pair interleave in groups of 4 so
+// that accumulator registers of tiles 2u / 2u+1 hold channels 32u + 8 lg + {0..3} / {4..7}
+__device__ __forceinline__ int tile_row_to_channel(int r, int i, int npairs)
+{
+    return r < 2 * npairs ? 32 * (r >> 1) + 8 * (i >> 2) + 4 * (r & 1) + (i & 3) : 16 * r + i;
+}
+
+// =====================================================================================================
+template <int RT, bool PRO>
+__global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
+{
+    constexpr int MT = 16 * RT, P = 2, PPI = 16 * P, KB = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int K = p.K, nfull = K >> 5, tail = (K >> 4) & 1;
+    uint4* As = reinterpret_cast<uint4*>(smem);                                       // [nfull][RT][64 lanes] x 16 B
+    uint2* At = reinterpret_cast<uint2*>(smem + (size_t)nfull * RT * 1024);           // [RT][64 lanes] x 8 B
+    float* psc_l = reinterpret_cast<float*>(smem + (size_t)nfull * RT * 1024 + (size_t)RT * 512);   // [K] x 2 (PRO)
+    const int m0 = blockIdx.x * MT;
+    const int grp = blockIdx.y / p.nblk, blk = blockIdx.y - grp * p.nblk;
+    const int pb = blk * p.ppb, pe = min(p.npix, pb + p.ppb);
+    const size_t gbase = (size_t)grp * p.npix;
+    const int nrt = min(RT, (p.M - m0) >> 4);
+    const int npairs = nrt >> 1;
+
+    // ---- stage the weight slice once, in fragment order ------------------------------------------
+    const int cpr = K >> 3;                                  // 16-B chunks per weight row
+    for (int idx = tid; idx < MT * cpr; idx += 256) {
+        const int crel = idx / cpr, c = idx - crel * cpr;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (m0 + crel < p.M) v = *reinterpret_cast<const uint4*>(p.W + (size_t)(m0 + crel) * K + 8 * c);
+        int r, i;
+        if (crel < 32 * npairs) {
+            const int w = crel & 31;
+            r = 2 * (crel >> 5) + ((w >> 2) & 1);
+            i = 4 * (w >> 3) + (w & 3);
+        } else {
+            r = crel >> 4;
+            i = crel & 15;
+        }
+        const int sidx = c >> 2, lgc = c & 3;
+        if (sidx < nfull) {
+            As[(sidx * RT + r) * 64 + lgc * 16 + i] = v;
+        } else {                                             // the 16-k tail: two 4-k halves per chunk
+            const int c2 = c - 4 * nfull;
+            At[r * 64 + (2 * c2) * 16 + i] = make_uint2(v.x, v.y);
+            At[r * 64 + (2 * c2 + 1) * 16 + i] = make_uint2(v.z, v.w);
+        }
+    }
+    if constexpr (PRO) {
+        if (p.psc)
+            for (int k = tid; k < K; k += 256) {
+                psc_l[k] = p.psc[grp * K + k];
+                psc_l[K + k] = p.psh[grp * K + k];
+            }
+    }
+    __syncthreads();
+    const bool affine = PRO && p.psc != nullptr;
+
+    f32x4 s1[RT], s2[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int n_iter = (pe - pb + PPI - 1) / PPI;
+    for (int it = wave; it < n_iter; it += 4) {
+        const int pix0 = pb + it * PPI;
+        bool pv[P];
+        const bf16* xp[P];
+        const float* gp[P];
+#pragma unroll
+        for (int g = 0; g < P; ++g) {
+            const int px = pix0 + 16 * g + li;
+            pv[g] = px < pe;
+            const size_t gpx = gbase + (pv[g] ? px : pb);
+            xp[g] = p.X + gpx * K;
+            gp[g] = PRO ? p.gate + (gpx / p.HW) * K : nullptr;
+        }
+        f32x4 acc[RT][P];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int g = 0; g < P; ++g) acc[r][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nfull; kb += KB) {
+            uint4 b[P][KB];
+#pragma unroll
+            for (int g = 0; g < P; ++g)
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                    b[g][k] = (pv[g] && kb + k < nfull) ? *reinterpret_cast<const uint4*>(xp[g] + (kb + k) * 32 + 8 * lg)
+                                                       : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (PRO) {
+#pragma unroll
+                for (int g = 0; g < P; ++g)
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) {
+                        if (!pv[g] || kb + k >= nfull) continue;
+                        const int kk = (kb + k) * 32 + 8 * lg;
+                        const f32x4 lo = pro4(lo4(b[g][k]), psc_l + kk, psc_l + K + kk, gp[g] + kk, affine);
+                        const f32x4 hi = pro4(hi4(b[g][k]), psc_l + kk + 4, psc_l + K + kk + 4, gp[g] + kk + 4, affine);
+                        b[g][k] = pack8(lo, hi);
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (kb + k >= nfull) break;
+                const uint4* A = As + (size_t)(kb + k) * RT * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (r >= nrt) break;                     // row tiles past M
+                    const uint4 a = A[r * 64];
+#pragma unroll
+                    for (int g = 0; g < P; ++g) acc[r][g] = mfma32(a, b[g][k], acc[r][g]);
+                }
+            }
+        }
+        if (tail) {
+            uint2 b4[P];
+#pragma unroll
+            for (int g = 0; g < P; ++g) {
+                b4[g] = pv[g] ? *reinterpret_cast<const uint2*>(xp[g] + nfull * 32 + 4 * lg) : make_uint2(0u, 0u);
+                if constexpr (PRO) {
+                    if (pv[g]) {
+                        const int kk = nfull * 32 + 4 * lg;
+                        b4[g] = pack4(pro4(cvt4(b4[g]), psc_l + kk, psc_l + K + kk, gp[g] + kk, affine));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (r >= nrt) break;
+                const uint2 a = At[r * 64 + lane];
+#pragma unroll
+                for (int g = 0; g < P; ++g) acc[r][g] = mfma16(a, b4[g], acc[r][g]);
+            }
+        }
+        // ---- epilogue of the iteration: acc[r][g][q] = D[channel(r, 4 lg + q)][pixel pix0 + 16 g + li] -----
+        if (p.stats) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int g = 0; g < P; ++g) { s1[r] += acc[r][g]; s2[r] += acc[r][g] * acc[r][g]; }   // padded pixels are exact zeros
+        }
+#pragma unroll
+        for (int g = 0; g < P; ++g) {
+            if (!pv[g]) continue;
+            const size_t o = (gbase + pix0 + 16 * g + li) * (size_t)p.M;
+            auto finish = [&](f32x4 v, int m) {
+                if (p.scale) v = v * ld4(p.scale + m) + ld4(p.shift + m);
+                if (p.res) v += ld4(p.res + o + m);
+                if (p.act == 2) v = swish4(v);
+                return v;
+            };
+#pragma unroll
+            for (int u = 0; u < RT / 2; ++u) {
+                if (u >= npairs) break;
+                const int m = m0 + 32 * u + 8 * lg;
+                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m), finish(acc[2 * u + 1][g], m + 4));
+            }
+            if (nrt & 1) {
+                const int r = nrt - 1;
+                const int m = m0 + 16 * r + 4 * lg;
+                f32x4 v = acc[0][g];
+#pragma unroll
+                for (int rr = 1; rr < RT; ++rr)
+                    if (rr == r) v = acc[rr][g];             // static register index
+                *reinterpret_cast<uint2*>(p.Y + o + m) = pack4(finish(v, m));
+            }
+        }
+    }
+
+    // ---- BN statistics: fold the 16 pixel lanes, then the 4 waves (fixed order) -----------------------
+    if (p.stats) {
+        __syncthreads();                       // every wave is done with the weight slice: reuse the LDS
+        float* red = reinterpret_cast<float*>(smem);          // [4 waves][MT][2]
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u = s1[r][q], v = s2[r][q];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    u += __shfl_xor(u, d);
+                    v += __shfl_xor(v, d);
+                }
+                if (li == 0 && r < nrt) {
+                    const int ml = tile_row_to_channel(r, 4 * lg + q, npairs);
+                    red[(wave * MT + ml) * 2 + 0] = u;
+                    red[(wave * MT + ml) * 2 + 1] = v;
+                }
+            }
+        __syncthreads();
+        if (tid < 16 * nrt) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                u += red[(w * MT + tid) * 2 + 0];
+                v += red[(w * MT + tid) * 2 + 1];
+            }
+            float* st = p.stats + (size_t)(grp * p.nblk + blk) * 2 * p.M;
+            st[m0 + tid] = u;
+            st[p.M + m0 + tid] = v;
+        }
+    }
+}
+
+// =====================================================================================================
+// weight gradient.  P[l][s] = sum_pix Big[pix][l] * Small[pix][s]; `swap` = Big is X (then P = dW^T).
+struct WgArgs {
+    const bf16* Big;      // [npix][L]
+    const bf16* Small;    // [npix][S]
+    float* slab;          // [splits][M][K]
+    int L, S, M, K, swap, npix;
+    int strideS;          // LDS row stride of the Small tile in bytes (32 x odd, >= 2 S)
+    const float* psc;     // prologue on X (the Big operand if swap, else the Small one)
+    const float* psh;
+    const float* gate;
+    int HW, pix_per_group;
+};
+constexpr int WG_STRIDE_BIG = 160;          // 64 channels x 2 B = 128 B of data per pixel row, padded to 32 B x 5
+
+__device__ __forceinline__ uint2 ds_read_tr16(const unsigned char* lds_ptr)
+{
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    // generic -> LDS address space: the low 32 bits of a generic LDS pointer are the LDS offset
+    const unsigned off = (unsigned)(size_t)lds_ptr;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)off);
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <int CC, bool PRO>
+__global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const WgArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int l0 = blockIdx.x * 64;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tsteps = (p.npix + 31) >> 5;
+    const int nsteps = split < tsteps ? (tsteps - split + nsplit - 1) / nsplit : 0;   // 32-pixel steps dealt round-robin
+    const int strideS = p.strideS;
+    const int bufbytes = 32 * WG_STRIDE_BIG + 32 * strideS;
+    const int cps = p.S >> 3;                                  // 16-B chunks per Small row
+    constexpr int NB = (32 * (2 * CC) + 255) / 256;            // Small-tile chunks per thread (S = 16 CC -> 2 CC chunks per row)
+
+    // staging: Big tile = 32 rows x 8 chunks (one per thread), Small tile = 32 rows x cps chunks
+    const int ra = tid >> 3, ca = tid & 7;
+    const bool a_ok = l0 + 8 * ca < p.L;
+    uint4 va, vb[NB];
+    auto xform = [&](uint4 v, int pix, int ch) {            // prologue on 8 channels ch.. of pixel pix of X
+        const int g = pix / p.pix_per_group;
+        const float* gt = p.gate + (size_t)(pix / p.HW) * p.K + ch;
+        const bool affine = p.psc != nullptr;
+        const float* sc = affine ? p.psc + g * p.K + ch : nullptr;
+        const float* sh = affine ? p.psh + g * p.K + ch : nullptr;
+        const f32x4 lo = pro4(lo4(v), sc, sh, gt, affine);
+        const f32x4 hi = pro4(hi4(v), affine ? sc + 4 : nullptr, affine ? sh + 4 : nullptr, gt + 4, affine);
+        return pack8(lo, hi);
+    };
+    auto gload = [&](int s) {
+        const int pb = (split + s * nsplit) * 32;
+        {
+            const int pix = pb + ra;
+            va = make_uint4(0u, 0u, 0u, 0u);
+            if (a_ok && pix < p.npix) {
+                va = *reinterpret_cast<const uint4*>(p.Big + (size_t)pix * p.L + l0 + 8 * ca);
+                if constexpr (PRO) { if (p.swap) va = xform(va, pix, l0 + 8 * ca); }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c / cps, cb = c - row * cps;
+            const int pix = pb + row;
+            vb[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < 32 * cps && pix < p.npix) {
+                vb[q] = *reinterpret_cast<const uint4*>(p.Small + (size_t)pix * p.S + 8 * cb);
+                if constexpr (PRO) { if (!p.swap) vb[q] = xform(vb[q], pix, 8 * cb); }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = smem + buf * bufbytes;
+        *reinterpret_cast<uint4*>(base + ra * WG_STRIDE_BIG + ca * 16) = va;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c / cps, cb = c - row * cps;
+            if (c < 32 * cps) *reinterpret_cast<uint4*>(base + 32 * WG_STRIDE_BIG + row * strideS + cb * 16) = vb[q];
+        }
+    };
+
+    f32x4 acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    // transposed fragment reads: lane (group lg, i = li) supplies the address of row (4 lg + (li >> 2)) [+16 for
+    // the second half of k], columns 4 (li & 3) .. +3 of the 16-channel block, and receives channel li of
+    // rows 4 lg .. 4 lg + 3: element j < 4 of a fragment is pixel 4 lg + j, j >= 4 pixel 16 + 4 lg + (j - 4)
+    // (the same permutation of k for both operands)
+    const int trow = 4 * lg + (li >> 2), tcol = 4 * (li & 3);
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const unsigned char* base = smem + buf * bufbytes;
+        const unsigned char* ab = base + trow * WG_STRIDE_BIG + (16 * wave + tcol) * 2;
+        const uint2 a0 = ds_read_tr16(ab), a1 = ds_read_tr16(ab + 16 * WG_STRIDE_BIG);
+        const uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        const unsigned char* bb = base + 32 * WG_STRIDE_BIG + trow * strideS + tcol * 2;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const uint2 b0 = ds_read_tr16(bb + 32 * c), b1 = ds_read_tr16(bb + 32 * c + 16 * strideS);
+            acc[c] = mfma32(a, make_uint4(b0.x, b0.y, b1.x, b1.y), acc[c]);
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[c][q] = P[l = l0 + 16 wave + 4 lg + q][s = 16 c + li]
+    const int l = l0 + 16 * wave + 4 * lg;
+    if (l < p.L) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int sc = 16 * c + li;
+            if (sc >= p.S) continue;
+            if (p.swap) {            // l = k (X channel), s = m: 4 consecutive k -> one 16-B store
+                *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + sc) * p.K + l) = acc[c];
+            } else {                 // l = m, s = k
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p.slab[((size_t)split * p.M + l + q) * p.K + sc] = acc[c][q];
+            }
+        }
+    }
+}
+
+// smallest 32 x odd >= bytes
+int odd32(int bytes)
+{
+    int n = (bytes + 31) / 32;
+    if (!(n & 1)) ++n;
+    return 32 * n;
+}
+
+// =====================================================================================================
+__global__ void cast_weights_kernel(const float* __restrict__ state, bf16* __restrict__ shadow,
+                                    const CastJob* __restrict__ jobs, int njobs)
+{
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+    const CastJob jb = jobs[j];
+    const int i = ((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+    if (i >= jb.M * jb.K) return;
+    const int m = i / jb.K, k = i - m * jb.K;
+    const bf16 v = (bf16)state[jb.src_off + i];
+    shadow[jb.w_off + i] = v;
+    shadow[jb.t_off + (long long)k * jb.M + m] = v;
+}
+
+}  // namespace
+
+// ---- launchers ------------------------------------------------------------------------------------------
+static int pw_rt(int K) { return K <= 640 ? 4 : 2; }           // weight slice <= 80 KB of LDS
+static int pw_ppb(int npix_per_group, int groups, int M, int K)
+{
+    const int MT = 16 * pw_rt(K);
+    const long long tilesM = (M + MT - 1) / MT;
+    const long long total = (long long)npix_per_group * groups * tilesM;
+    long long ppb = total / 2048;                               // ~2048 blocks when there is enough work
+    // staging the weight slice costs MT*K*2 B per block: keep it <= ~6 % of the block's pixel traffic
+    ppb = std::max<long long>(ppb, 16LL * MT);
+    ppb = std::min<long long>(std::max<long long>(ppb, 128), 4096);
+    return (int)((ppb + 31) / 32 * 32);
+}
+int pw_blocks(int npix_per_group, int groups, int M, int K)
+{
+    const int ppb = pw_ppb(npix_per_group, groups, M, K);
+    return (npix_per_group + ppb - 1) / ppb;
+}
+
+void launch_pw_conv(PwParams p, hipStream_t s)
+{
+    const int RT = pw_rt(p.K);
+    const int MT = 16 * RT;
+    p.ppb = pw_ppb(p.npix, p.groups, p.M, p.K);
+    p.nblk = (p.npix + p.ppb - 1) / p.ppb;
+    const bool pro = p.gate != nullptr;
+    size_t lds = (size_t)(p.K >> 5) * RT * 1024 + (size_t)RT * 512 + (pro ? (size_t)2 * p.K * 4 : 0);
+    lds = std::max<size_t>(lds, (size_t)4 * MT * 2 * 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<4, false>), 96 * 1024, "pw_conv_bf16_kernel<4,false>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<2, false>), 96 * 1024, "pw_conv_bf16_kernel<2,false>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<4, true>), 96 * 1024, "pw_conv_bf16_kernel<4,true>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<2, true>), 96 * 1024, "pw_conv_bf16_kernel<2,true>");
+        attr_done = true;
+    }
+    const dim3 grid((p.M + MT - 1) / MT, p.nblk * p.groups);
+    if (RT == 4) {
+        if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<4, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((pw_conv_bf16_kernel<4, false>), grid, dim3(256), lds, s, p);
+    } else {
+        if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<2, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((pw_conv_bf16_kernel<2, false>), grid, dim3(256), lds, s, p);
+    }
+}
+
+template <int CC>
+static void wg_launch(const WgArgs& a, bool pro, dim3 grid, size_t lds, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_wgrad_bf16_kernel<CC, false>), 64 * 1024, "pw_wgrad_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_wgrad_bf16_kernel<CC, true>), 64 * 1024, "pw_wgrad_bf16_kernel");
+        attr_done = true;
+    }
+    if (pro) hipLaunchKernelGGL((pw_wgrad_bf16_kernel<CC, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((pw_wgrad_bf16_kernel<CC, false>), grid, dim3(256), lds, s, a);
+}
+
+int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
+{
+    WgArgs a{};
+    a.swap = w.K > w.M;                      // the larger channel count is the tiled ("Big") operand
+    a.Big = a.swap ? w.X : w.dY;
+    a.Small = a.swap ? w.dY : w.X;
+    a.L = std::max(w.M, w.K); a.S = std::min(w.M, w.K);
+    if (a.S > 320 || (a.S & 15) || (a.L & 15)) return 0;
+    a.slab = w.slab; a.M = w.M; a.K = w.K; a.npix = w.npix;
+    a.psc = w.psc; a.psh = w.psh; a.gate = w.gate; a.HW = w.HW; a.pix_per_group = w.pix_per_group;
+    const int cc = a.S / 16;
+    static const int avail[] = {1, 2, 3, 5, 7, 12, 20};
+    int CCi = 20;
+    for (int v : avail) if (v >= cc) { CCi = v; break; }
+    a.strideS = odd32(2 * a.S);
+    // the tile the kernel stages is 16*CC wide only through cps = S/8 chunks: rows hold S channels; fragments of
+    // column tiles past S read stale LDS but their results are never stored (sc >= S)
+    if (odd32(2 * a.S) < 32 * CCi) a.strideS = odd32(32 * CCi);
+    const int tilesL = (a.L + 63) / 64;
+    const int tsteps = (w.npix + 31) / 32;
+    int splits = std::max(1, 2048 / tilesL);
+    splits = std::min(splits, std::max(1, tsteps / 8));
+    splits = (int)std::min<size_t>(splits, std::max<size_t>(1, slab_floats / ((size_t)w.M * w.K)));
+    const size_t lds = (size_t)2 * (32 * WG_STRIDE_BIG + 32 * a.strideS);
+    const dim3 grid(tilesL, splits);
+    const bool pro = w.gate != nullptr;
+    switch (CCi) {
+    case 1: wg_launch<1>(a, pro, grid, lds, s); break;
+    case 2: wg_launch<2>(a, pro, grid, lds, s); break;
+    case 3: wg_launch<3>(a, pro, grid, lds, s); break;
+    case 5: wg_launch<5>(a, pro, grid, lds, s); break;
+    case 7: wg_launch<7>(a, pro, grid, lds, s); break;
+    case 12: wg_launch<12>(a, pro, grid, lds, s); break;
+    default: wg_launch<20>(a, pro, grid, lds, s); break;
+    }
+    return splits;
+}
+
+void launch_cast_weights(const float* state, bf16* shadow, const CastJob* jobs, int njobs, int nblocks, hipStream_t s)
+{
+    if (njobs) hipLaunchKernelGGL(cast_weights_kernel, dim3(nblocks), dim3(256), 0, s, state, shadow, jobs, njobs);
+}

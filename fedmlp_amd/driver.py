@@ -5,8 +5,8 @@ per GPU, clients dealt round-robin over the ranks, aggregation as RCCL all-reduc
 (fedmlp_amd/fedavg.py).  Data is synthetic and HBM-resident (the reference's datasets and
 ImageNet weights are not available offline).
 
-  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m fedmlp_amd.driver \\
-      --exp FedMLP --n_clients 8 --rounds_warmup 4 --rounds_FedMLP_stage1 2
+  python -m fedmlp_amd.driver --gpus 8 --exp FedMLP --n_clients 8 --rounds_warmup 4 --rounds_FedMLP_stage1 2
+(with --gpus N > 1 and no torchrun environment the driver starts its N ranks itself, fedmlp_amd/launch.py)
 """
 import argparse
 import json
@@ -37,6 +37,15 @@ def args_parser():
     p.add_argument("--feature_dim", type=int, default=0, help="0 = the model's own (512 ResNet-18, 1280 Efficient_b0)")
     p.add_argument("--n_local", type=int, default=512, help="samples per client (5000 for ICH)")
     p.add_argument("--hw", type=int, default=224)
+    p.add_argument("--gpus", type=int, default=1, help="ranks = GPUs; clients are dealt round-robin over them")
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16: Efficient_b0 only")
+    p.add_argument("--pretrained", type=int, default=0, help="1: ImageNet checkpoint through build_model (utils/options.py:26)")
+    p.add_argument("--pretrained_path", default=None)
+    p.add_argument("--init_ckpt", default=None, help="torch.save(state_dict) file to start from (main.py:361-367)")
+    p.add_argument("--save_every", type=int, default=0, help="save netglob.state_dict() every N rounds (main.py:237)")
+    p.add_argument("--save_dir", default=".")
+    p.add_argument("--augment", type=int, default=0,
+                   help="1: uint8 HBM cache + per-sample RandomAffine/HFlip/Normalize kernel (dataset/dataset.py:40-53)")
     return p.parse_args()
 
 
@@ -62,6 +71,10 @@ class DeviceDataset:
 
 def main():
     args = args_parser()
+    from fedmlp_amd.launch import launched_by_torchrun, spawn_ranks
+    if args.gpus > 1 and not launched_by_torchrun():
+        import sys
+        sys.exit(spawn_ranks("fedmlp_amd.driver", sys.argv[1:], args.gpus, module=True))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
@@ -72,23 +85,29 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from fedmlp_amd import spec
     from fedmlp_amd.engine import Engine
-    from fedmlp_amd.model import ResidentNet
+    from fedmlp_amd.model import ResidentNet, build_model
     from fedmlp_amd.local_training import LocalUpdate
-    from fedmlp_amd.fedavg import allreduce_weighted_, tao_allreduce, proto_allreduce
+    from fedmlp_amd.fedavg import comm_init, tao_allreduce, proto_allreduce
 
     C, S1 = args.n_classes, args.rounds_FedMLP_stage1
     args.feature_dim = args.feature_dim or spec.FEATURE_DIM[args.model]
-    eng = Engine(args.model, C, args.hw, args.hw, 4 * args.batch_size, device=str(dev))
-    flat, cnt = spec.init_state(args.model, C, args.seed)
-    eng.set_state(flat, cnt)
+    eng = Engine(args.model, C, args.hw, args.hw, 4 * args.batch_size, device=str(dev), precision=args.precision)
+    comm_init(eng)                                        # the library's own RCCL communicator (C ABI)
+    # netglob = build_model(args) (main.py:73): from-scratch init, an ImageNet checkpoint, or --init_ckpt
+    host = build_model(args)
+    if args.init_ckpt:
+        host.load_state_dict(torch.load(args.init_ckpt, map_location="cpu"))
+    host._pull()
+    eng.set_state(host.flat, host.counters)
     glob = eng.state_tensor().clone()                     # netglob, replicated on every rank
+    glob_cnt = eng.counters().copy()                      # its num_batches_tracked counters
     net = ResidentNet(eng)
 
     mine = [c for c in range(args.n_clients) if c % world == rank]
     n_all = [args.n_local] * args.n_clients
     clients = {}
     for c in mine:                                       # client c annotates class c mod C
-        ds = DeviceDataset(args.n_local, C, args.hw, args.seed + 1000 * c, dev)
+        ds = (AugmentedDeviceDataset if args.augment else DeviceDataset)(args.n_local, C, args.hw, args.seed + 1000 * c, dev)
         pos = [np.where(ds.targets[:, k] == 1)[0] for k in range(C)]
         a = argparse.Namespace(**vars(args))
         clients[c] = LocalUpdate(a, c % C, ds, list(range(args.n_local)), pos, pos, active_class_list=[c % C])
@@ -97,12 +116,14 @@ def main():
     for rnd in range(args.rounds_warmup):
         t0 = time.perf_counter()
         acc = torch.zeros_like(glob)
-        t_num = np.zeros(C); t_den = np.zeros(C)
-        p_num = torch.zeros((2 * C, args.feature_dim)); p_den = np.zeros(2 * C)
+        acc_cnt = np.zeros(len(glob_cnt), np.float64)
+        t_loc = np.zeros(C); tn_loc = np.zeros(C)         # this rank's FedAvg_tao / FedAvg_proto numerators
+        p_loc = torch.zeros((2 * C, args.feature_dim)); pn_loc = np.zeros(C)
         losses = []
         for c in mine:
             loc = clients[c]
             eng.state_tensor().copy_(glob)                # net = deepcopy(netglob)  (main.py:181-184)
+            eng.counters(glob_cnt)
             w = n_all[c] / float(sum(n_all))
             if args.exp == "FedAVG":
                 ret = loc.train(rnd, net, None)
@@ -115,35 +136,52 @@ def main():
                                        loc.active_class_list, net=net)
             losses.append(float(ret[1]))
             acc.add_(eng.state_tensor(), alpha=w)         # FedAvg numerator (utils/FedAvg.py:9-13)
-            if len(ret) == 8:                             # FedAvg_tao / FedAvg_proto numerators
+            acc_cnt += w * eng.counters().astype(np.float64)
+            if len(ret) == 8:                             # several clients on one rank: fold them first
                 neg = np.array([0.0 if k in loc.active_class_list else 1.0 for k in range(C)])
                 act = 1.0 - neg
-                t_num += ret[6] * n_all[c] * neg; t_den += n_all[c] * neg
+                t_loc += ret[6] * n_all[c] * neg; tn_loc += n_all[c] * neg
                 pa = np.repeat(act, 2)
-                p_num += torch.where(torch.from_numpy(pa > 0)[:, None], ret[7] * n_all[c], torch.zeros(()))
-                p_den += n_all[c] * pa
-        if dist is not None:
-            dist.all_reduce(acc)
-        glob.copy_(acc)
+                p_loc += torch.where(torch.from_numpy(pa > 0)[:, None], ret[7] * n_all[c], torch.zeros(()))
+                pn_loc += n_all[c] * act
+        # ---- aggregation (main.py:216-234): every sum over clients is an RCCL all-reduce in the library.
+        # A rank that trained several clients has already folded them (weights n_c / sum(n)) into `acc`.
+        eng.state_tensor().copy_(acc)
+        eng.counters(np.zeros(len(glob_cnt), np.int64))   # the counters are reduced as float64 below
+        eng.fedavg_allreduce(1.0)                         # fm_fedavg_allreduce: ncclAllReduce of the state arena
+        glob.copy_(eng.state_tensor())
+        glob_cnt = np.trunc(rank_sum(acc_cnt, dev) + 1e-9).astype(np.int64)   # utils/FedAvg.py:13 + load_state_dict
+        eng.counters(glob_cnt)
         if args.exp == "FedMLP" and rnd >= S1 - 1:
-            buf = torch.from_numpy(np.concatenate([t_num, t_den])).to(dev)
-            pn, pd = p_num.to(dev), torch.from_numpy(p_den).to(dev)
-            if dist is not None:
-                dist.all_reduce(buf); dist.all_reduce(pn); dist.all_reduce(pd)
-            buf = buf.cpu().numpy()
-            tao = np.where(buf[C:] == 0, 1.0, buf[:C] / np.where(buf[C:] == 0, 1.0, buf[C:]))
+            # FedAvg_tao / FedAvg_proto (utils/FedAvg.py:51-93): this rank enters with its folded clients'
+            # means and, per class, the weight sum(n_c) of its clients that miss / annotate the class
             with np.errstate(invalid="ignore", divide="ignore"):
-                Prototype = torch.from_numpy(pn.cpu().numpy() / pd.cpu().numpy()[:, None].astype(np.float32))
+                t_rank = np.where(tn_loc > 0, t_loc / np.where(tn_loc > 0, tn_loc, 1.0), 0.0)
+                p_rank = p_loc.numpy() / np.repeat(np.where(pn_loc > 0, pn_loc, 1.0), 2)[:, None].astype(np.float32)
+            tao = tao_allreduce(t_rank, 1.0, tn_loc, device=dev, engine=eng)
+            Prototype = proto_allreduce(p_rank, 1.0, pn_loc, device=dev, engine=eng)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         rec = {"round": rnd, "sec": round(dt, 3), "mean_loss": float(np.mean(losses)) if losses else None,
                "samples_per_sec_per_gpu": round(len(mine) * args.n_local / dt, 1)}
         if rank == 0:
             print(json.dumps(rec), flush=True)
+            if args.save_every and (rnd + 1) % args.save_every == 0:     # torch.save(netglob.state_dict(), ...) main.py:237
+                torch.save(net.state_dict(), os.path.join(args.save_dir, f"model_{rnd}.pth"))
         log.append(rec)
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
     return log
+
+
+def rank_sum(x, dev):
+    """float64 sum of a small host vector over the ranks"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(x, np.float64)
+    t = torch.from_numpy(np.asarray(x, np.float64)).to(dev)
+    dist.all_reduce(t)
+    return t.cpu().numpy()
 
 
 if __name__ == "__main__":

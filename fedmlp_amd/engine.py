@@ -290,6 +290,14 @@ class Engine:
         _lib.check(self.lib.fm_debug_get_grads(self.h, flat.ctypes.data_as(C.c_void_p)))
         return flat
 
+    def debug_activation(self, kind, block, imgs):
+        """post-ReLU activation kept by the last train-mode forward, as an NCHW numpy array"""
+        dims = (C.c_int32 * 4)()
+        _lib.check(self.lib.fm_debug_activation(self.h, kind, block, imgs, None, dims))
+        out = np.empty(tuple(dims), np.float32)
+        _lib.check(self.lib.fm_debug_activation(self.h, kind, block, imgs, out.ctypes.data_as(C.c_void_p), dims))
+        return np.ascontiguousarray(out.transpose(0, 3, 1, 2))
+
     def debug_num_convs(self):
         return self.lib.fm_debug_num_convs(self.h)
 

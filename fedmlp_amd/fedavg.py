@@ -143,7 +143,7 @@ def proto_allreduce(proto, n_i, is_active_client_mask, device="cpu", engine=None
     if engine is not None and engine.comm_size() >= 1:
         return torch.from_numpy(engine.fedavg_proto(_np(proto), n_i, is_active_client_mask))
     m = np.repeat(np.asarray(is_active_client_mask, dtype=np.float32), 2)[:, None]
-    P = np.asarray(_np(proto), dtype=np.float32) * np.float32(n_i)     # NaN rows of an active class propagate
+    P = np.asarray(_np(proto), dtype=np.float32) * (np.float32(n_i) * m)     # NaN rows of an active class propagate
     num = torch.from_numpy(np.where(m > 0, P, 0.0).astype(np.float32)).to(device)
     den = torch.from_numpy((np.float32(n_i) * m[:, 0]).astype(np.float32)).to(device)
     d = _dist()

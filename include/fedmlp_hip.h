@@ -105,7 +105,8 @@ int fm_comm_size(fm_engine* e);
  * weighted mean of the num_batches_tracked counters (truncated on load like utils/FedAvg.py:13). */
 int fm_fedavg_allreduce(fm_engine* e, float w);
 /* FedAvg_tao over ranks: out[c] = sum_r t_r[c] n_r m_r[c] / sum_r n_r m_r[c] with m_r = this
- * rank's negative_mask (1 = class c is missing on this client); 1.0 where no rank has it (:66-67). */
+ * rank's negative_mask (1 = class c is missing on this client; a rank that stands for several folded
+ * clients passes n_i = 1 and their summed sample counts as the mask); 1.0 where no rank has it (:66-67). */
 int fm_fedavg_tao(fm_engine* e, const double* t_host, double n_i, const float* negative_mask_host,
                   double* out_host);
 /* FedAvg_proto over ranks: rows 2c, 2c+1 averaged over the ranks whose active_mask[c] = 1,
@@ -249,6 +250,14 @@ int fm_debug_num_convs(fm_engine* e);
  * All tensors NHWC fp32 on device; weights are the engine's current state. */
 int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, const float* dy_dev,
                   float* out_dev, int32_t imgs, int32_t groups, float* stats_dev);
+
+/* Post-ReLU activations the last train-mode forward kept (ResNet-18): kind 0 = relu(bn1(conv1)) of
+ * basic block `block`, kind 1 = the block's output relu(bn2(conv2) + identity); NHWC fp32 for the first
+ * `imgs` images, dims4 = {imgs, H, W, C}.  host_nhwc may be NULL to query the dims only.  Parity tests
+ * hand the ReLU masks (value > 0) to the oracle's backward pass, so a pre-activation within rounding
+ * distance of zero cannot turn a 1e-6 forward difference into a percent-level gradient difference. */
+int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs, float* host_nhwc,
+                        int32_t* dims4);
 
 /* Gradients of the last step in state_dict order (running-stat slots are 0). */
 int fm_debug_get_grads(fm_engine* e, float* host_f32);

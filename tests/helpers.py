@@ -60,6 +60,67 @@ def assert_norms_close(got, want, rtol, atol=1e-7, what=""):
         assert abs(g - w) <= atol + rtol * abs(w), f"{what} {k}: got {g} want {w}"
 
 
+class _MaskedReLU(torch.autograd.Function):
+    """relu whose BACKWARD mask is supplied: forward = the oracle's own relu(x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
+class relu_masks_from_engine:
+    """Context manager: the oracle ResNet's backward pass uses the ENGINE's ReLU masks.
+
+    Why: with ~1e6 ReLU inputs per step a few pre-activations always lie within the ~1e-6 distance
+    by which two fp32 summation orders differ; such an element's mask is decided by rounding, and one
+    flipped mask in a channel with a few hundred values moves that channel's BN-backward sums (and
+    everything upstream) by 1e-3.  Taking the masks from the engine's own forward activations
+    (fm_debug_activation: mask = value > 0) splits the check into (a) forward parity -- the oracle's
+    forward values are untouched and the loss is compared to 1e-5 -- and (b) backward parity for
+    identical masks, where 2e-4 holds on every seed.  The number of positions where the engine's
+    mask differs from the oracle's own is recorded in `.flips` (it must stay tiny).
+
+    Call order inside the oracle (oracle/resnet18_ref.py): per forward pass the stem ReLU, then for each
+    of the 8 basic blocks relu(bn1) and the output ReLU; views are forwarded one after the other."""
+
+    def __init__(self, eng, n_views, B):
+        self.masks = []
+        for v in range(n_views):
+            self.masks.append(None)                                    # stem: its own mask (6144+ values per channel)
+            for blk in range(8):
+                for kind in (0, 1):
+                    a = eng.debug_activation(kind, blk, n_views * B)[v * B:(v + 1) * B]
+                    self.masks.append(torch.from_numpy(a > 0))
+        self.flips = 0
+        self.calls = 0
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._F, self._orig = F, F.relu
+
+        def relu(x, *a, **k):
+            j = self.calls
+            self.calls += 1
+            if j >= len(self.masks) or self.masks[j] is None or not x.requires_grad:
+                return self._orig(x, *a, **k)
+            m = self.masks[j]
+            assert m.shape == x.shape, (j, m.shape, x.shape)
+            self.flips += int(((x.detach() > 0) != m).sum())
+            return _MaskedReLU.apply(x, m.to(x.dtype))
+        F.relu = relu
+        return self
+
+    def __exit__(self, *exc):
+        self._F.relu = self._orig
+        return False
+
+
 def relu_margin(net, xs, max_count=64):
     """Smallest |pre-activation| over the ReLUs whose BN statistics are thin (<= max_count values per
     channel) in a train-mode forward of `net` (a copy: running stats untouched) on the views `xs`.

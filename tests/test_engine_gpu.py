@@ -9,7 +9,7 @@ import torch
 
 from fedmlp_amd import spec
 from oracle import steps_ref as R
-from tests.helpers import oracle_net, conditioned_seed
+from tests.helpers import oracle_net, relu_masks_from_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -81,14 +81,6 @@ def _cmp_state(e, net, atol_w):
         np.testing.assert_allclose(sd[k], want, rtol=1e-4, atol=tol, err_msg=k)
 
 
-def _seed(views, B, seeds):
-    """Data seed picked by the ORACLE's ReLU margins (tests/helpers.conditioned_seed): a pre-activation
-    within rounding distance of zero in layer 4 (32 values per channel here) takes its mask from the conv
-    summation order and would turn a 1e-6 difference into a percent-level one for that channel."""
-    net = oracle_net(C_, 1037)
-    return conditioned_seed(net, lambda sd: _data(B, sd, views)[0], seeds)
-
-
 def test_forward_eval(eng):
     net = _load(eng)
     (x,), _ = _data(5, 1)
@@ -101,57 +93,63 @@ def test_forward_eval(eng):
 
 
 def test_step_bce(eng):
-    seed = _seed(1, 6, range(2, 40))
     net = _load(eng)
-    (x,), y = _data(6, seed)
+    (x,), y = _data(6, 2)
     pw = [3.0, 1.5, 4.0, 2.0, 2.5]
-    net.train()
-    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
-    _, z = net(x)
-    loss = R.loss_train(z, y, pw, 8, C_)
-    opt.zero_grad(); loss.backward(); opt.step()
     lo = torch.zeros(1, device="cuda")
     eng.step_bce(x.cuda(), y.cuda(), pw, 8, lo)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    with relu_masks_from_engine(eng, 1, 6) as rm:        # backward with the engine's ReLU masks (see helper)
+        _, z = net(x)
+        loss = R.loss_train(z, y, pw, 8, C_)
+        opt.zero_grad(); loss.backward()
+    opt.step()
+    assert rm.calls == 17 and rm.flips <= 16, rm.flips
     assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
     _cmp_grads(eng, net, what='bce')
     _cmp_state(eng, net, atol_w=2.5 * LR)
 
 
 def test_step_stage1(eng):
-    seed = _seed(2, 6, range(3, 40))
     net = _load(eng)
-    (x1, x2), y = _data(6, seed, views=2)
+    (x1, x2), y = _data(6, 3, views=2)
     act, neg = [1], [0, 2, 3, 4]
     glob = copy.deepcopy(net).eval()
-    net.train()
-    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
-    _, z1 = net(x1); _, z2 = net(x2)
-    with torch.no_grad():
-        _, g1 = glob(x1); _, g2 = glob(x2)
-    loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
-    opt.zero_grad(); loss.backward(); opt.step()
     eng.teacher_snapshot()
     lo = torch.zeros(1, device="cuda")
     mask = [1.0 if c in act else 0.0 for c in range(C_)]
     eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    with relu_masks_from_engine(eng, 2, 6) as rm:
+        _, z1 = net(x1); _, z2 = net(x2)
+        with torch.no_grad():
+            _, g1 = glob(x1); _, g2 = glob(x2)
+        loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
+        opt.zero_grad(); loss.backward()
+    opt.step()
+    assert rm.flips <= 32, rm.flips
     assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
     _cmp_grads(eng, net, what='stage1')
     _cmp_state(eng, net, atol_w=2.5 * LR)
 
 
 def test_step_stage2(eng):
-    seed = _seed(1, 7, range(4, 40))
     net = _load(eng)
-    (x,), y = _data(7, seed)
+    (x,), y = _data(7, 4)
     g = torch.Generator().manual_seed(44)
     dist = (torch.rand((7, C_), generator=g) < 0.4).float()
-    net.train()
-    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
-    _, z = net(x)
-    loss = R.loss_stage2(z, y, dist)
-    opt.zero_grad(); loss.backward(); opt.step()
     lo = torch.zeros(1, device="cuda")
     eng.step_stage2(x.cuda(), y.cuda(), dist.cuda(), lo)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    with relu_masks_from_engine(eng, 1, 7) as rm:
+        _, z = net(x)
+        loss = R.loss_stage2(z, y, dist)
+        opt.zero_grad(); loss.backward()
+    opt.step()
+    assert rm.flips <= 16, rm.flips
     assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
     _cmp_grads(eng, net, what='stage2')
     _cmp_state(eng, net, atol_w=2.5 * LR)
@@ -170,15 +168,17 @@ def test_step_fixmatch(eng):
     (xw, xs), y = _data(8, 5, views=2)
     act, neg = [0], [1, 2, 3, 4]
     pw, pwu = [3.0, 1.5, 4.0, 2.0, 2.5], [3.3, 1, 1, 1, 1]
-    net.train()
-    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
-    _, zw = net(xw); _, zs = net(xs)
-    assert len(R.fixmatch_mask(zw, neg, 8)) > 0, "test needs at least one confident row"
-    loss = R.loss_fixmatch(zw, zs, y, pw, pwu, act, neg, 8, 1, C_)
-    opt.zero_grad(); loss.backward(); opt.step()
     lo = torch.zeros(1, device="cuda")
     mask = [1.0 if c in act else 0.0 for c in range(C_)]
     eng.step_fixmatch(xw.cuda(), xs.cuda(), y.cuda(), pw, pwu, mask, 1, 8, lo)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    with relu_masks_from_engine(eng, 2, 8) as rm:
+        _, zw = net(xw); _, zs = net(xs)
+        assert len(R.fixmatch_mask(zw, neg, 8)) > 0, "test needs at least one confident row"
+        loss = R.loss_fixmatch(zw, zs, y, pw, pwu, act, neg, 8, 1, C_)
+        opt.zero_grad(); loss.backward()
+    opt.step()
     assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
     # fc weights x40 saturate sigmoids (p(1-p) ~ 1e-9): gradients are ill-conditioned there
     _cmp_grads(eng, net, rtol=2e-3, what='fixmatch')
@@ -235,23 +235,25 @@ def test_step_stage1_chestxray14_shape():
         act = [2, 5, 11]
         neg = [c for c in range(C) if c not in act]
         glob = copy.deepcopy(net).eval()
-        net.train()
-        opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
-        _, z1 = net(x1); _, z2 = net(x2)
-        with torch.no_grad():
-            _, g1 = glob(x1); _, g2 = glob(x2)
-        loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 3)
-        opt.zero_grad(); loss.backward(); opt.step()
         e.teacher_snapshot()
         lo = torch.zeros(1, device="cuda")
         mask = [1.0 if c in act else 0.0 for c in range(C)]
         e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 3, 8, lo)
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+        with relu_masks_from_engine(e, 2, 6):
+            _, z1 = net(x1); _, z2 = net(x2)
+            with torch.no_grad():
+                _, g1 = glob(x1); _, g2 = glob(x2)
+            loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 3)
+            opt.zero_grad(); loss.backward()
+        opt.step()
         assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
         gsd = spec.flat_to_state_dict("Resnet18", C, e.debug_get_grads(), np.zeros(e.ni, np.int64))
         for k, p in net.named_parameters():
             want = p.grad.numpy()
             err = float(np.abs(gsd[k] - want).max() / (np.abs(want).max() + 1e-12))
-            assert err < 1e-3, (k, err)
+            assert err < 2e-4, (k, err)
     finally:
         e.close()
 
