@@ -73,9 +73,11 @@ SYMBOLS = {
     "fm_fedavg_allreduce": (C.c_int, [_P, C.c_float]),
     "fm_fedavg_tao": (C.c_int, [_P, C.POINTER(C.c_double), C.c_double, _F, C.POINTER(C.c_double)]),
     "fm_fedavg_proto": (C.c_int, [_P, _P, C.c_double, _F, _P]),
+    "fm_profile_ops": (C.c_int, [_P, _I32, C.c_char_p, _I32]),
     "fm_debug_num_convs": (C.c_int, [_P]),
     "fm_debug_conv_info": (C.c_int, [_P, _I32, C.POINTER(_I32)]),
     "fm_debug_conv": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I32, _I32, _P]),
+    "fm_debug_pw": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "fm_debug_get_grads": (C.c_int, [_P, _P]),
     "fm_debug_activation": (C.c_int, [_P, _I32, _I32, _I32, _P, C.POINTER(_I32)]),
 }

@@ -22,6 +22,33 @@ __device__ __forceinline__ f32x4 ld4(const bf16* p)
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
+// NV consecutive channel quads per thread: one 16-B access per lane in either storage type
+// (NV = 1 for fp32 = 4 channels, NV = 2 for bf16 = 8 channels)
+template <typename T> struct VecOf { static constexpr int NV = 1; };
+template <> struct VecOf<bf16> { static constexpr int NV = 2; };
+template <int NV, typename T> __device__ __forceinline__ void ldv(const T* p, f32x4 (&v)[NV])
+{
+    if constexpr (NV == 1) v[0] = ld4(p);
+    else {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+        v[0] = __builtin_convertvector(__builtin_shufflevector(r, r, 0, 1, 2, 3), f32x4);
+        v[1] = __builtin_convertvector(__builtin_shufflevector(r, r, 4, 5, 6, 7), f32x4);
+    }
+}
+template <int NV, typename T> __device__ __forceinline__ void stv(T* p, const f32x4 (&v)[NV])
+{
+    if constexpr (NV == 1) st4(p, v[0]);
+    else {
+        const bf16x4 a = __builtin_convertvector(v[0], bf16x4), b = __builtin_convertvector(v[1], bf16x4);
+        *reinterpret_cast<bf16x8*>(p) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+// float vectors (scale, gate ...) read as NV quads
+template <int NV> __device__ __forceinline__ void ldf(const float* p, f32x4 (&v)[NV])
+{
+#pragma unroll
+    for (int h = 0; h < NV; ++h) v[h] = ld4(p + 4 * h);
+}
 #endif
 
 // ---------------------------------------------------------------------------

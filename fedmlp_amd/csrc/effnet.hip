@@ -16,55 +16,78 @@
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// FAST = bf16 storage: v_exp_f32 / v_rcp_f32 (1 ulp-class fp32 results feeding 8-bit mantissas) instead of the
+// IEEE expf / division sequences -- with 8 elements per 16 B the exact forms make these passes VALU-bound
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
-__device__ __forceinline__ f32x4 act_fwd(f32x4 v, int act)
+template <bool FAST> __device__ __forceinline__ float sigm_t(float v)
+{
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    else return 1.f / (1.f + expf(-v));
+}
+template <bool FAST = false> __device__ __forceinline__ f32x4 act_fwd(f32x4 v, int act)
 {
     if (act == 1) { for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f); }
-    else if (act == 2) { for (int k = 0; k < 4; ++k) v[k] = v[k] * sigm(v[k]); }
+    else if (act == 2) { for (int k = 0; k < 4; ++k) v[k] = v[k] * sigm_t<FAST>(v[k]); }
     return v;
 }
 // d act(v) / dv for act = swish
-__device__ __forceinline__ float swish_grad(float v)
+template <bool FAST = false> __device__ __forceinline__ float swish_grad(float v)
 {
-    const float s = sigm(v);
+    const float s = sigm_t<FAST>(v);
     return s * (1.f + v * (1.f - s));
 }
 
 // ------------------------------------------------------------ BN(+act) apply ---
-// out = act(y*scale+shift) * rowscale[img] + res      (per group scale/shift, any C % 4 == 0)
+// Every thread moves ONE 16-B piece per tensor: 4 channels in fp32, 8 in bf16 (NV quads; the mixed fp32-y /
+// bf16-activation form of the stem uses 4).  C % (4 NV) == 0 (channel counts are padded to 16).
+template <typename TY, typename TA> struct NvOf { static constexpr int NV = (VecOf<TY>::NV == 2 && VecOf<TA>::NV == 2) ? 2 : 1; };
+
+// out = act(y*scale+shift) * rowscale[img] + res      (per group scale/shift)
 template <typename TY, typename TA>
 __global__ void bnact_apply_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
                                    const float* __restrict__ shift, const TA* __restrict__ res,
                                    const float* __restrict__ rowscale, TA* __restrict__ out, int pix_per_group,
                                    int HW, int C, int act)
 {
+    constexpr int NV = NvOf<TY, TA>::NV;
     const int g = blockIdx.y;
-    const int Q = C >> 2;
-    const int64_t n4 = (int64_t)pix_per_group * Q;
+    const int Q = C / (4 * NV);
+    const int64_t nq = (int64_t)pix_per_group * Q;
     const size_t base = (size_t)g * pix_per_group * C;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int cq = (int)(i % Q);
-        const int64_t pix = i / Q;
-        const size_t o = base + (size_t)i * 4;
-        f32x4 v = ld4(y + o) * ld4(scale + g * C + cq * 4) +
-                  ld4(shift + g * C + cq * 4);
-        v = act_fwd(v, act);
-        if (rowscale) v = v * rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
-        if (res) v += ld4(res + o);
-        st4(out + o, v);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int cq = (int)(i % Q);
+    const int64_t pix = i / Q;
+    const size_t o = base + (size_t)i * (4 * NV);
+    f32x4 v[NV], sc[NV], sh[NV];
+    ldv<NV>(y + o, v);
+    ldf<NV>(scale + g * C + cq * 4 * NV, sc);
+    ldf<NV>(shift + g * C + cq * 4 * NV, sh);
+#pragma unroll
+    for (int h = 0; h < NV; ++h) v[h] = act_fwd<NV == 2>(v[h] * sc[h] + sh[h], act);
+    if (rowscale) {
+        const float rs = rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) v[h] = v[h] * rs;
     }
+    if (res) {
+        f32x4 r[NV];
+        ldv<NV>(res + o, r);
+#pragma unroll
+        for (int h = 0; h < NV; ++h) v[h] += r[h];
+    }
+    stv<NV>(out + o, v);
 }
-// ty / ta: storage type of the raw conv output y and of the activations (res, out): DT_F32 or DT_BF16
-// (the stem's y stays fp32 in the bf16 configuration: it comes from the fp32 implicit-GEMM kernel)
 template <typename T> static inline const T* cp(const void* p) { return reinterpret_cast<const T*>(p); }
 template <typename T> static inline T* mp(void* p) { return reinterpret_cast<T*>(p); }
 
+// ty / ta: storage type of the raw conv output y and of the activations (res, out): DT_F32 or DT_BF16
+// (the stem's y stays fp32 in the bf16 configuration: it comes from the fp32 implicit-GEMM kernel)
 void k_bnact_apply(const void* y, int ty, const float* scale, const float* shift, const void* res, const float* rowscale,
                    void* out, int ta, int groups, int pix_per_group, int HW, int C, int act, hipStream_t s)
 {
-    const int64_t n4 = (int64_t)pix_per_group * (C / 4);
-    const dim3 grid(cdiv(n4, 256), groups);
+    const int nv = (ty == DT_BF16 && ta == DT_BF16) ? 2 : 1;
+    const dim3 grid(cdiv((int64_t)pix_per_group * (C / (4 * nv)), 256), groups);
     if (ty == DT_F32 && ta == DT_F32)
         hipLaunchKernelGGL((bnact_apply_kernel<float, float>), grid, dim3(256), 0, s, cp<float>(y), scale, shift, cp<float>(res),
                            rowscale, mp<float>(out), pix_per_group, HW, C, act);
@@ -88,62 +111,85 @@ __global__ void chan_reduce_kernel(const TA* __restrict__ a, const TY* __restric
                                    int HW, int C, int mode, int act, const float* __restrict__ gate,
                                    const float* __restrict__ dsv)
 {
-    __shared__ f32x4 red[2][256];
+    constexpr int NV = NvOf<TY, TA>::NV;
+    __shared__ f32x4 red[2][NV][256];
     const int g = blockIdx.y, nblk = gridDim.x;
-    const int Q = C >> 2;
-    const int QT = Q < 256 ? Q : 256;          // quads handled concurrently
+    const int Q = C / (4 * NV);                // 16-B pieces per pixel
+    const int QT = Q < 256 ? Q : 256;          // pieces handled concurrently
     const int P = 256 / QT;                    // pixel lanes
     const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
     const bool active = pl < P;
     const int TP = 8 * P;                     // pixel tiles dealt round-robin to the blocks (DRAM locality)
     const size_t base = (size_t)g * pix_per_group * C;
     for (int cq = cq0; cq < Q; cq += QT) {
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = cq * 4 * NV;
+        f32x4 s1[NV], s2[NV];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) { s1[h] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (active) {
-            f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, sc = {0, 0, 0, 0}, sh = {0, 0, 0, 0};
+            f32x4 mu[NV], is[NV], sc[NV], sh[NV];
+#pragma unroll
+            for (int h = 0; h < NV; ++h) { mu[h] = is[h] = sc[h] = sh[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (mode == 1) {
-                mu = ld4(mean + g * C + cq * 4);
-                is = ld4(istd + g * C + cq * 4);
+                ldf<NV>(mean + g * C + c0, mu);
+                ldf<NV>(istd + g * C + c0, is);
                 if (act == 2) {
-                    sc = ld4(scale + g * C + cq * 4);
-                    sh = ld4(shift + g * C + cq * 4);
+                    ldf<NV>(scale + g * C + c0, sc);
+                    ldf<NV>(shift + g * C + c0, sh);
                 }
             }
             for (int t0 = blockIdx.x * TP; t0 < pix_per_group; t0 += nblk * TP)
 #pragma unroll 4
             for (int p = t0 + pl; p < min(pix_per_group, t0 + TP); p += P) {
-                const size_t o = base + (size_t)p * C + cq * 4;
+                const size_t o = base + (size_t)p * C + c0;
+                f32x4 yy[NV];
+                ldv<NV>(y + o, yy);
                 if (mode == 0) {
-                    const f32x4 v = ld4(y + o);
-                    s1 += v;
-                    s2 += v * v;
+#pragma unroll
+                    for (int h = 0; h < NV; ++h) { s1[h] += yy[h]; s2[h] += yy[h] * yy[h]; }
                 } else {
-                    f32x4 d = ld4(a + o);
-                    const f32x4 yy = ld4(y + o);
+                    f32x4 d[NV];
+                    ldv<NV>(a + o, d);
                     if (gate) {          // squeeze-excite backward folded in: d(a_d) = d(a_s)*gate + ds/HW
-                        const size_t io = ((size_t)g * (pix_per_group / HW) + p / HW) * C + cq * 4;
-                        d = d * ld4(gate + io) +
-                            ld4(dsv + io) * (1.f / (float)HW);
+                        const size_t io = ((size_t)g * (pix_per_group / HW) + p / HW) * C + c0;
+                        f32x4 gt[NV], dv[NV];
+                        ldf<NV>(gate + io, gt);
+                        ldf<NV>(dsv + io, dv);
+#pragma unroll
+                        for (int h = 0; h < NV; ++h) d[h] = d[h] * gt[h] + dv[h] * (1.f / (float)HW);
                     }
                     if (act == 2) {
-                        const f32x4 v = yy * sc + sh;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) d[k] *= swish_grad(v[k]);
+                        for (int h = 0; h < NV; ++h) {
+                            const f32x4 v = yy[h] * sc[h] + sh[h];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) d[h][k] *= swish_grad<NV == 2>(v[k]);
+                        }
                     }
-                    if (rowscale) d = d * rowscale[(size_t)g * (pix_per_group / HW) + p / HW];
-                    s1 += d;
-                    s2 += d * ((yy - mu) * is);
+                    if (rowscale) {
+                        const float rs = rowscale[(size_t)g * (pix_per_group / HW) + p / HW];
+#pragma unroll
+                        for (int h = 0; h < NV; ++h) d[h] = d[h] * rs;
+                    }
+#pragma unroll
+                    for (int h = 0; h < NV; ++h) { s1[h] += d[h]; s2[h] += d[h] * ((yy[h] - mu[h]) * is[h]); }
                 }
             }
         }
         __syncthreads();
-        if (active) { red[0][pl * QT + cq0] = s1; red[1][pl * QT + cq0] = s2; }
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < NV; ++h) { red[0][h][pl * QT + cq0] = s1[h]; red[1][h][pl * QT + cq0] = s2[h]; }
+        }
         __syncthreads();
         if (pl == 0) {
-            for (int k = 1; k < P; ++k) { s1 += red[0][k * QT + cq0]; s2 += red[1][k * QT + cq0]; }
-            float* o = part + ((size_t)(g * nblk + blockIdx.x) * 2) * C + cq * 4;
-            st4(o, s1);
-            st4(o + C, s2);
+            float* o = part + ((size_t)(g * nblk + blockIdx.x) * 2) * C + c0;
+#pragma unroll
+            for (int h = 0; h < NV; ++h) {
+                for (int k = 1; k < P; ++k) { s1[h] += red[0][h][k * QT + cq0]; s2[h] += red[1][h][k * QT + cq0]; }
+                st4(o + 4 * h, s1[h]);
+                st4(o + C + 4 * h, s2[h]);
+            }
         }
     }
 }
@@ -172,40 +218,58 @@ __global__ void bnact_bwd_apply_kernel(const TA* __restrict__ dz, const TY* __re
                                        TY* __restrict__ dy, int pix_per_group, int HW, int C, int act,
                                        const float* __restrict__ gate, const float* __restrict__ dsv)
 {
+    constexpr int NV = NvOf<TY, TA>::NV;
     const int g = blockIdx.y;
-    const int Q = C >> 2;
-    const int64_t n4 = (int64_t)pix_per_group * Q;
+    const int Q = C / (4 * NV);
+    const int64_t nq = (int64_t)pix_per_group * Q;
     const size_t base = (size_t)g * pix_per_group * C;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int cq = (int)(i % Q);
-        const int64_t pix = i / Q;
-        const size_t o = base + (size_t)i * 4;
-        f32x4 d = ld4(dz + o);
-        const f32x4 yy = ld4(y + o);
-        if (gate) {
-            const size_t io = ((size_t)g * (pix_per_group / HW) + pix / HW) * C + cq * 4;
-            d = d * ld4(gate + io) + ld4(dsv + io) * (1.f / (float)HW);
-        }
-        if (act == 2) {
-            const f32x4 v = yy * ld4(scale + g * C + cq * 4) +
-                            ld4(shift + g * C + cq * 4);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int c0 = (int)(i % Q) * 4 * NV;
+    const int64_t pix = i / Q;
+    const size_t o = base + (size_t)i * (4 * NV);
+    f32x4 d[NV], yy[NV];
+    ldv<NV>(dz + o, d);
+    ldv<NV>(y + o, yy);
+    if (gate) {
+        const size_t io = ((size_t)g * (pix_per_group / HW) + pix / HW) * C + c0;
+        f32x4 gt[NV], dv[NV];
+        ldf<NV>(gate + io, gt);
+        ldf<NV>(dsv + io, dv);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] *= swish_grad(v[k]);
-        }
-        if (rowscale) d = d * rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
-        st4(dy + o, ld4(ca + g * C + cq * 4) * d +
-                                            ld4(cb + g * C + cq * 4) * yy +
-                                            ld4(cc + g * C + cq * 4));
+        for (int h = 0; h < NV; ++h) d[h] = d[h] * gt[h] + dv[h] * (1.f / (float)HW);
     }
+    if (act == 2) {
+        f32x4 sc[NV], sh[NV];
+        ldf<NV>(scale + g * C + c0, sc);
+        ldf<NV>(shift + g * C + c0, sh);
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            const f32x4 v = yy[h] * sc[h] + sh[h];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[h][k] *= swish_grad<NV == 2>(v[k]);
+        }
+    }
+    if (rowscale) {
+        const float rs = rowscale[(size_t)g * (pix_per_group / HW) + pix / HW];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) d[h] = d[h] * rs;
+    }
+    f32x4 a_[NV], b_[NV], c_[NV];
+    ldf<NV>(ca + g * C + c0, a_);
+    ldf<NV>(cb + g * C + c0, b_);
+    ldf<NV>(cc + g * C + c0, c_);
+#pragma unroll
+    for (int h = 0; h < NV; ++h) d[h] = a_[h] * d[h] + b_[h] * yy[h] + c_[h];
+    stv<NV>(dy + o, d);
 }
 // dz is stored as the activations are (ta), y and the result dy as the raw conv output is (ty)
 void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const float* ca, const float* cb, const float* cc,
                        const float* scale, const float* shift, const float* rowscale, void* dy, int groups,
                        int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s)
 {
-    const int64_t n4 = (int64_t)pix_per_group * (C / 4);
-    const dim3 grid(cdiv(n4, 256), groups);
+    const int nv = (ty == DT_BF16 && ta == DT_BF16) ? 2 : 1;
+    const dim3 grid(cdiv((int64_t)pix_per_group * (C / (4 * nv)), 256), groups);
     if (ty == DT_F32 && ta == DT_F32)
         hipLaunchKernelGGL((bnact_bwd_apply_kernel<float, float>), grid, dim3(256), 0, s, cp<float>(dz), cp<float>(y), ca, cb, cc,
                            scale, shift, rowscale, mp<float>(dy), pix_per_group, HW, C, act, gate, dsv);
@@ -249,7 +313,7 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
     }
     if (scale) {
         acc = acc * ld4(scale + cq * 4) + ld4(shift + cq * 4);
-        acc = act_fwd(acc, act);
+        acc = act_fwd<VecOf<T>::NV == 2>(acc, act);
     }
     st4(y + i * 4, acc);
 }
@@ -306,7 +370,7 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const T* __restrict__ x
     for (int j = 0; j < 4; ++j) {
         if (ow0 + j >= Wo) continue;
         f32x4 v = acc[j];
-        if (scale) v = act_fwd(v * sc + sh, act);
+        if (scale) v = act_fwd<VecOf<T>::NV == 2>(v * sc + sh, act);
         st4(y + ((size_t)(img * Ho + oh) * Wo + ow0 + j) * C + cq * 4, v);
     }
 }
@@ -388,7 +452,7 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ 
         for (int j = 0; j < 4; ++j) {
             if (ow0 + j >= Wo) continue;
             f32x4 v = acc[r][j];
-            if (scale) v = act_fwd(v * sc + sh, act);
+            if (scale) v = act_fwd<VecOf<T>::NV == 2>(v * sc + sh, act);
             st4(y + ((size_t)(img * Ho + oh0 + r) * Wo + ow0 + j) * C + cq * 4, v);
         }
     }
@@ -767,45 +831,61 @@ void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, int imgs, in
 
 // per-image channel sums over a chunk of pixels: part[img][chunk][C] = sum_p a[p][c] (* b[p][c]).
 // `tsel` 1 / 2: operand a / b is a raw BN input and is read as swish(v*scale[g]+shift[g]), g = img/ipg
-// (the post-BN activation is never materialised).
+// (the post-BN activation is never materialised).  One 16-B piece per thread and tensor (NV quads).
 template <typename T>
 __global__ __launch_bounds__(256) void chan_pool_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                         float* __restrict__ part, int HW, int C, int QT, int P,
                                                         int tsel, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int ipg)
 {
-    __shared__ f32x4 red[256];
+    constexpr int NV = VecOf<T>::NV;
+    __shared__ f32x4 red[NV][256];
     const int img = blockIdx.y, nch = gridDim.x;
-    const int Q = C >> 2;
+    const int Q = C / (4 * NV);
     const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
     const int chunk = (HW + nch - 1) / nch;
     const int pb = blockIdx.x * chunk, pe = min(HW, pb + chunk);
     const int g = tsel ? img / ipg : 0;
     for (int cq = cq0; cq < Q; cq += QT) {
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = cq * 4 * NV;
+        f32x4 s1[NV], sc[NV], sh[NV];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) { s1[h] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[h] = f32x4{1.f, 1.f, 1.f, 1.f}; sh[h] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (tsel) {
-            sc = ld4(scale + g * C + cq * 4);
-            sh = ld4(shift + g * C + cq * 4);
+            ldf<NV>(scale + g * C + c0, sc);
+            ldf<NV>(shift + g * C + c0, sh);
         }
 #pragma unroll 4
         for (int p = pb + pl; p < pe; p += P) {
-            const size_t o = ((size_t)img * HW + p) * C + cq * 4;
-            f32x4 v = ld4(a + o);
-            if (tsel == 1) v = act_fwd(v * sc + sh, 2);
-            if (b) {
-                f32x4 w = ld4(b + o);
-                if (tsel == 2) w = act_fwd(w * sc + sh, 2);
-                v = v * w;
+            const size_t o = ((size_t)img * HW + p) * C + c0;
+            f32x4 v[NV];
+            ldv<NV>(a + o, v);
+            if (tsel == 1) {
+#pragma unroll
+                for (int h = 0; h < NV; ++h) v[h] = act_fwd<NV == 2>(v[h] * sc[h] + sh[h], 2);
             }
-            s1 += v;
+            if (b) {
+                f32x4 w[NV];
+                ldv<NV>(b + o, w);
+#pragma unroll
+                for (int h = 0; h < NV; ++h) {
+                    if (tsel == 2) w[h] = act_fwd<NV == 2>(w[h] * sc[h] + sh[h], 2);
+                    v[h] = v[h] * w[h];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < NV; ++h) s1[h] += v[h];
         }
         __syncthreads();
-        red[threadIdx.x] = s1;
+#pragma unroll
+        for (int h = 0; h < NV; ++h) red[h][threadIdx.x] = s1[h];
         __syncthreads();
         if (pl == 0) {
-            for (int k = 1; k < P; ++k) s1 += red[k * QT + cq0];
-            st4(part + ((size_t)img * nch + blockIdx.x) * C + cq * 4, s1);
+#pragma unroll
+            for (int h = 0; h < NV; ++h) {
+                for (int k = 1; k < P; ++k) s1[h] += red[h][k * QT + cq0];
+                st4(part + ((size_t)img * nch + blockIdx.x) * C + c0 + 4 * h, s1[h]);
+            }
         }
     }
 }
@@ -814,7 +894,7 @@ void k_chan_pool(const void* a, const void* b, int dt, float* part, int imgs, in
                  const float* shift, int ipg, hipStream_t s)
 {
     int QT, P, yt;
-    dw_map(C, QT, P, yt);
+    dw_map(dt == DT_BF16 ? C / 2 : C, QT, P, yt);          // 16-B pieces per pixel: C/4 (fp32) or C/8 (bf16)
     const dim3 grid(chan_pool_chunks(HW), imgs), blk(QT * P);
     if (dt == DT_F32)
         hipLaunchKernelGGL((chan_pool_kernel<float>), grid, blk, 0, s, cp<float>(a), cp<float>(b), part, HW, C, QT, P, tsel, scale, shift, ipg);
@@ -873,37 +953,44 @@ void k_se_fwd(const void* a, int dt, const float* scale, const float* shift, int
 // out = A * gate[img][c], A = a or (scale != null) swish(a*scale[g]+shift[g]) with g = img/ipg
 template <typename T>
 __global__ void se_scale_kernel(const T* __restrict__ a, const float* __restrict__ gate, T* __restrict__ out,
-                                int64_t n4, int HW, int C, const float* __restrict__ scale,
+                                int64_t nq, int HW, int C, const float* __restrict__ scale,
                                 const float* __restrict__ shift, int ipg)
 {
-    const int Q = C >> 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const int cq = (int)(i % Q);
-        const int64_t img = i / Q / HW;
-        f32x4 v = ld4(a + i * 4);
-        if (scale) {
-            const int g = (int)(img / ipg);
-            v = act_fwd(v * ld4(scale + g * C + cq * 4) +
-                            ld4(shift + g * C + cq * 4), 2);
-        }
-        st4(out + i * 4, v * ld4(gate + img * C + cq * 4));
+    constexpr int NV = VecOf<T>::NV;
+    const int Q = C / (4 * NV);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int c0 = (int)(i % Q) * 4 * NV;
+    const int64_t img = i / Q / HW;
+    f32x4 v[NV], gt[NV];
+    ldv<NV>(a + i * (4 * NV), v);
+    if (scale) {
+        const int g = (int)(img / ipg);
+        f32x4 sc[NV], sh[NV];
+        ldf<NV>(scale + g * C + c0, sc);
+        ldf<NV>(shift + g * C + c0, sh);
+#pragma unroll
+        for (int h = 0; h < NV; ++h) v[h] = act_fwd<NV == 2>(v[h] * sc[h] + sh[h], 2);
     }
+    ldf<NV>(gate + img * C + c0, gt);
+#pragma unroll
+    for (int h = 0; h < NV; ++h) v[h] = v[h] * gt[h];
+    stv<NV>(out + i * (4 * NV), v);
 }
 void k_se_scale(const void* a, int dt, const float* scale, const float* shift, int ipg, const float* gate, void* out, int imgs,
                 int HW, int C, hipStream_t s)
 {
-    const int64_t n4 = (int64_t)imgs * HW * (C / 4);
-    const dim3 grid(cdiv(n4, 256));
+    const int64_t nq = (int64_t)imgs * HW * (C / (dt == DT_BF16 ? 8 : 4));
+    const dim3 grid(cdiv(nq, 256));
     if (dt == DT_F32)
-        hipLaunchKernelGGL((se_scale_kernel<float>), grid, dim3(256), 0, s, cp<float>(a), gate, mp<float>(out), n4, HW, C, scale, shift, ipg);
+        hipLaunchKernelGGL((se_scale_kernel<float>), grid, dim3(256), 0, s, cp<float>(a), gate, mp<float>(out), nq, HW, C, scale, shift, ipg);
     else
-        hipLaunchKernelGGL((se_scale_kernel<bf16>), grid, dim3(256), 0, s, cp<bf16>(a), gate, mp<bf16>(out), n4, HW, C, scale, shift, ipg);
+        hipLaunchKernelGGL((se_scale_kernel<bf16>), grid, dim3(256), 0, s, cp<bf16>(a), gate, mp<bf16>(out), nq, HW, C, scale, shift, ipg);
 }
 
 // backward, one block per image:  dgs[c] = sum_hw dout*a ; dgp = dgs*g(1-g) ; dr = W2^T dgp ;
 // drp = dr*swish'(r_pre) ; ds = W1^T drp.  Stores dgp [imgs][C], drp [imgs][Cs], ds [imgs][C].
-__global__ void se_bwd_kernel(const float* __restrict__ pool, int nch,
+__global__ void se_bwd_kernel(const float* __restrict__ pool, int nch, int pstride,
                               const float* __restrict__ gate, const float* __restrict__ rpre,
                               const float* __restrict__ W1, const float* __restrict__ W2, float* __restrict__ dgp,
                               float* __restrict__ drp, float* __restrict__ ds, int HW, int C, int Cs)
@@ -914,7 +1001,7 @@ __global__ void se_bwd_kernel(const float* __restrict__ pool, int nch,
     const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float t = 0.f;
-        for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * C + c];
+        for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * pstride + c];
         const float g = gate[(size_t)img * C + c];
         t *= g * (1.f - g);
         g_[c] = t;
@@ -944,8 +1031,136 @@ void k_se_bwd(const void* dout, const void* a, int dt, const float* scale, const
               int imgs, int HW, int C, int Cs, hipStream_t s)
 {
     k_chan_pool(dout, a, dt, pool_ws, imgs, HW, C, scale ? 2 : 0, scale, shift, ipg, s);
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW), C,
                        gate, rpre, W1, W2, dgp, drp, ds, HW, C, Cs);
+}
+
+// ---- squeeze-excite backward + BN1 backward sums from ONE pass over (d a_s, y_d) ------------------------
+// The BN1 backward needs S1 = sum dyh and S2 = sum dyh*xh over the batch with dyh = (d*gate + ds/HW)*sg
+// (d = d a_s, sg = swish'(v), v = y*scale+shift, xh = (y-mean)*istd), but ds itself comes out of the squeeze-excite
+// backward, which needs the per-image sums of d*a_d first.  gate and ds are constant over an image, so
+//   S1 = sum_img gate*P1 + ds/HW*Q1,  S2 = sum_img gate*P2 + ds/HW*Q2
+// with per-image sums P1 = sum d*sg, P2 = sum d*sg*xh, Q1 = sum sg, Q2 = sum sg*xh.  All five per-image sums
+// (R = sum d*a_d for the squeeze-excite backward included) are taken in the single pass below; the separate
+// reduction pass of the BN1 backward (two more reads of the block's largest gradient tensors) is gone.
+// part layout [img][chunk][5][C].
+template <typename T>
+__global__ __launch_bounds__(256) void chan_pool5_kernel(const T* __restrict__ d, const T* __restrict__ y,
+                                                         float* __restrict__ part, int HW, int C, int QT, int P,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ istd,
+                                                         int ipg)
+{
+    constexpr int NV = VecOf<T>::NV;
+    constexpr bool FAST = NV == 2;
+    __shared__ f32x4 red[5][NV][256];
+    const int img = blockIdx.y, nch = gridDim.x;
+    const int Q = C / (4 * NV);
+    const int cq0 = threadIdx.x % QT, pl = threadIdx.x / QT;
+    const int chunk = (HW + nch - 1) / nch;
+    const int pb = blockIdx.x * chunk, pe = min(HW, pb + chunk);
+    const int g = img / ipg;
+    for (int cq = cq0; cq < Q; cq += QT) {
+        const int c0 = cq * 4 * NV;
+        f32x4 acc[5][NV], sc[NV], sh[NV], mu[NV], is[NV];
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int h = 0; h < NV; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ldf<NV>(scale + g * C + c0, sc);
+        ldf<NV>(shift + g * C + c0, sh);
+        ldf<NV>(mean + g * C + c0, mu);
+        ldf<NV>(istd + g * C + c0, is);
+#pragma unroll 2
+        for (int p = pb + pl; p < pe; p += P) {
+            const size_t o = ((size_t)img * HW + p) * C + c0;
+            f32x4 dd[NV], yy[NV];
+            ldv<NV>(d + o, dd);
+            ldv<NV>(y + o, yy);
+#pragma unroll
+            for (int h = 0; h < NV; ++h) {
+                const f32x4 v = yy[h] * sc[h] + sh[h];
+                const f32x4 xh = (yy[h] - mu[h]) * is[h];
+                f32x4 ad, sg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sgm = sigm_t<FAST>(v[k]);
+                    ad[k] = v[k] * sgm;
+                    sg[k] = sgm * (1.f + v[k] * (1.f - sgm));
+                }
+                const f32x4 dsg = dd[h] * sg;
+                acc[0][h] += dd[h] * ad;
+                acc[1][h] += dsg;
+                acc[2][h] += dsg * xh;
+                acc[3][h] += sg;
+                acc[4][h] += sg * xh;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int h = 0; h < NV; ++h) red[t][h][threadIdx.x] = acc[t][h];
+        __syncthreads();
+        // the P pixel lanes of a (sum, piece) pair are folded by ONE thread each: 5 NV QT folds spread over the block
+        for (int j = threadIdx.x; j < 5 * NV * QT; j += blockDim.x) {
+            const int t = j / (NV * QT), rem = j - t * NV * QT, h = rem / QT, q = rem - h * QT;
+            f32x4 v = red[t][h][q];
+            for (int k = 1; k < P; ++k) v += red[t][h][k * QT + q];
+            st4(part + (((size_t)img * nch + blockIdx.x) * 5 + t) * C + (cq - cq0 + q) * 4 * NV + 4 * h, v);
+        }
+    }
+}
+// BN1-backward sums from the per-image partials: part_out[g][0][2][C]; block = (64 channels, group), 4 image lanes
+__global__ void bn1_sums_kernel(const float* __restrict__ pool5, int nch, const float* __restrict__ gate,
+                                const float* __restrict__ ds, float* __restrict__ out, int HW, int C, int ipg)
+{
+    __shared__ float red[2][4][64];
+    const int g = blockIdx.y, cl = threadIdx.x & 63, il = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const float inv = 1.f / (float)HW;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int i = il; i < ipg; i += 4) {
+            const size_t img = (size_t)g * ipg + i;
+            float p1 = 0.f, p2 = 0.f, q1 = 0.f, q2 = 0.f;
+            for (int k = 0; k < nch; ++k) {
+                const float* pp = pool5 + ((img * nch + k) * 5) * C + c;
+                p1 += pp[C]; p2 += pp[2 * C]; q1 += pp[3 * C]; q2 += pp[4 * C];
+            }
+            const float gt = gate[img * C + c], dv = ds[img * C + c] * inv;
+            s1 += gt * p1 + dv * q1;
+            s2 += gt * p2 + dv * q2;
+        }
+    red[0][il][cl] = s1; red[1][il][cl] = s2;
+    __syncthreads();
+    if (il == 0 && c < C) {
+        out[(size_t)g * 2 * C + c] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
+        out[(size_t)g * 2 * C + C + c] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
+    }
+}
+// pool_ws: [imgs][chunks][5][C]; writes dgp/drp/ds like k_se_bwd and the BN1-backward sums to bn_part [groups][1][2][C]
+void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, const float* shift, const float* mean,
+                  const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
+                  const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
+                  hipStream_t s)
+{
+    int QT, P, yt;
+    dw_map(dt == DT_BF16 ? C / 2 : C, QT, P, yt);
+    // fewer, longer pixel chunks than the forward pooling: the five-way fold at the end of a block is amortised over
+    // >= 512 pixels, and imgs x nch blocks still fill the chip
+    const int nch = std::max(1, std::min(chan_pool_chunks(HW), std::max(HW / 512, imgs >= 512 ? 1 : 2)));
+    const dim3 grid(nch, imgs), blk(QT * P);
+    if (dt == DT_F32)
+        hipLaunchKernelGGL((chan_pool5_kernel<float>), grid, blk, 0, s, cp<float>(dout), cp<float>(y), pool_ws, HW, C, QT, P, scale,
+                           shift, mean, istd, ipg);
+    else
+        hipLaunchKernelGGL((chan_pool5_kernel<bf16>), grid, blk, 0, s, cp<bf16>(dout), cp<bf16>(y), pool_ws, HW, C, QT, P, scale,
+                           shift, mean, istd, ipg);
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, nch, 5 * C, gate, rpre, W1,
+                       W2, dgp, drp, ds, HW, C, Cs);
+    hipLaunchKernelGGL(bn1_sums_kernel, dim3(cdiv(C, 64), imgs / ipg), dim3(256), 0, s, pool_ws, nch, gate, ds, bn_part, HW, C,
+                       ipg);
 }
 
 // dW2[c][j] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]

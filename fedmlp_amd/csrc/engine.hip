@@ -23,6 +23,7 @@
 #include "comm.h"
 #include "common.h"
 #include "kernels.h"
+#include "pwconv.h"
 
 static thread_local std::string g_err;
 const char* fm_last_error(void) { return g_err.c_str(); }
@@ -66,6 +67,7 @@ struct Conv {
     int ncls = 0;
     DgradClass cls[4];
     int bn;                   // index of the BatchNorm that follows
+    long long wb_off = -1, wbt_off = -1;   // bf16 shadow of a 1x1 conv's weights [cout_p][cin_p] / transposed (bf16 mode)
     double macs_per_img;      // algorithmic MACs (real k, real cin)
     float* y = nullptr;       // raw conv output (train) [max_images][hout][wout][cout]
 };
@@ -104,6 +106,7 @@ struct StateEntry {           // one state_dict entry, in reference key order
 };
 
 struct EvPair { hipEvent_t a, b; int family; double flops; };
+struct OpEv { hipEvent_t a, b; int id; };
 
 }  // namespace
 
@@ -154,6 +157,13 @@ struct fm_engine {
     int sel_cap = 0;
     // profiling
     bool prof = false, prof_fail = false;
+    // per-op timing (FM profile leg of tools/op_profile.py): label = "<op>@<block>"
+    bool oprof = false;
+    int ctx = -1;
+    std::vector<std::string> op_names;
+    std::vector<double> op_ms;
+    std::vector<int64_t> op_n;
+    std::vector<OpEv> opevs;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ev_free;
     double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
@@ -170,6 +180,14 @@ struct fm_engine {
     double* comm_buf = nullptr;       // device scratch of the small all-reduces
     size_t comm_buf_n = 0;
     int precision = 0;                // 0 fp32 activations, 1 bf16 activations (EfficientNet-B0 only)
+    int dt = DT_F32;                  // storage type of activations / their gradients (DT_F32 or DT_BF16)
+    bf16 *wb = nullptr, *twb = nullptr;   // bf16 weight shadows of the student / the teacher (1x1 convs, W and W^T)
+    size_t wb_numel = 0;
+    CastJob* cast_jobs = nullptr;
+    int n_cast_jobs = 0, n_cast_blocks = 0;
+    bool wb_dirty = true, twb_dirty = true;
+    bool fuse_gate = false;           // squeeze-excite gate applied on the project conv's operand load (a_s never stored)
+    float* stem_dy = nullptr;         // bf16 mode: fp32 gradient of the stem's raw output (the stem conv stays fp32)
 };
 
 namespace {
@@ -186,6 +204,14 @@ int dalloc(fm_engine* e, T** p, size_t n)
 #define DALLOC(p, n)                                   \
     do {                                               \
         int rc_ = dalloc(e, &(p), (n));                \
+        if (rc_ != FM_OK) return rc_;                  \
+    } while (0)
+
+// activation buffer of n elements in the engine's storage type (kept behind float* handles)
+int aalloc(fm_engine* e, float** p, size_t n) { return dalloc(e, p, e->precision ? (n + 1) / 2 : n); }
+#define AALLOC(p, n)                                   \
+    do {                                               \
+        int rc_ = aalloc(e, &(p), (n));                \
         if (rc_ != FM_OK) return rc_;                  \
     } while (0)
 
@@ -274,6 +300,24 @@ int build_tables(fm_engine* e)
             blk += (int)(((size_t)c.cin_p * d.taps.n * c.cout_p + 255) / 256);
             jobs.push_back(j);
         }
+    if (e->precision) {        // bf16 shadows (W and W^T) of every 1x1 convolution
+        std::vector<CastJob> cj;
+        long long off = 0;
+        int cb = 0;
+        for (auto& c : e->convs) {
+            if (c.k != 1) continue;
+            const long long n = (long long)c.cout_p * c.cin_p;
+            c.wb_off = off; c.wbt_off = off + n;
+            cj.push_back({(long long)c.w_off, c.wb_off, c.wbt_off, c.cout_p, c.cin_p, cb});
+            off += 2 * n;
+            cb += (int)((n + 255) / 256);
+        }
+        e->wb_numel = (size_t)off;
+        e->n_cast_jobs = (int)cj.size(); e->n_cast_blocks = cb;
+        DALLOC(e->cast_jobs, cj.size());
+        HIPCHK(hipMemcpy(e->cast_jobs, cj.data(), cj.size() * sizeof(CastJob), hipMemcpyHostToDevice));
+        DALLOC(e->wb, e->wb_numel); DALLOC(e->twb, e->wb_numel);
+    }
     e->n_pack_jobs = (int)jobs.size();
     e->n_pack_blocks = blk;
     DALLOC(e->pack_jobs, jobs.size());
@@ -472,8 +516,10 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->x4, B * e->H * e->W * 4);
     size_t max_stats = 0, max_slab = 0;
     for (auto& c : e->convs) {
-        DALLOC(c.y, B * c.hout * c.wout * c.cout_p);
-        const size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout_p) - 1) / igemm_tile_n(c.cout_p) + 2;
+        if (c.cin == 3) DALLOC(c.y, B * c.hout * c.wout * c.cout_p);       // the stem's raw output is fp32 in every mode
+        else AALLOC(c.y, B * c.hout * c.wout * c.cout_p);
+        size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout_p) - 1) / igemm_tile_n(c.cout_p) + 2;
+        if (e->precision) tiles = std::max<size_t>(tiles, B * c.hout * c.wout / 128 + 4);   // pw_blocks(): >= 128 pixels per block
         max_stats = std::max(max_stats, (tiles + 2 * 32) * 2 * c.cout_p);   // + folded partials
         max_slab = std::max(max_slab, c.w_numel);
     }
@@ -493,12 +539,13 @@ int alloc_workspaces(fm_engine* e)
         DALLOC(e->GA, pooled); DALLOC(e->GB, pooled); DALLOC(e->GC, pooled); DALLOC(e->GD, pooled); DALLOC(e->GE, pooled);
     } else {
         size_t g_io = B * c0.hout * c0.wout * c0.cout_p, t_small = 0, t_mid = 0, t_big = 0, max_ce = 0, max_cs = 0;
-        DALLOC(e->a0, g_io);
+        AALLOC(e->a0, g_io);
+        if (e->precision) DALLOC(e->stem_dy, g_io);
         for (auto& m : e->mbs) {
             const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
-            if (m.c_exp >= 0) DALLOC(m.a_e, nin * m.ce_p);
-            DALLOC(m.y_d, nout * m.ce_p); DALLOC(m.a_s, nout * m.ce_p);
-            DALLOC(m.out, nout * m.cout_p);
+            if (m.c_exp >= 0) AALLOC(m.a_e, nin * m.ce_p);
+            AALLOC(m.y_d, nout * m.ce_p); AALLOC(m.a_s, nout * m.ce_p);
+            AALLOC(m.out, nout * m.cout_p);
             DALLOC(m.sq, B * m.ce_p); DALLOC(m.rpre, B * m.cs); DALLOC(m.gate, B * m.ce_p);
             g_io = std::max(g_io, std::max(nin * m.cin_p, nout * m.cout_p));
             t_small = std::max(t_small, nout * m.cout_p);
@@ -508,10 +555,10 @@ int alloc_workspaces(fm_engine* e)
         }
         const Conv& chd = e->convs[e->c_head];
         t_mid = std::max(t_mid, B * chd.hout * chd.wout * chd.cout_p);
-        DALLOC(e->GA, g_io); DALLOC(e->GB, g_io);
-        DALLOC(e->T_small, t_small); DALLOC(e->T_mid, t_mid); DALLOC(e->T_big, t_big);
+        AALLOC(e->GA, g_io); AALLOC(e->GB, g_io);
+        AALLOC(e->T_small, t_small); AALLOC(e->T_mid, t_mid); AALLOC(e->T_big, t_big);
         DALLOC(e->se_dgp, B * max_ce); DALLOC(e->se_drp, B * max_cs); DALLOC(e->se_ds, B * max_ce);
-        DALLOC(e->se_pool, B * 16 * max_ce);
+        DALLOC(e->se_pool, B * 16 * 5 * max_ce);       // [imgs][<=16 chunks][5 sums][C]
         DALLOC(e->hfeat, B * e->D);
     }
     DALLOC(e->ws_stats, max_stats);
@@ -558,11 +605,50 @@ struct ProfScope {
     }
 };
 
+struct OpScope {
+    fm_engine* e; hipEvent_t a{}, b{}; int id = -1; bool on;
+    OpScope(fm_engine* e_, const char* op) : e(e_), on(e_->oprof)
+    {
+        if (!on) return;
+        char lab[96];
+        snprintf(lab, sizeof lab, "%s@%d", op, e->ctx);
+        for (size_t i = 0; i < e->op_names.size(); ++i)
+            if (e->op_names[i] == lab) { id = (int)i; break; }
+        if (id < 0) { id = (int)e->op_names.size(); e->op_names.push_back(lab); e->op_ms.push_back(0); e->op_n.push_back(0); }
+        a = get_ev(e); b = get_ev(e);
+        on = a && b && hipEventRecord(a, e->st) == hipSuccess;
+    }
+    ~OpScope()
+    {
+        if (on && hipEventRecord(b, e->st) == hipSuccess) e->opevs.push_back({a, b, id});
+    }
+};
+#define OP(name) OpScope os_(e, name)
+
 // ---- layer launchers --------------------------------------------------------------
+// operand prologue of a pointwise conv (bf16 mode): Xe = swish(X*psc+psh)*gate, psc == null: X*gate
+struct Prologue { const float* psc; const float* psh; const float* gate; };
+
+const bf16* shadow_of(fm_engine* e, const float* S) { return S == e->tstate ? e->twb : e->wb; }
+
 void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, int imgs, int groups,
-              const float* scale, const float* shift, const float* res, int relu, float* stats)
+              const float* scale, const float* shift, const float* res, int relu, float* stats,
+              const Prologue* pro = nullptr)
 {
     const Conv& c = e->convs[ci];
+    if (e->precision && c.k == 1) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
+        PwParams q{};
+        q.W = shadow_of(e, S) + c.wb_off;
+        q.X = reinterpret_cast<const bf16*>(x); q.Y = reinterpret_cast<bf16*>(y);
+        q.M = c.cout_p; q.K = c.cin_p;
+        q.npix = (imgs / groups) * c.hout * c.wout; q.groups = groups;
+        q.scale = scale; q.shift = shift; q.res = reinterpret_cast<const bf16*>(res); q.act = relu;
+        q.stats = stats;
+        if (pro && pro->gate) { q.psc = pro->psc; q.psh = pro->psh; q.gate = pro->gate; }
+        q.HW = c.hout * c.wout;
+        launch_pw_conv(q, e->st);
+        return;
+    }
     IgemmParams p{};
     p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
     if (c.cin == 3) { p.stem_kw = c.k; p.stem_pad = c.pad; p.stem_h2 = c.kw_p == 8 ? 1 : 0; }
@@ -586,9 +672,10 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     launch_igemm(p, groups, e->st);
 }
 
-int stats_tiles(fm_engine* e, int ci, int imgs_per_group)
+int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
 {
     const Conv& c = e->convs[ci];
+    if (e->precision && c.k == 1) return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin_p);
     const int bn = igemm_tile_n(c.cout_p);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
@@ -599,6 +686,17 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
                 bool acc_cls0)
 {
     Conv& c = e->convs[ci];
+    if (e->precision && c.k == 1) {          // dX = dY W: the same streaming kernel with the transposed bf16 shadow
+        PwParams q{};
+        q.W = shadow_of(e, S) + c.wbt_off;
+        q.X = reinterpret_cast<const bf16*>(dy); q.Y = reinterpret_cast<bf16*>(dx);
+        q.M = c.cin_p; q.K = c.cout_p;
+        q.npix = imgs * c.hout * c.wout; q.groups = 1;
+        q.res = reinterpret_cast<const bf16*>(res);
+        q.HW = c.hout * c.wout;
+        launch_pw_conv(q, e->st);
+        return;
+    }
     for (int k = 0; k < c.ncls; ++k) {
         DgradClass& d = c.cls[k];
         IgemmParams p{};
@@ -623,9 +721,21 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
     }
 }
 
-void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs)
+void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs, const Prologue* pro = nullptr,
+                int pix_per_group = 0)
 {
     const Conv& c = e->convs[ci];
+    if (e->precision && c.k == 1) {
+        PwWgradParams q{};
+        q.dY = reinterpret_cast<const bf16*>(dy); q.X = reinterpret_cast<const bf16*>(x);
+        q.slab = e->ws_slab; q.M = c.cout_p; q.K = c.cin_p; q.npix = imgs * c.hout * c.wout;
+        if (pro && pro->gate) { q.psc = pro->psc; q.psh = pro->psh; q.gate = pro->gate; }
+        q.HW = c.hout * c.wout; q.pix_per_group = pix_per_group ? pix_per_group : q.npix;
+        const int sk = launch_pw_wgrad(q, e->slab_floats, e->st);
+        if (sk > 0) k_reduce_slabs(e->ws_slab, e->grad + c.w_off, sk, (int64_t)c.w_numel, e->st);
+        else g_err = "pw_wgrad: shape not handled";
+        return;
+    }
     WgradParams p{};
     p.dY = dy; p.X = x; p.slab = e->ws_slab; p.tab = c.tab; p.zeros = e->zeros;
     p.M = c.cout_p; p.Nw = c.Kw;
@@ -667,7 +777,7 @@ void bn_fwd_finalize(fm_engine* e, int ci, int groups, int imgs_per_group)
     const Conv& c = e->convs[ci];
     const int bi = c.bn;
     Bn& b = e->bns[bi];
-    k_bn_finalize(e->ws_stats, groups, stats_tiles(e, ci, imgs_per_group), b.C, imgs_per_group * c.hout * c.wout,
+    k_bn_finalize(e->ws_stats, groups, stats_tiles(e, ci, imgs_per_group, groups), b.C, imgs_per_group * c.hout * c.wout,
                   e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
                   e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale,
                   b.shift, e->bn_eps, e->bn_mom, e->st);
@@ -727,7 +837,7 @@ void forward_train(fm_engine* e, int groups, int B)
         cur = blk.out;
     }
     const Conv& cl = e->convs[e->blocks.back().c2];
-    k_avgpool(cur, e->feat, imgs, cl.hout * cl.wout, 512, e->st);
+    k_avgpool(cur, DT_F32, e->feat, imgs, cl.hout * cl.wout, 512, e->st);
     k_fc_fwd(e->feat, S + e->off_fcw, S + e->off_fcb, e->logits, imgs, 512, e->C, e->st);
     e->ev_dirty = true;      // running stats moved
 }
@@ -759,7 +869,7 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
         cur = blk.out;
     }
     const Conv& cl = e->convs[e->blocks.back().c2];
-    k_avgpool(cur, feat, imgs, cl.hout * cl.wout, 512, e->st);
+    k_avgpool(cur, DT_F32, feat, imgs, cl.hout * cl.wout, 512, e->st);
     k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, 512, e->C, e->st);
 }
 
@@ -767,8 +877,15 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
 void ensure_packed(fm_engine* e)
 {
     if (!e->wpack_dirty) return;
-    if (e->n_pack_jobs) k_pack_dgrad_all(e->state, e->pack_jobs, e->n_pack_jobs, e->n_pack_blocks, e->st);
+    if (e->precision) launch_cast_weights(e->state, e->wb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
+    else if (e->n_pack_jobs) k_pack_dgrad_all(e->state, e->pack_jobs, e->n_pack_jobs, e->n_pack_blocks, e->st);
     e->wpack_dirty = false;
+}
+void ensure_teacher_shadow(fm_engine* e)
+{
+    if (!e->precision || !e->twb_dirty) return;
+    launch_cast_weights(e->tstate, e->twb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
+    e->twb_dirty = false;
 }
 
 // optimizer.step(): one fused kernel over the whole trainable arena (torch Adam with coupled L2)
@@ -790,7 +907,7 @@ void backward_and_step(fm_engine* e, int groups, int B)
     const int imgs = groups * B;
     const float* S = e->state;
     const Conv& cl = e->convs[e->blocks.back().c2];
-    k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, nullptr, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, imgs,
+    k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, nullptr, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, DT_F32, imgs,
              512, e->C, cl.hout * cl.wout, e->st);
     float *ga = e->GA, *ge = e->GE;
     for (int b = (int)e->blocks.size() - 1; b >= 0; --b) {
@@ -820,12 +937,17 @@ void backward_and_step(fm_engine* e, int groups, int B)
 }
 
 // =============================== EfficientNet-B0 graph =================================
+// Squeeze-excite gate on the project conv's operand load: only where the conv reads its input once or twice
+// (<= 2 M-tiles).  The late blocks (K = 672, 1152: 32-row M-tiles, 6-10 of them) would redo the BN + Swish
+// prologue per M-tile on tensors that are tiny anyway: they keep the materialised a_s.
+bool fuse_for(fm_engine* e, const MBConv& m) { return e->fuse_gate && pw_tiles_m(m.cout_p, m.ce_p) <= 2; }
+
 // BN over an arbitrary NHWC tensor (depthwise output): statistics by chan_reduce, then the same finalize
 void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per_group, int HW)
 {
     Bn& b = e->bns[bi];
-    k_chan_reduce(nullptr, y, nullptr, nullptr, nullptr, nullptr, nullptr, e->ws_part, groups, pix_per_group, HW, b.C,
-                  0, 0, nullptr, nullptr, e->st);
+    k_chan_reduce(nullptr, e->dt, y, e->dt, nullptr, nullptr, nullptr, nullptr, nullptr, e->ws_part, groups, pix_per_group,
+                  HW, b.C, 0, 0, nullptr, nullptr, e->st);
     k_bn_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
                   e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
                   e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale, b.shift,
@@ -835,16 +957,20 @@ void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per
 
 // backward through act(bn(y))*rowscale: dz -> dy (may alias dz); writes dgamma/dbeta
 void bnact_bwd(fm_engine* e, int bi, const float* dz, const float* y, float* dy, const float* rowscale, int groups,
-               int pix_per_group, int HW, int act, const float* gate = nullptr, const float* dsv = nullptr)
+               int pix_per_group, int HW, int act, const float* gate = nullptr, const float* dsv = nullptr,
+               int ty = -1, bool sums_ready = false)
 {
     Bn& b = e->bns[bi];
-    k_chan_reduce(dz, y, b.mean, b.istd, b.scale, b.shift, rowscale, e->ws_part, groups, pix_per_group, HW, b.C, 1,
-                  act, gate, dsv, e->st);
-    k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
+    if (ty < 0) ty = e->dt;                  // storage type of y / dy (the stem's are fp32 in every mode)
+    // sums_ready: ws_part already holds the two backward sums as ONE partial per group (k_se_bwd_bn1)
+    if (!sums_ready)
+        k_chan_reduce(dz, e->dt, y, ty, b.mean, b.istd, b.scale, b.shift, rowscale, e->ws_part, groups, pix_per_group, HW, b.C,
+                      1, act, gate, dsv, e->st);
+    k_bn_bwd_finalize(e->ws_part, groups, sums_ready ? 1 : bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
                       e->state + e->off_gamma + b.ch_off, b.mean, b.istd, e->ca, e->cb, e->cc,
                       e->grad + e->off_gamma + b.ch_off, e->grad + e->off_beta + b.ch_off, e->st);
-    k_bnact_bwd_apply(dz, y, e->ca, e->cb, e->cc, b.scale, b.shift, rowscale, dy, groups, pix_per_group, HW, b.C, act,
-                      gate, dsv, e->st);
+    k_bnact_bwd_apply(dz, e->dt, y, ty, e->ca, e->cb, e->cc, b.scale, b.shift, rowscale, dy, groups, pix_per_group, HW,
+                      b.C, act, gate, dsv, e->st);
 }
 
 void eff_forward_train(fm_engine* e, int groups, int B)
@@ -852,62 +978,69 @@ void eff_forward_train(fm_engine* e, int groups, int B)
     const int imgs = groups * B;
     const float* S = e->state;
     Conv& cs = e->convs[e->c_stem];
-    conv_fwd(e, e->c_stem, S, e->x4, cs.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
-    bn_fwd_finalize(e, e->c_stem, groups, B);
+    e->ctx = -1;
+    { OP("conv_fwd"); conv_fwd(e, e->c_stem, S, e->x4, cs.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats); }
+    { OP("bn_fwd_finalize"); bn_fwd_finalize(e, e->c_stem, groups, B); }
     {
         Bn& b = e->bns[e->bn_stem];
-        k_bnact_apply(cs.y, b.scale, b.shift, nullptr, nullptr, e->a0, groups, B * cs.hout * cs.wout,
-                      cs.hout * cs.wout, b.C, 2, e->st);
+        { OP("k_bnact_apply"); k_bnact_apply(cs.y, DT_F32, b.scale, b.shift, nullptr, nullptr, e->a0, e->dt, groups, B * cs.hout * cs.wout,
+                      cs.hout * cs.wout, b.C, 2, e->st); }
     }
     const float* cur = e->a0;
     for (size_t i = 0; i < e->mbs.size(); ++i) {
         MBConv& m = e->mbs[i];
+        e->ctx = (int)i;
         const int HWi = m.hin * m.win, HWo = m.hout * m.wout;
         const float* a_e = cur;
         if (m.c_exp >= 0) {
             Conv& ce = e->convs[m.c_exp];
-            conv_fwd(e, m.c_exp, S, cur, ce.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
-            bn_fwd_finalize(e, m.c_exp, groups, B);
+            { OP("exp_fwd"); conv_fwd(e, m.c_exp, S, cur, ce.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats); }
+            { OP("bn_fwd_finalize"); bn_fwd_finalize(e, m.c_exp, groups, B); }
             Bn& b = e->bns[m.bn0];
-            k_bnact_apply(ce.y, b.scale, b.shift, nullptr, nullptr, m.a_e, groups, B * HWi, HWi, b.C, 2, e->st);
+            { OP("k_bnact_apply"); k_bnact_apply(ce.y, e->dt, b.scale, b.shift, nullptr, nullptr, m.a_e, e->dt, groups, B * HWi, HWi, b.C, 2, e->st); }
             a_e = m.a_e;
         }
-        k_dw_fwd(a_e, S + m.dw_off, m.y_d, nullptr, nullptr, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
-                 m.pad_t, m.pad_l, 0, e->st);
-        bn_fwd_tensor(e, m.bn1, m.y_d, groups, B * HWo, HWo);
+        { OP("k_dw_fwd"); k_dw_fwd(a_e, S + m.dw_off, m.y_d, e->dt, nullptr, nullptr, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                 m.pad_t, m.pad_l, 0, e->st); }
+        { OP("bn_fwd_tensor"); bn_fwd_tensor(e, m.bn1, m.y_d, groups, B * HWo, HWo); }
         {
             // a_d = swish(bn1(y_d)) is never written: the pooling and the gating pass form it on load
             Bn& b = e->bns[m.bn1];
-            k_se_fwd(m.y_d, b.scale, b.shift, B, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off,
-                     m.sq, m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st);
-            k_se_scale(m.y_d, b.scale, b.shift, B, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
+            { OP("k_se_fwd"); k_se_fwd(m.y_d, e->dt, b.scale, b.shift, B, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off,
+                     m.sq, m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st); }
+            if (!fuse_for(e, m)) k_se_scale(m.y_d, e->dt, b.scale, b.shift, B, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
         }
         Conv& cp = e->convs[m.c_proj];
-        conv_fwd(e, m.c_proj, S, m.a_s, cp.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
-        bn_fwd_finalize(e, m.c_proj, groups, B);
+        if (fuse_for(e, m)) {          // a_s = swish(bn1(y_d)) * gate is formed on the project conv's operand load
+            const Prologue pro{e->bns[m.bn1].scale, e->bns[m.bn1].shift, m.gate};
+            { OP("proj_fwd"); conv_fwd(e, m.c_proj, S, m.y_d, cp.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, &pro); }
+        } else
+            { OP("proj_fwd"); conv_fwd(e, m.c_proj, S, m.a_s, cp.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats); }
+        { OP("bn_fwd_finalize"); bn_fwd_finalize(e, m.c_proj, groups, B); }
         {
             Bn& b = e->bns[m.bn2];
             const float* dc = (m.skip && e->dc_dev) ? e->dc_dev + i * (size_t)imgs : nullptr;
-            k_bnact_apply(cp.y, b.scale, b.shift, m.skip ? cur : nullptr, dc, m.out, groups, B * HWo, HWo, b.C, 0,
-                          e->st);
+            { OP("k_bnact_apply"); k_bnact_apply(cp.y, e->dt, b.scale, b.shift, m.skip ? cur : nullptr, dc, m.out, e->dt, groups, B * HWo, HWo,
+                          b.C, 0, e->st); }
         }
         cur = m.out;
     }
     Conv& ch = e->convs[e->c_head];
     const int HWh = ch.hout * ch.wout;
-    conv_fwd(e, e->c_head, S, cur, ch.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
-    bn_fwd_finalize(e, e->c_head, groups, B);
+    e->ctx = 100;
+    { OP("conv_fwd"); conv_fwd(e, e->c_head, S, cur, ch.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats); }
+    { OP("bn_fwd_finalize"); bn_fwd_finalize(e, e->c_head, groups, B); }
     {
         Bn& b = e->bns[e->bn_head];
-        k_bnact_apply(ch.y, b.scale, b.shift, nullptr, nullptr, e->T_mid, groups, B * HWh, HWh, b.C, 2, e->st);
+        { OP("k_bnact_apply"); k_bnact_apply(ch.y, e->dt, b.scale, b.shift, nullptr, nullptr, e->T_mid, e->dt, groups, B * HWh, HWh, b.C, 2, e->st); }
     }
-    k_avgpool(e->T_mid, e->feat, imgs, HWh, e->D, e->st);
+    { OP("k_avgpool"); k_avgpool(e->T_mid, e->dt, e->feat, imgs, HWh, e->D, e->st); }
     const float* h = e->feat;
     if (e->drop_dev) {
-        k_mul(e->feat, e->drop_dev, e->hfeat, (int64_t)imgs * e->D, e->st);
+        { OP("k_mul"); k_mul(e->feat, e->drop_dev, e->hfeat, (int64_t)imgs * e->D, e->st); }
         h = e->hfeat;
     }
-    k_fc_fwd(h, S + e->off_fcw, S + e->off_fcb, e->logits, imgs, e->D, e->C, e->st);
+    { OP("k_fc_fwd"); k_fc_fwd(h, S + e->off_fcw, S + e->off_fcb, e->logits, imgs, e->D, e->C, e->st); }
     e->ev_dirty = true;
 }
 
@@ -915,33 +1048,47 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
                       float* logits)
 {
     if (dirty) {
-        k_bn_eval_affine(S + e->off_gamma, S + e->off_beta, S + e->off_rm, S + e->off_rv, evs, evh, e->n_bn_ch,
-                         e->bn_eps, e->st);
+        { OP("k_bn_eval_affine"); k_bn_eval_affine(S + e->off_gamma, S + e->off_beta, S + e->off_rm, S + e->off_rv, evs, evh, e->n_bn_ch,
+                         e->bn_eps, e->st); }
         dirty = false;
     }
     auto sc = [&](int bi) { return evs + e->bns[bi].ch_off; };
     auto sh = [&](int bi) { return evh + e->bns[bi].ch_off; };
-    conv_fwd(e, e->c_stem, S, e->x4, e->a0, imgs, 1, sc(e->bn_stem), sh(e->bn_stem), nullptr, 2, nullptr);
+    if (e->precision) {      // the stem conv is fp32: raw output, then BN + Swish into the bf16 activation
+        Conv& cs = e->convs[e->c_stem];
+        { OP("conv_fwd"); conv_fwd(e, e->c_stem, S, e->x4, cs.y, imgs, 1, nullptr, nullptr, nullptr, 0, nullptr); }
+        { OP("k_bnact_apply"); k_bnact_apply(cs.y, DT_F32, sc(e->bn_stem), sh(e->bn_stem), nullptr, nullptr, e->a0, e->dt, 1, imgs * cs.hout * cs.wout,
+                      cs.hout * cs.wout, e->bns[e->bn_stem].C, 2, e->st); }
+    } else
+        { OP("conv_fwd"); conv_fwd(e, e->c_stem, S, e->x4, e->a0, imgs, 1, sc(e->bn_stem), sh(e->bn_stem), nullptr, 2, nullptr); }
     const float* cur = e->a0;
+    e->ctx = 200;
     for (auto& m : e->mbs) {
+        ++e->ctx;                                  // eval-mode ops are labelled @201..@216 (head @300)
         const int HWo = m.hout * m.wout;
         const float* a_e = cur;
         if (m.c_exp >= 0) {
-            conv_fwd(e, m.c_exp, S, cur, m.a_e, imgs, 1, sc(m.bn0), sh(m.bn0), nullptr, 2, nullptr);
+            { OP("exp_fwd"); conv_fwd(e, m.c_exp, S, cur, m.a_e, imgs, 1, sc(m.bn0), sh(m.bn0), nullptr, 2, nullptr); }
             a_e = m.a_e;
         }
-        k_dw_fwd(a_e, S + m.dw_off, m.y_d, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
-                 m.pad_t, m.pad_l, 2, e->st);          // eval: y_d holds swish(bn1(.)) directly
-        k_se_fwd(m.y_d, nullptr, nullptr, 1, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq,
-                 m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st);
-        k_se_scale(m.y_d, nullptr, nullptr, 1, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st);
-        conv_fwd(e, m.c_proj, S, m.a_s, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr);
+        { OP("k_dw_fwd"); k_dw_fwd(a_e, S + m.dw_off, m.y_d, e->dt, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                 m.pad_t, m.pad_l, 2, e->st); }          // eval: y_d holds swish(bn1(.)) directly
+        { OP("k_se_fwd"); k_se_fwd(m.y_d, e->dt, nullptr, nullptr, 1, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq,
+                 m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st); }
+        if (fuse_for(e, m)) {      // the gate multiplies the activation on the project conv's operand load
+            const Prologue pro{nullptr, nullptr, m.gate};
+            { OP("proj_fwd"); conv_fwd(e, m.c_proj, S, m.y_d, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr, &pro); }
+        } else {
+            { OP("k_se_scale"); k_se_scale(m.y_d, e->dt, nullptr, nullptr, 1, m.gate, m.a_s, imgs, HWo, m.ce_p, e->st); }
+            { OP("proj_fwd"); conv_fwd(e, m.c_proj, S, m.a_s, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr); }
+        }
         cur = m.out;
     }
     Conv& ch = e->convs[e->c_head];
-    conv_fwd(e, e->c_head, S, cur, e->T_mid, imgs, 1, sc(e->bn_head), sh(e->bn_head), nullptr, 2, nullptr);
-    k_avgpool(e->T_mid, feat, imgs, ch.hout * ch.wout, e->D, e->st);
-    k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, e->D, e->C, e->st);
+    e->ctx = 300;
+    { OP("conv_fwd"); conv_fwd(e, e->c_head, S, cur, e->T_mid, imgs, 1, sc(e->bn_head), sh(e->bn_head), nullptr, 2, nullptr); }
+    { OP("k_avgpool"); k_avgpool(e->T_mid, e->dt, feat, imgs, ch.hout * ch.wout, e->D, e->st); }
+    { OP("k_fc_fwd"); k_fc_fwd(feat, S + e->off_fcw, S + e->off_fcb, logits, imgs, e->D, e->C, e->st); }
 }
 
 
@@ -953,58 +1100,70 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     Conv& ch = e->convs[e->c_head];
     const int HWh = ch.hout * ch.wout;
     const float* h = e->drop_dev ? e->hfeat : e->feat;
-    k_fc_bwd(e->dlogits, h, S + e->off_fcw, e->drop_dev, G + e->off_fcw, G + e->off_fcb, e->T_mid, imgs, e->D, e->C,
-             HWh, e->st);
-    bnact_bwd(e, e->bn_head, e->T_mid, ch.y, e->T_mid, nullptr, groups, B * HWh, HWh, 2);
-    conv_wgrad(e, e->c_head, e->mbs.back().out, e->T_mid, imgs);
+    e->ctx = 500;
+    { OP("k_fc_bwd"); k_fc_bwd(e->dlogits, h, S + e->off_fcw, e->drop_dev, G + e->off_fcw, G + e->off_fcb, e->T_mid, e->dt, imgs, e->D, e->C,
+             HWh, e->st); }
+    { OP("bnact_bwd"); bnact_bwd(e, e->bn_head, e->T_mid, ch.y, e->T_mid, nullptr, groups, B * HWh, HWh, 2); }
+    { OP("conv_wgrad"); conv_wgrad(e, e->c_head, e->mbs.back().out, e->T_mid, imgs); }
     float *go = e->GA, *gi = e->GB;
-    conv_dgrad(e, e->c_head, S, e->T_mid, go, imgs, nullptr, false);
+    { OP("conv_dgrad"); conv_dgrad(e, e->c_head, S, e->T_mid, go, imgs, nullptr, false); }
     for (int i = (int)e->mbs.size() - 1; i >= 0; --i) {
         MBConv& m = e->mbs[i];
+        e->ctx = 400 + i;                          // backward ops @400..@415 (head @500, stem @399)
         const float* in = i == 0 ? e->a0 : e->mbs[i - 1].out;
         const int HWi = m.hin * m.win, HWo = m.hout * m.wout;
         Conv& cp = e->convs[m.c_proj];
         const float* dc = (m.skip && e->dc_dev) ? e->dc_dev + (size_t)i * imgs : nullptr;
         // out = bn2(y_p)*dc + in
-        bnact_bwd(e, m.bn2, go, cp.y, e->T_small, dc, groups, B * HWo, HWo, 0);
-        conv_wgrad(e, m.c_proj, m.a_s, e->T_small, imgs);
-        conv_dgrad(e, m.c_proj, S, e->T_small, e->T_mid, imgs, nullptr, false);          // d a_s
-        // a_s = a_d * gate(a_d)
+        { OP("bnact_bwd"); bnact_bwd(e, m.bn2, go, cp.y, e->T_small, dc, groups, B * HWo, HWo, 0); }
         Bn& b1 = e->bns[m.bn1];
-        k_se_bwd(e->T_mid, m.y_d, b1.scale, b1.shift, B, e->se_pool, m.gate, m.rpre, S + m.w1_off, S + m.w2_off,
-                 e->se_dgp, e->se_drp, e->se_ds, imgs, HWo, m.ce_p, m.cs, e->st);
-        k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, G + m.w1_off, G + m.b1_off, G + m.w2_off, G + m.b2_off, imgs,
-                   m.ce_p, m.cs, e->st);
-        // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward (no separate pass)
-        bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds);   // d y_d
+        if (fuse_for(e, m)) {      // the project conv's operand a_s was never stored: re-formed from y_d on load
+            const Prologue pro{b1.scale, b1.shift, m.gate};
+            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.y_d, e->T_small, imgs, &pro, B * HWo); }
+        } else
+            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.a_s, e->T_small, imgs); }
+        { OP("proj_dgrad"); conv_dgrad(e, m.c_proj, S, e->T_small, e->T_mid, imgs, nullptr, false); }          // d a_s
+        // a_s = a_d * gate(a_d)
+        // ONE pass over (d a_s, y_d) yields the squeeze-excite backward's pooled sums and the BN1-backward sums
+        { OP("k_se_bwd"); k_se_bwd_bn1(e->T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
+                     S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
+        { OP("k_se_wgrad"); k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, G + m.w1_off, G + m.b1_off, G + m.w2_off, G + m.b2_off, imgs,
+                   m.ce_p, m.cs, e->st); }
+        // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
+        { OP("bnact_bwd"); bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
+                                     true); }   // d y_d
         const float* a_e = m.c_exp >= 0 ? m.a_e : in;
         const int nb = dw_wgrad_blocks(imgs * HWo);
-        k_dw_wgrad(e->T_mid, a_e, e->ws_slab, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t, m.pad_l,
-                   e->st);
-        k_reduce_slabs(e->ws_slab, G + m.dw_off, nb, (int64_t)m.k * m.k * m.ce_p, e->st);
+        { OP("k_dw_wgrad"); k_dw_wgrad(e->T_mid, a_e, e->dt, e->ws_slab, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t, m.pad_l,
+                   e->st); }
+        { OP("k_reduce_slabs"); k_reduce_slabs(e->ws_slab, G + m.dw_off, nb, (int64_t)m.k * m.k * m.ce_p, e->st); }
         if (m.c_exp >= 0) {
             Conv& ce = e->convs[m.c_exp];
-            k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
-                       m.pad_l, e->st);                                                   // d a_e
-            bnact_bwd(e, m.bn0, e->T_big, ce.y, e->T_big, nullptr, groups, B * HWi, HWi, 2);
-            conv_wgrad(e, m.c_exp, in, e->T_big, imgs);
-            conv_dgrad(e, m.c_exp, S, e->T_big, gi, imgs, m.skip ? go : nullptr, false);
+            { OP("k_dw_dgrad"); k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
+                       m.pad_l, e->st); }                                                   // d a_e
+            { OP("bnact_bwd"); bnact_bwd(e, m.bn0, e->T_big, ce.y, e->T_big, nullptr, groups, B * HWi, HWi, 2); }
+            { OP("exp_wgrad"); conv_wgrad(e, m.c_exp, in, e->T_big, imgs); }
+            { OP("exp_dgrad"); conv_dgrad(e, m.c_exp, S, e->T_big, gi, imgs, m.skip ? go : nullptr, false); }
         } else {
-            k_dw_dgrad(e->T_mid, S + m.dw_off, gi, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
-                       m.pad_l, e->st);
-            if (m.skip) k_add_inplace(gi, go, (int64_t)imgs * HWi * m.cin_p, e->st);
+            { OP("k_dw_dgrad"); k_dw_dgrad(e->T_mid, S + m.dw_off, gi, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
+                       m.pad_l, e->st); }
+            if (m.skip) k_add_inplace(gi, go, e->dt, (int64_t)imgs * HWi * m.cin_p, e->st);
         }
         std::swap(go, gi);
     }
     Conv& cs = e->convs[e->c_stem];
-    bnact_bwd(e, e->bn_stem, go, cs.y, go, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2);
-    conv_wgrad(e, e->c_stem, e->x4, go, imgs);
-    adam_step(e);
+    e->ctx = 399;
+    float* sdy = e->precision ? e->stem_dy : go;        // fp32 gradient of the stem's fp32 raw output
+    { OP("bnact_bwd"); bnact_bwd(e, e->bn_stem, go, cs.y, sdy, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2, nullptr, nullptr,
+              DT_F32); }
+    { OP("conv_wgrad"); conv_wgrad(e, e->c_stem, e->x4, sdy, imgs); }
+    { OP("adam_step"); adam_step(e); }
 }
 
 // model dispatch
 void net_forward_train(fm_engine* e, int groups, int B)
 {
+    ensure_packed(e);
     if (e->model == 1) eff_forward_train(e, groups, B);
     else forward_train(e, groups, B);
 }
@@ -1016,6 +1175,8 @@ void net_forward_eval(fm_engine* e, bool teacher, int imgs)
     bool& dirty = teacher ? e->tev_dirty : e->ev_dirty;
     float* feat = teacher ? e->tfeat : e->feat;
     float* logits = teacher ? e->tlogits : e->logits;
+    if (teacher) ensure_teacher_shadow(e);
+    else ensure_packed(e);
     if (e->model == 1) eff_forward_eval(e, S, evs, evh, dirty, imgs, feat, logits);
     else forward_eval(e, S, evs, evh, dirty, imgs, feat, logits);
 }
@@ -1050,6 +1211,8 @@ int fm_create(const fm_config* cfg, fm_engine** out)
            "precision (reserved[0]) must be 0 (fp32) or, for EfficientNet-B0, 1 (bf16 activations)");
     fm_engine* e = new fm_engine();
     e->precision = cfg->reserved[0];
+    e->dt = e->precision ? DT_BF16 : DT_F32;
+    e->fuse_gate = e->precision && !(getenv("FM_FUSE_GATE") && atoi(getenv("FM_FUSE_GATE")) == 0);
     e->cfg = *cfg;
     e->st = reinterpret_cast<hipStream_t>(cfg->stream);
     e->C = cfg->n_classes; e->H = cfg->in_h; e->W = cfg->in_w; e->maxB = cfg->max_images;
@@ -1271,6 +1434,7 @@ int fm_teacher_snapshot(fm_engine* e)
     HIPCHK(hipMemcpyAsync(e->tstate, e->state, e->NS * 4, hipMemcpyDeviceToDevice, e->st));
     e->tcounters = e->counters;
     e->tev_dirty = true;
+    e->twb_dirty = true;
     return FM_OK;
 }
 
@@ -1498,6 +1662,7 @@ int fm_teacher_axpby(fm_engine* e, float w_teacher, float w_student)
     for (size_t i = 0; i < e->counters.size(); ++i)
         e->tcounters[i] = (int64_t)(w_teacher * (float)e->tcounters[i] + w_student * (float)e->counters[i]);
     e->tev_dirty = true;
+    e->twb_dirty = true;
     return FM_OK;
 }
 
@@ -1510,6 +1675,7 @@ int fm_teacher_swap(fm_engine* e)
     std::swap(e->ev_dirty, e->tev_dirty);
     std::swap(e->counters, e->tcounters);
     e->wpack_dirty = true;
+    e->twb_dirty = true;
     return FM_OK;
 }
 
@@ -1550,6 +1716,49 @@ int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms,
     return FM_OK;
 }
 
+int fm_debug_pw(fm_engine* e, int32_t op, int32_t conv, const void* x_dev, const void* dy_dev, void* out_dev,
+                int32_t imgs, int32_t groups, const float* psc_dev, const float* psh_dev, const float* gate_dev,
+                float* stats_dev)
+{
+    ARGCHK(e && out_dev && conv >= 0 && conv < (int)e->convs.size(), "conv index");
+    ARGCHK(e->precision == 1 && e->convs[conv].k == 1, "bf16 engine and a 1x1 convolution");
+    ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs/groups");
+    Conv& c = e->convs[conv];
+    ensure_packed(e);
+    const Prologue pro{psc_dev, psh_dev, gate_dev};
+    if (op == 0) {
+        ARGCHK(x_dev, "x");
+        conv_fwd(e, conv, e->state, reinterpret_cast<const float*>(x_dev), reinterpret_cast<float*>(out_dev), imgs, groups,
+                 nullptr, nullptr, nullptr, 0, stats_dev ? e->ws_stats : nullptr, gate_dev ? &pro : nullptr);
+        if (stats_dev) {
+            const int tiles = stats_tiles(e, conv, imgs / groups, groups);
+            std::vector<float> h((size_t)groups * tiles * 2 * c.cout_p), o((size_t)groups * 2 * c.cout_p, 0.f);
+            HIPCHK(hipMemcpyAsync(h.data(), e->ws_stats, h.size() * 4, hipMemcpyDeviceToHost, e->st));
+            HIPCHK(hipStreamSynchronize(e->st));
+            for (int g = 0; g < groups; ++g)
+                for (int k = 0; k < 2 * c.cout_p; ++k) {
+                    double sum = 0;
+                    for (int t = 0; t < tiles; ++t) sum += h[((size_t)g * tiles + t) * 2 * c.cout_p + k];
+                    o[(size_t)g * 2 * c.cout_p + k] = (float)sum;
+                }
+            HIPCHK(hipMemcpy(stats_dev, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+        }
+    } else if (op == 1) {
+        ARGCHK(dy_dev, "dy");
+        conv_dgrad(e, conv, e->state, reinterpret_cast<const float*>(dy_dev), reinterpret_cast<float*>(out_dev), imgs,
+                   reinterpret_cast<const float*>(x_dev), false);      // x_dev = optional residual [npix][cin_p] bf16
+    } else if (op == 2) {
+        ARGCHK(x_dev && dy_dev, "x/dy");
+        conv_wgrad(e, conv, reinterpret_cast<const float*>(x_dev), reinterpret_cast<const float*>(dy_dev), imgs,
+                   gate_dev ? &pro : nullptr, (imgs / groups) * c.hout * c.wout);
+        HIPCHK(hipMemcpyAsync(out_dev, e->grad + c.w_off, c.w_numel * 4, hipMemcpyDeviceToDevice, e->st));
+    } else {
+        ARGCHK(false, "op");
+    }
+    HIPCHK(hipGetLastError());
+    return FM_OK;
+}
+
 int fm_debug_get_grads(fm_engine* e, float* host_f32)
 {
     ARGCHK(e && host_f32, "null");
@@ -1568,6 +1777,30 @@ int fm_debug_get_grads(fm_engine* e, float* host_f32)
     }
     HIPCHK(hipMemcpyAsync(host_f32, e->stage_sd, (size_t)e->nf_sd * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
+    return FM_OK;
+}
+
+int fm_profile_ops(fm_engine* e, int32_t enable, char* buf, int32_t cap)
+{
+    ARGCHK(e, "null engine");
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (auto& p : e->opevs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { e->op_ms[p.id] += t; e->op_n[p.id] += 1; }
+        e->ev_free.push_back(p.a); e->ev_free.push_back(p.b);
+    }
+    e->opevs.clear();
+    if (buf && cap > 0) {
+        std::string out;
+        char line[160];
+        for (size_t i = 0; i < e->op_names.size(); ++i) {
+            snprintf(line, sizeof line, "%s\t%lld\t%.6f\n", e->op_names[i].c_str(), (long long)e->op_n[i], e->op_ms[i]);
+            out += line;
+        }
+        snprintf(buf, (size_t)cap, "%s", out.c_str());
+        e->op_names.clear(); e->op_ms.clear(); e->op_n.clear();
+    }
+    e->oprof = enable != 0;
     return FM_OK;
 }
 
@@ -1603,6 +1836,7 @@ int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, co
                   int32_t imgs, int32_t groups, float* stats_dev)
 {
     ARGCHK(e && out_dev && conv >= 0 && conv < (int)e->convs.size(), "conv index");
+    ARGCHK(!e->precision, "fm_debug_conv works on fp32 tensors: create the engine with precision 0");
     ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs/groups");
     Conv& c = e->convs[conv];
     if (op == 0) {
@@ -1611,7 +1845,7 @@ int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, co
                  stats_dev ? e->ws_stats : nullptr);
         if (stats_dev) {
             // fold the per-tile partials with the finalize kernel's own reduction order: sum/sumsq only
-            const int tiles = stats_tiles(e, conv, imgs / groups);
+            const int tiles = stats_tiles(e, conv, imgs / groups, groups);
             std::vector<float> h((size_t)groups * tiles * 2 * c.cout_p), o((size_t)groups * 2 * c.cout_p, 0.f);
             HIPCHK(hipMemcpyAsync(h.data(), e->ws_stats, h.size() * 4, hipMemcpyDeviceToHost, e->st));
             HIPCHK(hipStreamSynchronize(e->st));

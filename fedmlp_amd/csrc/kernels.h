@@ -100,6 +100,12 @@ void k_se_scale(const void* a, int dt, const float* scale, const float* shift, i
 void k_se_bwd(const void* dout, const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws,
               const float* gate, const float* rpre, const float* W1, const float* W2, float* dgp, float* drp, float* ds,
               int imgs, int HW, int C, int Cs, hipStream_t s);
+// squeeze-excite backward AND the BN1-backward sums from one pass over (dout = d a_s, y = raw depthwise output);
+// pool_ws [imgs][16][5][C]; bn_part [groups][1][2][C] is what k_bn_bwd_finalize consumes with nblk = 1
+void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, const float* shift, const float* mean,
+                  const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
+                  const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
+                  hipStream_t s);
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
                 float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s);
 void k_mul(const float* a, const float* b, float* y, int64_t n, hipStream_t s);

@@ -25,6 +25,7 @@ struct PwParams {
     int HW;               // pixels per image (gate row = global pixel / HW)
 };
 int pw_blocks(int npix_per_group, int groups, int M, int K);   // nblk the launcher will use (statistics layout)
+int pw_tiles_m(int M, int K);       // M-tiles of the launch: the pixel operand (and its prologue) is read once per M-tile
 void launch_pw_conv(PwParams p, hipStream_t s);
 
 // dW[m][k] = sum_pix dY[pix][m] * Xe[pix][k]  -> fp32 partial slabs [splits][M][K]

@@ -130,6 +130,16 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
     f32x4 s1[RT], s2[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // eval epilogue: this lane's per-channel affine, loaded once (register r holds the 4 channels of row tile r)
+    f32x4 esc[RT], esh[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        esc[r] = f32x4{1.f, 1.f, 1.f, 1.f}; esh[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.scale && r < nrt) {
+            const int m = m0 + tile_row_to_channel(r, 4 * lg, npairs);
+            esc[r] = ld4(p.scale + m); esh[r] = ld4(p.shift + m);
+        }
+    }
 
     const int n_iter = (pe - pb + PPI - 1) / PPI;
     for (int it = wave; it < n_iter; it += 4) {
@@ -214,8 +224,8 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
         for (int g = 0; g < P; ++g) {
             if (!pv[g]) continue;
             const size_t o = (gbase + pix0 + 16 * g + li) * (size_t)p.M;
-            auto finish = [&](f32x4 v, int m) {
-                if (p.scale) v = v * ld4(p.scale + m) + ld4(p.shift + m);
+            auto finish = [&](f32x4 v, int m, f32x4 sc, f32x4 sh) {
+                v = v * sc + sh;
                 if (p.res) v += ld4(p.res + o + m);
                 if (p.act == 2) v = swish4(v);
                 return v;
@@ -224,16 +234,17 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
             for (int u = 0; u < RT / 2; ++u) {
                 if (u >= npairs) break;
                 const int m = m0 + 32 * u + 8 * lg;
-                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m), finish(acc[2 * u + 1][g], m + 4));
+                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m, esc[2 * u], esh[2 * u]),
+                                                               finish(acc[2 * u + 1][g], m + 4, esc[2 * u + 1], esh[2 * u + 1]));
             }
             if (nrt & 1) {
                 const int r = nrt - 1;
                 const int m = m0 + 16 * r + 4 * lg;
-                f32x4 v = acc[0][g];
+                f32x4 v = acc[0][g], sc = esc[0], sh = esh[0];
 #pragma unroll
                 for (int rr = 1; rr < RT; ++rr)
-                    if (rr == r) v = acc[rr][g];             // static register index
-                *reinterpret_cast<uint2*>(p.Y + o + m) = pack4(finish(v, m));
+                    if (rr == r) { v = acc[rr][g]; sc = esc[rr]; sh = esh[rr]; }   // static register index
+                *reinterpret_cast<uint2*>(p.Y + o + m) = pack4(finish(v, m, sc, sh));
             }
         }
     }
@@ -441,6 +452,7 @@ static int pw_ppb(int npix_per_group, int groups, int M, int K)
     ppb = std::min<long long>(std::max<long long>(ppb, 128), 4096);
     return (int)((ppb + 31) / 32 * 32);
 }
+int pw_tiles_m(int M, int K) { return (M + 16 * pw_rt(K) - 1) / (16 * pw_rt(K)); }
 int pw_blocks(int npix_per_group, int groups, int M, int K)
 {
     const int ppb = pw_ppb(npix_per_group, groups, M, K);

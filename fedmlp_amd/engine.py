@@ -17,7 +17,7 @@ PRECISION_IDS = {"fp32": 0, "bf16": 1}
 def _ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.int32), \
+    assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.int32, torch.bfloat16), \
         (t.device, t.dtype, t.is_contiguous())
     return C.c_void_p(t.data_ptr())
 
@@ -278,6 +278,17 @@ class Engine:
         _lib.check(self.lib.fm_profile_read(self.h, family, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
+    def profile_ops(self, enable, read=True):
+        """[(label, calls, total_ms)] of the ops timed since the last read (EfficientNet-B0 graph)."""
+        buf = C.create_string_buffer(1 << 16) if read else None
+        _lib.check(self.lib.fm_profile_ops(self.h, int(enable), buf, (1 << 16) if read else 0))
+        rows = []
+        if read:
+            for line in buf.value.decode().splitlines():
+                lab, n, ms = line.split("\t")
+                rows.append((lab, int(n), float(ms)))
+        return rows
+
     # ---- kernel-level test hooks ----------------------------------------------------------
     def debug_conv_info(self, conv):
         info = (C.c_int32 * 16)()
@@ -289,6 +300,10 @@ class Engine:
         flat = np.empty(self.nf, np.float32)
         _lib.check(self.lib.fm_debug_get_grads(self.h, flat.ctypes.data_as(C.c_void_p)))
         return flat
+
+    def debug_pw(self, op, conv, x, dy, out, imgs, groups=1, psc=None, psh=None, gate=None, stats=None):
+        _lib.check(self.lib.fm_debug_pw(self.h, op, conv, _ptr(x), _ptr(dy), _ptr(out), imgs, groups, _ptr(psc),
+                                        _ptr(psh), _ptr(gate), _ptr(stats)))
 
     def debug_activation(self, kind, block, imgs):
         """post-ReLU activation kept by the last train-mode forward, as an NCHW numpy array"""

@@ -236,6 +236,12 @@ int fm_feature_dim(fm_engine* e);
 int fm_profile_enable(fm_engine* e, int32_t on);
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops);
 
+/* Per-op timing of the EfficientNet-B0 graph (tools/op_profile.py): while enabled, HIP events bracket every op
+ * of the step; a call drains them and, when buf != NULL, writes "op@block<TAB>calls<TAB>total ms" lines and
+ * resets the table.  Blocks: -1 stem, 0..15 train forward, 100 head, 201..216 / 300 eval forward,
+ * 399..415 / 500 backward. */
+int fm_profile_ops(fm_engine* e, int32_t enable, char* buf, int32_t cap);
+
 /* ---- kernel-level test hooks (tests/ only; not part of the drop-in surface) -- */
 /* info[0..12] = cin, cout, k, stride, pad, hin, win, hout, wout, cin_p (padded
  * input channels of the NHWC operand), Kw (row length of the engine-layout
@@ -250,6 +256,16 @@ int fm_debug_num_convs(fm_engine* e);
  * All tensors NHWC fp32 on device; weights are the engine's current state. */
 int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, const float* dy_dev,
                   float* out_dev, int32_t imgs, int32_t groups, float* stats_dev);
+
+/* bf16 pointwise-convolution kernels of a precision-1 engine (conv must be a 1x1 convolution):
+ * op 0: x bf16 [imgs,h,w,cin_p] -> out bf16 [imgs,h,w,cout_p] raw; stats_dev (optional) per-group (sum, sumsq)
+ *       [groups][2][cout_p] fp32; gate_dev != NULL applies the operand prologue
+ *       x <- swish(x*psc[g]+psh[g]) * gate[img]   (psc_dev NULL: x * gate[img]); psc/psh [groups][cin_p], gate [imgs][cin_p]
+ * op 1: dy bf16 [imgs,h,w,cout_p] -> out bf16 [imgs,h,w,cin_p]; x_dev (optional) = residual added to the result
+ * op 2: (x, dy) -> out fp32 [cout_p][cin_p], with the same optional prologue on x */
+int fm_debug_pw(fm_engine* e, int32_t op, int32_t conv, const void* x_dev, const void* dy_dev, void* out_dev,
+                int32_t imgs, int32_t groups, const float* psc_dev, const float* psh_dev, const float* gate_dev,
+                float* stats_dev);
 
 /* Post-ReLU activations the last train-mode forward kept (ResNet-18): kind 0 = relu(bn1(conv1)) of
  * basic block `block`, kind 1 = the block's output relu(bn2(conv2) + identity); NHWC fp32 for the first

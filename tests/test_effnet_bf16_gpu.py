@@ -1,0 +1,328 @@
+"""EfficientNet-B0 with bf16 activation storage (BASELINE configs[4]) on a real MI355X, through the C ABI.
+
+The reference has no bf16 counterpart (utils/local_training.py:14 imports autocast and never uses it),
+so the yardstick is the fp32 oracle (oracle/efficientnet_ref.py) and the tolerances are this build's own,
+stated here: bf16 keeps 8 significant bits (relative rounding 2^-9 = 2.0e-3 per stored value); through 82
+stored tensors of one forward pass the logits agree with fp32 to ~1e-2 of their range and the per-tensor
+gradients to a few percent of their max.  Kernel-level tests pin the bf16 kernels themselves much tighter:
+against fp32 arithmetic on the SAME bf16-rounded inputs they are exact up to fp32 summation order."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fedmlp_amd import spec
+from oracle import steps_ref as R
+
+pytestmark = pytest.mark.gpu
+
+C_, HW, LR = 5, 64, 3e-5
+REPORT = {}
+
+
+def _dump():
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_bf16.json", "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fedmlp_amd.engine import Engine
+    e = Engine("Efficient_b0", C_, HW, HW, 16, precision="bf16")
+    e.stochastic = False
+    yield e
+    e.close()
+
+
+def _load(e, seed=1037):
+    from tests.test_effnet_gpu import _oracle          # perturbed BN affine / running stats / SE biases
+    net = _oracle(seed)
+    flat, cnt = spec.state_dict_to_flat("Efficient_b0", C_, net.state_dict())
+    e.set_state(flat, cnt)
+    e.adam_reset(LR)
+    e.set_stochastic(None, None)
+    return net
+
+
+def _data(B, seed, views=1):
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn((B, 3, HW, HW), generator=g) for _ in range(views)]
+    y = (torch.rand((B, C_), generator=g) < 0.3).float()
+    return xs, y
+
+
+def _rel(got, want):
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+
+
+# ---- kernel level: the bf16 pointwise kernels vs fp32 math on the same bf16-rounded operands -------------
+def _pw_convs(e):
+    out = []
+    for ci in range(e.debug_num_convs()):
+        info = e.debug_conv_info(ci)
+        if info["k"] == 1:
+            out.append((ci, info))
+    return out
+
+
+def _engine_weight(e, ci, info):
+    """the conv's fp32 master weight in engine layout [cout_p][cin_p] (padding rows/cols are zero)"""
+    flat, cnt = e.get_state()
+    sd = spec.flat_to_state_dict("Efficient_b0", C_, flat, cnt)
+    keys = [k for k, shape, _ in spec.entries("Efficient_b0", C_) if len(shape) == 4]
+    # the engine's conv order is the state_dict order of the non-depthwise, non-squeeze-excite conv weights
+    ckeys = [k for k in keys if "_depthwise" not in k and "_se_" not in k]
+    w = sd[ckeys[ci]].reshape(info["cout"], info["cin"])
+    W = np.zeros((info["cout_p"], info["cin_p"]), np.float32)
+    W[:info["cout"], :info["cin"]] = w
+    return W
+
+
+@pytest.mark.parametrize("which", ["small_k", "tail_k", "big_k", "head"])
+def test_pw_conv_fwd_dgrad_wgrad_vs_fp32_on_rounded_operands(eng, which):
+    _load(eng)
+    convs = _pw_convs(eng)
+    pick = {"small_k": lambda i: i["cin_p"] == 16, "tail_k": lambda i: i["cin_p"] == 144 and i["cout_p"] == 32,
+            "big_k": lambda i: i["cin_p"] == 1152 and i["cout_p"] == 320, "head": lambda i: i["cout_p"] == 1280}[which]
+    ci, info = next((c, i) for c, i in convs if pick(i))
+    M, K, h, w = info["cout_p"], info["cin_p"], info["hout"], info["wout"]
+    imgs, groups = 6, 2
+    npix = imgs * h * w
+    g = torch.Generator().manual_seed(ci)
+    x = torch.randn((npix, K), generator=g).to(torch.bfloat16)
+    dy = torch.randn((npix, M), generator=g).to(torch.bfloat16)
+    res = torch.randn((npix, K), generator=g).to(torch.bfloat16)
+    W = torch.from_numpy(_engine_weight(eng, ci, info)).to(torch.bfloat16).float()
+    dev = eng.device
+    xd, dyd, resd = x.to(dev), dy.to(dev), res.to(dev)
+    # forward + statistics
+    out = torch.empty((npix, M), dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros((groups, 2, M), device=dev)
+    eng.debug_pw(0, ci, xd, None, out, imgs, groups, stats=stats)
+    want = x.float() @ W.t()
+    np.testing.assert_allclose(out.float().cpu().numpy(), want.to(torch.bfloat16).float().numpy(), rtol=1e-2, atol=1e-2)
+    err = (out.float().cpu() - want).abs().max() / want.abs().max()
+    assert err < 6e-3, err                                   # one bf16 rounding of the fp32 result
+    wg = want.view(groups, -1, M)
+    np.testing.assert_allclose(stats[:, 0].cpu().numpy(), wg.sum(1).numpy(), rtol=2e-4, atol=2e-3 * float(wg.abs().sum(1).max()))
+    np.testing.assert_allclose(stats[:, 1].cpu().numpy(), (wg * wg).sum(1).numpy(), rtol=2e-4, atol=1e-2)
+    # data gradient (+ residual)
+    dx = torch.empty((npix, K), dtype=torch.bfloat16, device=dev)
+    eng.debug_pw(1, ci, resd, dyd, dx, imgs)
+    want = dy.float() @ W + res.float()
+    err = (dx.float().cpu() - want).abs().max() / want.abs().max()
+    assert err < 6e-3, err
+    # weight gradient (fp32 output, fixed-order split reduction)
+    dw = torch.empty((M, K), device=dev)
+    eng.debug_pw(2, ci, xd, dyd, dw, imgs)
+    want = dy.float().t() @ x.float()
+    err = (dw.cpu() - want).abs().max() / want.abs().max()
+    assert err < 2e-5, err
+    REPORT[f"pw_{which}"] = {"conv": ci, "M": M, "K": K, "wgrad_rel_err": float(err)}
+    _dump()
+
+
+def test_pw_prologue_gate_matches_materialised_operand(eng):
+    """Squeeze-excite gate fused into the project conv: Xe = swish(x*sc+sh)*gate on load, in the forward and in
+    the weight gradient, against the same arithmetic done in torch on the bf16 operand."""
+    _load(eng)
+    ci, info = next((c, i) for c, i in _pw_convs(eng) if i["cin_p"] == 240 and i["cout_p"] == 48)
+    M, K, h, w = info["cout_p"], info["cin_p"], info["hout"], info["wout"]
+    imgs, groups = 4, 2
+    npix = imgs * h * w
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((npix, K), generator=g).to(torch.bfloat16)
+    dy = torch.randn((npix, M), generator=g).to(torch.bfloat16)
+    sc = torch.rand((groups, K), generator=g) + 0.5
+    sh = torch.randn((groups, K), generator=g) * 0.3
+    gate = torch.rand((imgs, K), generator=g)
+    W = torch.from_numpy(_engine_weight(eng, ci, info)).to(torch.bfloat16).float()
+    dev = eng.device
+    xf = x.float().view(groups, -1, K)
+    v = xf * sc[:, None, :] + sh[:, None, :]
+    a = (v * torch.sigmoid(v)).view(imgs, h * w, K) * gate[:, None, :]
+    xe = a.reshape(npix, K).to(torch.bfloat16).float()          # the operand the MFMA sees
+    for affine in (True, False):
+        if not affine:
+            xe = (x.float().view(imgs, h * w, K) * gate[:, None, :]).reshape(npix, K).to(torch.bfloat16).float()
+        out = torch.empty((npix, M), dtype=torch.bfloat16, device=dev)
+        eng.debug_pw(0, ci, x.to(dev), None, out, imgs, groups, psc=sc.to(dev) if affine else None,
+                     psh=sh.to(dev) if affine else None, gate=gate.to(dev))
+        want = xe @ W.t()
+        err = (out.float().cpu() - want).abs().max() / want.abs().max()
+        assert err < 1.2e-2, (affine, err)                      # operand re-rounded after a fast exp/rcp + output rounding
+        dw = torch.empty((M, K), device=dev)
+        eng.debug_pw(2, ci, x.to(dev), dy.to(dev), dw, imgs, groups, psc=sc.to(dev) if affine else None,
+                     psh=sh.to(dev) if affine else None, gate=gate.to(dev))
+        want = dy.float().t() @ xe
+        err = (dw.cpu() - want).abs().max() / want.abs().max()
+        assert err < 5e-3, (affine, err)
+
+
+# ---- model level ---------------------------------------------------------------------------------------
+def test_forward_eval_bf16_vs_fp32_oracle(eng):
+    net = _load(eng)
+    (x,), _ = _data(6, 1)
+    net.eval()
+    with torch.no_grad():
+        f, z = net(x)
+    fe, ze = eng.forward_eval(x.to(eng.device))
+    ef, ez = _rel(fe.cpu().numpy(), f.numpy()), _rel(ze.cpu().numpy(), z.numpy())
+    REPORT["eval_64"] = {"feature_rel_to_max": ef, "logits_rel_to_max": ez}
+    _dump()
+    assert ef < 1e-2 and ez < 1e-2, (ef, ez)
+
+
+def _grads(e):
+    return spec.flat_to_state_dict("Efficient_b0", C_, e.debug_get_grads(), np.zeros(e.ni, np.int64))
+
+
+def _grad_report(e, net, what, C=C_):
+    """Per-tensor agreement of the bf16 engine's gradients with the fp32 oracle's: largest deviation relative to
+    the tensor's max, and the cosine between the two gradient vectors.  Tensors whose gradient is analytically
+    zero (`_bn2.bias` without drop-connect: a per-channel constant added in front of a conv + BatchNorm) hold
+    rounding noise on both sides and are skipped when both are below 1e-3 of the typical gradient size."""
+    gsd = spec.flat_to_state_dict("Efficient_b0", C, e.debug_get_grads(), np.zeros(e.ni, np.int64))
+    typ = float(np.median([p.grad.abs().max().item() for _, p in net.named_parameters()]))
+    errs, cos = {}, {}
+    for k, p in net.named_parameters():
+        want, got = p.grad.numpy().ravel(), gsd[k].ravel()
+        if np.abs(want).max() < 1e-3 * typ and np.abs(got).max() < 5e-2 * typ:
+            continue                 # analytically zero: fp32 holds ~1e-9 of noise there, bf16 storage ~1e-5
+        errs[k] = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        den = np.linalg.norm(got) * np.linalg.norm(want)
+        cos[k] = float(np.dot(got, want) / den) if den > 0 else 1.0
+    worst = sorted(errs, key=errs.get)[-5:]
+    REPORT[what] = {"tensors_compared": len(errs), "worst_tensors": {k: errs[k] for k in worst},
+                    "max_rel_to_max_err": max(errs.values()),
+                    "median_rel_to_max_err": float(np.median(list(errs.values()))),
+                    "min_cosine": min(cos.values()), "lowest_cosines": {k: cos[k] for k in sorted(cos, key=cos.get)[:5]},
+                    "median_cosine": float(np.median(list(cos.values())))}
+    _dump()
+    return errs, cos
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_step_bce_bf16_vs_fp32_oracle(fuse, monkeypatch):
+    """One LocalUpdate.train step (utils/local_training.py:657-675) in bf16 storage vs the fp32 oracle, with and
+    without the gate-on-load fusion: loss to 1e-2, every gradient tensor's direction (cosine) >= 0.98 and
+    its largest deviation <= 10 % of the tensor's max, post-Adam weights inside 2.5 lr of the oracle's."""
+    from fedmlp_amd.engine import Engine
+    monkeypatch.setenv("FM_FUSE_GATE", fuse)
+    e = Engine("Efficient_b0", C_, HW, HW, 16, precision="bf16")
+    try:
+        e.stochastic = False
+        net = _load(e)
+        (x,), y = _data(6, 2)
+        pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+        _, z = net(x)
+        loss = R.loss_train(z, y, pw, 8, C_)
+        opt.zero_grad(); loss.backward(); opt.step()
+        lo = torch.zeros(1, device=e.device)
+        e.step_bce(x.to(e.device), y.to(e.device), pw, 8, lo)
+        rel = abs(lo.item() - loss.item()) / abs(loss.item())
+        errs, cos = _grad_report(e, net, f"bce_fuse{fuse}")
+        REPORT[f"bce_fuse{fuse}"]["loss_rel_err"] = rel
+        _dump()
+        assert rel < 5e-3, rel
+        assert np.median(list(cos.values())) > 0.99 and min(cos.values()) > 0.95, min(cos, key=cos.get)
+        assert np.median(list(errs.values())) < 0.15 and max(errs.values()) < 0.3, max(errs, key=errs.get)
+        flat, _ = e.get_state()
+        sd = spec.flat_to_state_dict("Efficient_b0", C_, flat, np.zeros(e.ni, np.int64))
+        for k, v in net.state_dict().items():
+            if "num_batches" in k or "running" in k:
+                continue
+            assert np.abs(sd[k] - v.numpy()).max() <= 2.5 * LR + 1e-6, k      # Adam's first step is +-lr*sign(g)
+    finally:
+        e.close()
+
+
+def test_step_stage1_bf16_vs_fp32_oracle(eng):
+    import copy
+    net = _load(eng)
+    (x1, x2), y = _data(6, 3, views=2)
+    act, neg = [1], [0, 2, 3, 4]
+    glob = copy.deepcopy(net).eval()
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+    _, z1 = net(x1); _, z2 = net(x2)
+    with torch.no_grad():
+        _, g1 = glob(x1); _, g2 = glob(x2)
+    loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 1)
+    opt.zero_grad(); loss.backward(); opt.step()
+    eng.teacher_snapshot()
+    lo = torch.zeros(1, device=eng.device)
+    mask = [1.0 if c in act else 0.0 for c in range(C_)]
+    eng.step_stage1(x1.to(eng.device), x2.to(eng.device), y.to(eng.device), mask, 1, 8, lo)
+    rel = abs(lo.item() - loss.item()) / abs(loss.item())
+    errs, cos = _grad_report(eng, net, "stage1")
+    REPORT["stage1"]["loss_rel_err"] = rel
+    _dump()
+    assert rel < 5e-3, rel
+    assert np.median(list(cos.values())) > 0.99 and min(cos.values()) > 0.95
+    assert np.median(list(errs.values())) < 0.15 and max(errs.values()) < 0.3
+
+
+def test_bf16_training_reduces_the_loss_like_fp32(eng):
+    """30 Adam steps on one fixed batch in bf16 storage: the loss curve follows the fp32 oracle's
+    (same init, same data) within 3 % at every step and ends lower than it started."""
+    net = _load(eng)
+    (x,), y = _data(8, 7)
+    pw = [2.0] * C_
+    eng.adam_reset(1e-3)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=5e-4)
+    lo = torch.zeros(30, device=eng.device)
+    want = []
+    for s in range(30):
+        _, z = net(x)
+        loss = R.loss_train(z, y, pw, 8, C_)
+        opt.zero_grad(); loss.backward(); opt.step()
+        want.append(loss.item())
+        eng.step_bce(x.to(eng.device), y.to(eng.device), pw, 8, lo[s:s + 1])
+    got = lo.cpu().numpy()
+    REPORT["train30"] = {"loss_first": float(got[0]), "loss_last": float(got[-1]), "oracle_last": want[-1],
+                         "max_rel_dev": float(np.max(np.abs(got - np.array(want)) / np.array(want)))}
+    _dump()
+    assert got[-1] < 0.01 * got[0]
+    np.testing.assert_allclose(got[:3], np.array(want)[:3], rtol=5e-3)
+    np.testing.assert_allclose(got, np.array(want), rtol=0.25)       # lr 1e-3: rounding-level gradient differences compound
+    np.testing.assert_allclose(got[-1], want[-1], rtol=0.05)           # ... and wash out again as the fit converges
+
+
+def test_bf16_224_eval_and_step_are_finite_and_close(eng):
+    from fedmlp_amd.engine import Engine
+    e = Engine("Efficient_b0", C_, 224, 224, 8, precision="bf16")
+    try:
+        e.stochastic = False
+        net = _load(e)
+        x = torch.randn((3, 3, 224, 224), generator=torch.Generator().manual_seed(8))
+        net.eval()
+        with torch.no_grad():
+            f, z = net(x)
+        fe, ze = e.forward_eval(x.to(e.device))
+        ez = _rel(ze.cpu().numpy(), z.numpy())
+        REPORT["eval_224"] = {"logits_rel_to_max": ez, "feature_rel_to_max": _rel(fe.cpu().numpy(), f.numpy())}
+        _dump()
+        assert ez < 1e-2, ez
+        # one training step at the benchmark's spatial size (thin 2x2 late layers of the 64x64 tests are gone)
+        y = torch.zeros((3, C_)); y[0, 1] = 1; y[2, 3] = 1
+        pw = [2.0] * C_
+        net.train()
+        _, z = net(x)
+        loss = R.loss_train(z, y, pw, 4, C_)
+        loss.backward()
+        lo = torch.zeros(1, device=e.device)
+        e.step_bce(x.to(e.device), y.to(e.device), pw, 4, lo)
+        errs, cos = _grad_report(e, net, "bce_224")
+        REPORT["bce_224"]["loss_rel_err"] = abs(lo.item() - loss.item()) / abs(loss.item())
+        _dump()
+        assert REPORT["bce_224"]["loss_rel_err"] < 5e-3
+        assert np.median(list(cos.values())) > 0.995 and min(cos.values()) > 0.95
+    finally:
+        e.close()
