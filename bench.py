@@ -135,8 +135,8 @@ def measured_traffic(kernel_name, args):
     the profiled one."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
-            doc = json.load(f)
-        if doc.get("workload") != workload_key(args):
+            doc = json.load(f).get(workload_key(args))
+        if doc is None:
             return None
         key = kernel_name.replace(" ", "")
         for k, v in doc["kernels"].items():

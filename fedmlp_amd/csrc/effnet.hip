@@ -403,6 +403,24 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int iw0 = ow0 - PT;
+    // (PRELOAD: the thread's whole (K+1) x (K+3) input window requested up front and kept packed in registers.  Built and
+    // measured for bf16: 244 VGPRs = 2 waves per SIMD, depthwise forward 6.2 -> 8.4 ms per step -- off.)
+    constexpr bool PRELOAD = false;
+    uint2 raw[PRELOAD ? K + 1 : 1][PRELOAD ? NIN : 1];
+    if constexpr (PRELOAD) {
+#pragma unroll
+        for (int ir = 0; ir <= K; ++ir) {
+            const int ih = oh0 + ir - PT;
+            const bool rv = (unsigned)ih < (unsigned)Hi;
+            const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) {
+                const int iw = iw0 + j;
+                raw[ir][j] = (rv && (unsigned)iw < (unsigned)Wi) ? *reinterpret_cast<const uint2*>(xr + (size_t)iw * C)
+                                                                 : make_uint2(0u, 0u);
+            }
+        }
+    }
     f32x4 wprev[K];
 #pragma unroll
     for (int ir = 0; ir <= K; ++ir) {
@@ -416,13 +434,18 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ 
         }
         const int ih = oh0 + ir - PT;
         if ((unsigned)ih < (unsigned)Hi) {
-            const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
             f32x4 xin[NIN];
+            if constexpr (PRELOAD) {
 #pragma unroll
-            for (int j = 0; j < NIN; ++j) {
-                const int iw = iw0 + j;
-                xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < NIN; ++j)
+                    xin[j] = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw[ir][j]), f32x4);
+            } else {
+                const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int iw = iw0 + j;
+                    xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
             if (ir < K) {
 #pragma unroll
@@ -463,12 +486,173 @@ static inline bool dw_blk_ok(int K, int S, int Hi, int Wi, int pad_t, int pad_l)
     const int pt = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
     return (K == 3 || K == 5) && (S == 1 || S == 2) && pad_t == pt && pad_l == pt && !getenv("FM_DW_GENERIC");
 }
+// ---- LDS-tiled stride-1 depthwise convolution (forward; with the rotated kernel also the stride-1 data gradient) ----
+// The register-blocked kernels above re-read every input value (K+1)(K+3)/8 = 3 (3x3) or 6 (5x5) times through L1 and
+// run at 1.2-2.7 TB/s of their tensors' bytes while using ~7 % of the FMA rate.  Here a block owns ONE image x a
+// TH x TW output tile x CG = 4 CQ channels: the (TH+K-1) x (TW+K-1) input window is fetched once (16-B loads), converted
+// once, optionally passed through BN + Swish once (PRO: the expand conv's raw output is consumed directly and the
+// post-BN activation never exists in HBM), and parked in LDS as fp32; every thread then computes 2 rows x 4 columns
+// of one channel quad from LDS (ds_read_b128, pixel stride padded by 16 B so that the positions of a lane group fall on
+// different banks).  Weights sit in LDS too ([K*K][CG], rotated for the data gradient).
+template <int K, int TH, int TW, int CQ, typename T, bool PRO>
+__global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ psc, const float* __restrict__ psh, int ipg,
+                                                      int H, int W, int C, int act, int flip, int tiles_x, int tiles_y)
+{
+    constexpr int PT = (K - 1) / 2;
+    constexpr int TIH = TH + K - 1, TIW = TW + K - 1;
+    constexpr int CG = 4 * CQ, PS = CG + 4;                  // channels per block, padded pixel stride (floats)
+    constexpr int NV = VecOf<T>::NV;                         // 16-B global pieces: 4 (fp32) or 8 (bf16) channels
+    constexpr int CPP = CG / (4 * NV);                       // pieces per pixel
+    constexpr bool FAST = NV == 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                                         // [TIH][TIW][PS]
+    float* ws = lds + TIH * TIW * PS;                        // [K*K][CG]
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int img = b / tiles_y;
+    const int c0 = blockIdx.y * CG;
+    const int oh0 = ty * TH, ow0 = tx * TW;
+    // ---- stage weights (rotated by 180 degrees for the data gradient) and the input window ----------------------
+    for (int i = tid; i < K * K * CQ; i += 256) {
+        const int t = i / CQ, q = i - t * CQ;
+        const int c = c0 + 4 * q;
+        const int wi = flip ? K * K - 1 - t : t;
+        st4(ws + t * CG + 4 * q, c < C ? ld4(w + wi * C + c) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    const int g = PRO ? img / ipg : 0;
+    for (int i = tid; i < TIH * TIW * CPP; i += 256) {
+        const int pix = i / CPP, pc = i - pix * CPP;
+        const int r = pix / TIW, cc = pix - r * TIW;
+        const int ih = oh0 + r - PT, iw = ow0 + cc - PT;
+        const int c = c0 + pc * 4 * NV;
+        f32x4 v[NV];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) v[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c < C) {
+            ldv<NV>(x + ((size_t)(img * H + ih) * W + iw) * C + c, v);
+            if constexpr (PRO) {
+                f32x4 sc[NV], sh[NV];
+                ldf<NV>(psc + g * C + c, sc);
+                ldf<NV>(psh + g * C + c, sh);
+#pragma unroll
+                for (int h = 0; h < NV; ++h) v[h] = act_fwd<FAST>(v[h] * sc[h] + sh[h], 2);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NV; ++h) st4(xs + pix * PS + pc * 4 * NV + 4 * h, v[h]);
+    }
+    __syncthreads();
+    // ---- compute: thread = (channel quad, 2 x 4 output block) ---------------------------------------------------------
+    const int cq = tid % CQ, pos = tid / CQ;
+    const int pr = pos / (TW / 4), pcb = pos - pr * (TW / 4);
+    const int r0 = 2 * pr, cb = 4 * pcb;                      // tile-local output row / column of the thread's block
+    const int c = c0 + 4 * cq;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wprev[K];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) wprev[kw] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a REAL loop over the K+1 input rows (not unrolled): unrolled, the compiler hoists all (K+1)(K+3) LDS reads to the
+    // top and the kernel needs 256 VGPRs (one block per CU); one row at a time it needs ~110
+#pragma unroll 1
+    for (int ir = 0; ir <= K; ++ir) {
+        f32x4 wcur[K], xin[K + 3];
+        const int irw = ir < K ? ir : K - 1;                 // row K has no taps of its own (feeds the lower output row only)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wcur[kw] = ld4(ws + (irw * K + kw) * CG + 4 * cq);
+        const float* xr = xs + ((r0 + ir) * TIW + cb) * PS + 4 * cq;
+#pragma unroll
+        for (int j = 0; j < K + 3; ++j) xin[j] = ld4(xr + j * PS);
+        if (ir < K) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[0][j] += xin[j + kw] * wcur[kw];
+        }
+        if (ir >= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[1][j] += xin[j + kw] * wprev[kw];
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
+    }
+    if (c >= C) return;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) { sc = ld4(scale + c); sh = ld4(shift + c); }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oh = oh0 + r0 + r;
+        if (oh >= H) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ow = ow0 + cb + j;
+            if (ow >= W) continue;
+            f32x4 v = acc[r][j];
+            if (scale) v = act_fwd<FAST>(v * sc + sh, act);
+            st4(y + ((size_t)(img * H + oh) * W + ow) * C + c, v);
+        }
+    }
+}
+template <int K, int TH, int TW, int CQ, typename T>
+static void dw_tile_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, const float* psc,
+                           const float* psh, int ipg, int imgs, int H, int W, int C, int act, int flip, hipStream_t s)
+{
+    static_assert((TH / 2) * (TW / 4) * CQ == 256, "one 2x4 output block per thread");
+    constexpr int CG = 4 * CQ;
+    constexpr size_t lds = ((size_t)(TH + K - 1) * (TW + K - 1) * (CG + 4) + (size_t)K * K * CG) * sizeof(float);
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const dim3 grid(tiles_x * tiles_y * imgs, (C + CG - 1) / CG);
+    static bool done = false;
+    if (!done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&dw_tile_kernel<K, TH, TW, CQ, T, false>), (int)lds, "dw_tile_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&dw_tile_kernel<K, TH, TW, CQ, T, true>), (int)lds, "dw_tile_kernel");
+        done = true;
+    }
+    if (psc)
+        hipLaunchKernelGGL((dw_tile_kernel<K, TH, TW, CQ, T, true>), grid, dim3(256), lds, s, x, w, y, scale, shift, psc, psh, ipg, H, W,
+                           C, act, flip, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((dw_tile_kernel<K, TH, TW, CQ, T, false>), grid, dim3(256), lds, s, x, w, y, scale, shift, psc, psh, ipg, H, W,
+                           C, act, flip, tiles_x, tiles_y);
+}
+// tile shape by image width: 16x16 tiles of 32 channels tile 112 exactly; narrower images trade rows for columns / channels
+template <int K, typename T>
+static void dw_tile_t(const T* x, const float* w, T* y, const float* scale, const float* shift, const float* psc, const float* psh,
+                      int ipg, int imgs, int H, int W, int C, int act, int flip, hipStream_t s)
+{
+    if (W >= 100) dw_tile_launch<K, 16, 16, 8, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
+    else if (W >= 40) dw_tile_launch<K, 8, 32, 8, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
+    else if (W >= 12) dw_tile_launch<K, 8, 16, 16, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
+    else dw_tile_launch<K, 8, 8, 32, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
+}
+// Measured (bf16, 1024 images, FM_DW_TILE=2 forces the tiled kernel everywhere): it beats the register-blocked kernels
+// only where 16x16 tiles of 32 channels fit exactly -- block 0's 112x112x32: 0.61 -> 0.53 ms (3.1 TB/s) -- and loses
+// on every narrower layer (56x56x144: 0.77 -> 1.32 ms; 28x28x240: 0.59 -> 0.66 ms): two blocks per CU (57-76 KB of LDS)
+// with a barrier between staging and compute hide latency worse than 16 independent waves.  Default: tiled for W >= 100.
+static inline int dw_tile_mode() { static const int v = getenv("FM_DW_TILE") ? atoi(getenv("FM_DW_TILE")) : 1; return v; }
+static inline bool dw_tile_on(int W) { return dw_tile_mode() == 2 || (dw_tile_mode() == 1 && W >= 100); }
+
 template <typename T>
 static void dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
-                     int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
+                     int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s,
+                     const float* psc = nullptr, const float* psh = nullptr, int ipg = 1)
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
     const dim3 blk(256);
+    if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        if (K == 3) dw_tile_t<3, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
+        else dw_tile_t<5, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
+        return;
+    }
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const dim3 grid(cdiv((int64_t)imgs * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 4), 256));
         if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
@@ -589,6 +773,12 @@ static void dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
     const dim3 blk(256);
+    if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        const float* nul = nullptr;
+        if (K == 3) dw_tile_t<3, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
+        else dw_tile_t<5, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
+        return;
+    }
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         // stride 1: dx = dy (*) rot180(w), the forward kernel with the rotated kernel (Hi == Ho, Wi == Wo)
         const dim3 grid(cdiv((int64_t)imgs * ((Hi + 1) / 2) * ((Wi + 3) / 4) * (C / 4), 256));

@@ -119,31 +119,36 @@ void k_scale(float* x, float w, int64_t n, hipStream_t s)
 // Replaces, for a uint8 cache of already-resized images kept in HBM, the per-sample CPU work of
 // the reference's train transform (dataset/dataset.py:40-53): RandomAffine(10 deg, 2 %) with
 // NEAREST sampling and fill 0, RandomHorizontalFlip, ToTensor, Normalize.  The random draws stay
-// on the host (params); one thread per output pixel, the three channel planes share the source
+// on the host; what crosses the ABI per sample is what Pillow's nearest-neighbour affine walks
+// (libImaging/Geometry.c affine_fixed): the six coefficients in 16.16 fixed point
+//   c2 = FIX(a2 + a0/2 + a1/2), c5 = FIX(a5 + a3/2 + a4/2), c0, c1, c3, c4 = FIX(a0, a1, a3, a4)
+// and the source pixel of output (x, y) is ((c2 + c0 x + c1 y) >> 16, (c5 + c3 x + c4 y) >> 16):
+// integer arithmetic, bit-exact with Pillow.  The flip is applied after the affine (output x reads
+// the affine image at W-1-x).  One thread per output pixel, the three channel planes share the source
 // coordinate.  HBM-bound: reads <= 3 B, writes 12 B per pixel.
 __global__ void augment_kernel(const uint8_t* __restrict__ cache, const int* __restrict__ idx,
-                               const float* __restrict__ params, float* __restrict__ out, int H, int W, float m0,
+                               const int* __restrict__ params, float* __restrict__ out, int H, int W, float m0,
                                float m1, float m2, float s0, float s1, float s2)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= H * W) return;
     const int y = i / W, x = i - y * W;
-    const float* p = params + b * 8;
-    const int xs = p[6] != 0.f ? W - 1 - x : x;                // flip is applied after the affine
-    const float fx = xs + 0.5f, fy = y + 0.5f;
-    const int xin = (int)floorf(p[0] * fx + p[1] * fy + p[2]);
-    const int yin = (int)floorf(p[3] * fx + p[4] * fy + p[5]);
+    const int* p = params + b * 8;
+    const int xs = p[6] != 0 ? W - 1 - x : x;
+    const int xin = (p[2] + p[0] * xs + p[1] * y) >> 16;        // arithmetic shift = floor, as in C on int
+    const int yin = (p[5] + p[3] * xs + p[4] * y) >> 16;
     const bool ok = xin >= 0 && xin < W && yin >= 0 && yin < H;
     const uint8_t* src = cache + (size_t)idx[b] * 3 * H * W + (ok ? yin * W + xin : 0);
     const float v0 = ok ? (float)src[0] : 0.f, v1 = ok ? (float)src[(size_t)H * W] : 0.f,
                 v2 = ok ? (float)src[(size_t)2 * H * W] : 0.f;
     float* o = out + (size_t)b * 3 * H * W + i;
-    o[0] = (v0 / 255.f - m0) / s0;
-    o[(size_t)H * W] = (v1 / 255.f - m1) / s1;
-    o[(size_t)2 * H * W] = (v2 / 255.f - m2) / s2;
+    // ToTensor: float32 / 255 ; Normalize: (v - mean) / std -- IEEE division, no reciprocal, no contraction
+    o[0] = __fdiv_rn(__fsub_rn(__fdiv_rn(v0, 255.f), m0), s0);
+    o[(size_t)H * W] = __fdiv_rn(__fsub_rn(__fdiv_rn(v1, 255.f), m1), s1);
+    o[(size_t)2 * H * W] = __fdiv_rn(__fsub_rn(__fdiv_rn(v2, 255.f), m2), s2);
 }
-void k_augment(const uint8_t* cache, const int* idx, const float* params, float* out, int B, int H, int W,
+void k_augment(const uint8_t* cache, const int* idx, const int* params, float* out, int B, int H, int W,
                float m0, float m1, float m2, float s0, float s1, float s2, hipStream_t s)
 {
     hipLaunchKernelGGL(augment_kernel, dim3(cdiv((int64_t)H * W, 256), B), dim3(256), 0, s, cache, idx, params, out,

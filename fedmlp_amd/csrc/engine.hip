@@ -1615,7 +1615,7 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
     return FM_OK;
 }
 
-int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const float* params_dev, int32_t B,
+int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const int32_t* params_dev, int32_t B,
                const float* mean_host, const float* std_host, float* out_dev)
 {
     ARGCHK(e && cache_dev && idx_dev && params_dev && mean_host && std_host && out_dev && B >= 1, "null");

@@ -25,9 +25,9 @@ void k_scale(float* x, float w, int64_t n, hipStream_t s);
 void k_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);   // y = a*y + b*x
 
 // ---- input pipeline: uint8 HBM cache -> augmented, normalised fp32 NCHW batch.
-// params[b] = {m0..m5 (inverse affine, PIL AFFINE convention), flip, unused}; nearest sampling,
+// params[b] = {c0, c1, c2, c3, c4, c5 (Pillow's 16.16 fixed-point inverse affine), flip, unused}; nearest sampling,
 // fill 0, then horizontal flip, /255, (v-mean)/std   (dataset/dataset.py:40-53 pipeline)
-void k_augment(const uint8_t* cache, const int* idx, const float* params, float* out, int B, int H, int W,
+void k_augment(const uint8_t* cache, const int* idx, const int* params, float* out, int B, int H, int W,
                float m0, float m1, float m2, float s0, float s1, float s2, hipStream_t s);
 
 // ---- batch norm ---------------------------------------------------------------

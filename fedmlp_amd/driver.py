@@ -49,6 +49,15 @@ def args_parser():
     return p.parse_args()
 
 
+def AugmentedDeviceDataset(n, C, hw, seed, device):
+    """synthetic uint8 images behind fedmlp_amd.augment.AugmentedDataset (uint8 HBM cache + fm_augment)"""
+    from fedmlp_amd.augment import AugmentedDataset
+    rs = np.random.RandomState(seed)
+    imgs = rs.randint(0, 256, size=(n, 3, hw, hw)).astype(np.uint8)
+    targets = (rs.uniform(size=(n, C)) < 0.15).astype(np.float32)
+    return AugmentedDataset(imgs, targets, train=True, generator=torch.Generator().manual_seed(seed))
+
+
 class DeviceDataset:
     """dataset/all_dataset.py:64-83 contract on synthetic data kept in HBM."""
 

@@ -261,10 +261,12 @@ class Engine:
 
     # ---- input pipeline ---------------------------------------------------------------
     def augment(self, cache_u8, idx, params, mean, std):
-        """uint8 cache [N,3,H,W] + sample indices [B] (int32) + affine/flip params [B,8] -> fp32 NCHW batch."""
+        """uint8 cache [N,3,H,W] + sample indices [B] (int32) + fixed-point affine/flip records [B,8] (int32,
+        fedmlp_amd.augment.fixed_point_params) -> fp32 NCHW batch."""
         B = idx.shape[0]
         out = torch.empty((B, 3, self.in_h, self.in_w), device=self.device, dtype=torch.float32)
         assert cache_u8.is_cuda and cache_u8.dtype == torch.uint8 and cache_u8.is_contiguous()
+        assert params.dtype == torch.int32 and params.shape == (B, 8)
         _lib.check(self.lib.fm_augment(self.h, C.c_void_p(cache_u8.data_ptr()), _ptr(idx), _ptr(params), B,
                                        _lib.fvec(mean, 3), _lib.fvec(std, 3), _ptr(out)))
         return out

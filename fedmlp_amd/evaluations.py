@@ -64,6 +64,11 @@ def multilabel_metrics(all_labels, all_probs, threshold=0.5):
             "hamming_loss": hamming}
 
 
+def _hw(ds):
+    s = ds[0]["image"]
+    return int(s.shape[-2]), int(s.shape[-1])
+
+
 def globaltest(net, test_dataset, args):
     """utils/evaluations.py:15-73 with the forward on the HIP engine."""
     net.eval()
@@ -74,7 +79,9 @@ def globaltest(net, test_dataset, args):
     probs = []
     for i in range(0, n, bs):
         idx = list(range(i, min(n, i + bs)))
-        if views is not None and "image" in views:
+        if hasattr(test_dataset, "device_batch"):
+            x = test_dataset.device_batch(net.bind(*_hw(test_dataset), bs), "image", idx)
+        elif views is not None and "image" in views:
             x = views["image"][i:i + len(idx)]
         else:
             x = torch.stack([torch.as_tensor(test_dataset[j]["image"], dtype=torch.float32) for j in idx])

@@ -99,6 +99,7 @@ class LocalUpdate(object):
         self.traindata_idx = []
         self.idxss = []
         self.order_queue = []
+        self.tagging_log = None            # set to [] to record (class, pool, similarities) of every tagging call
         self._dev = {}
 
     # ---- data plumbing -------------------------------------------------------------------
@@ -119,6 +120,10 @@ class LocalUpdate(object):
 
     def _images(self, eng, key, pos):
         ds_idx = [self.idxs[p] for p in pos]
+        if hasattr(self.dataset, "device_batch"):
+            # HBM-resident uint8 cache + fm_augment: a fresh RandomAffine / HFlip draw per sample and per view,
+            # like dataset/all_dataset.py:66-91 applies its transform inside every __getitem__
+            return self.dataset.device_batch(eng, key, ds_idx)
         v = self._views(eng)
         if v is not None and key in v:
             sel = torch.as_tensor(ds_idx, device=eng.device, dtype=torch.long)
@@ -421,6 +426,9 @@ class LocalUpdate(object):
             if len(pool_idx):
                 sim = eng.cos_tag(pool_f.contiguous(), proto_dev, [cls])
                 top, bot = eng.select_topk(sim[0], a.clean_threshold, a.noise_threshold)
+                if self.tagging_log is not None:       # parity tests: similarity of every pool sample of this round
+                    self.tagging_log.append({"rnd": rnd, "cls": cls, "pool_idx": list(pool_idx),
+                                             "sim": sim[0].cpu().numpy()})
             else:
                 top, bot = [], []
             clean = [int(pool_idx[j]) for j in top]

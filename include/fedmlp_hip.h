@@ -191,10 +191,15 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
 /* Train transform of dataset/dataset.py:40-53 on a uint8 cache of already-resized images
  * [N,3,H,W] kept in HBM: RandomAffine(10 deg, translate 2 %) with NEAREST sampling and fill 0,
  * RandomHorizontalFlip, ToTensor (/255), Normalize(mean, std).  The random draws are the
- * caller's: params_dev[b] = {m0..m5 = inverse affine matrix in PIL's AFFINE convention
- * (source = M * (x+0.5, y+0.5, 1)), flip (0/1), unused}.  idx_dev[b] = sample index in the cache.
- * out_dev: fp32 NCHW [B,3,H,W], i.e. what fm_step_* consume.  mean/std: host[3]. */
-int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const float* params_dev,
+ * caller's.  params_dev[b] = int32 {c0, c1, c2, c3, c4, c5, flip (0/1), unused}: the inverse affine
+ * matrix (PIL AFFINE convention: source = M * (x, y, 1)) in the 16.16 fixed point Pillow's
+ * nearest-neighbour affine uses (libImaging/Geometry.c affine_fixed):
+ *   c0, c1, c3, c4 = FIX(a0, a1, a3, a4), c2 = FIX(a2 + a0/2 + a1/2), c5 = FIX(a5 + a3/2 + a4/2),
+ *   FIX(v) = floor(v * 65536 + 0.5); source pixel = ((c2 + c0 x + c1 y) >> 16, (c5 + c3 x + c4 y) >> 16).
+ * Integer arithmetic: the result is bit-exact with the PIL pipeline (tests/golden/augment_pil.npz).
+ * idx_dev[b] = sample index in the cache.  out_dev: fp32 NCHW [B,3,H,W], i.e. what fm_step_* consume.
+ * mean/std: host[3]. */
+int fm_augment(fm_engine* e, const uint8_t* cache_dev, const int32_t* idx_dev, const int32_t* params_dev,
                int32_t B, const float* mean_host, const float* std_host, float* out_dev);
 
 /* ---- generic train step (the other baselines of main.py's --exp switch) -----

@@ -50,7 +50,7 @@ import utils.utils as UU                   # noqa: E402  (reference)
 
 from fedmlp_amd import spec                # noqa: E402
 from oracle.resnet18_ref import ResNet18Ref  # noqa: E402
-from tests.synth import synth_arrays, class_lists  # noqa: E402
+from tests.synth import synth_arrays, class_lists, perturbed_bn  # noqa: E402
 
 torch.set_num_threads(8)
 torch.use_deterministic_algorithms(True)
@@ -240,21 +240,34 @@ def g_train_traj(out):
     json.dump(rec, open(os.path.join(out, "traj_train.json"), "w"), indent=1)
 
 
-def g_fedmlp_traj(out):
+def perturb_bn(net, seed):
+    """non-trivial BatchNorm affine (gamma = 1 + 0.1 n, beta = 0.1 n): with the default beta = 0 the first Adam
+    steps move every bias by +-lr*sign(g), which makes ~1e-3 norms of rounding-level gradients (the conditioned
+    goldens start from here; the GPU tests rebuild the same init from the recorded seed)."""
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, v in perturbed_bn([(k, tuple(t.shape)) for k, t in sd.items()], seed):
+            sd[k].copy_(torch.from_numpy(v))
+    return net
+
+
+def g_fedmlp_traj(out, C=4, n_cl=2, N=512, hw=32, data_seed=23, order_seed=202, bn_seed=None,
+                  name="traj_fedmlp", p_pos=0.3):
     """full FedMLP two-stage flow (train_FedMLP, utils/local_training.py:904-1256
     + main.py:178-237 aggregation): 2 clients x 512 samples, C=4, bs 32, 32x32,
     S1 = 2 (rounds 0-1 stage 1, prototype pass at rnd 1; rounds 2-3 stage 2)."""
-    C, n_cl, N, hw = 4, 2, 512, 32
     args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=2)
-    ds = SynthDataset(n_cl * N, C, hw, 23, True)
+    ds = SynthDataset(n_cl * N, C, hw, data_seed, True, p_pos)
     pos, neg = class_lists(ds.targets, C)
     users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
-    rs = np.random.RandomState(202)
+    rs = np.random.RandomState(order_seed)
     netglob = build_net(C, 1037)
+    if bn_seed is not None:
+        perturb_bn(netglob, bn_seed)
     locals_ = [LT.LocalUpdate(args, i, deepcopy(ds), users[i], pos, neg, active_class_list=[i])
                for i in range(n_cl)]
-    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": 23, "init_seed": 1037,
-           "bs": 32, "S1": 2, "users": users, "rounds": []}
+    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": data_seed, "init_seed": 1037,
+           "bn_seed": bn_seed, "p_pos": p_pos, "bs": 32, "S1": 2, "users": users, "rounds": []}
     xprobe = torch.from_numpy(ds.x1[:4])
     tao, Prototype = [0] * C, []
     neg_lists, act_lists = [None] * n_cl, [None] * n_cl
@@ -308,8 +321,45 @@ def g_fedmlp_traj(out):
         r["glob_norms"] = tensor_norms(netglob.state_dict())
         r["probe_logits"] = z.tolist()
         rec["rounds"].append(r)
-    json.dump(rec, open(os.path.join(out, "traj_fedmlp.json"), "w"), indent=1)
-    np.savez_compressed(os.path.join(out, "traj_fedmlp_protos.npz"), **protos_npz)
+    json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(out, name + "_protos.npz"), **protos_npz)
+
+
+def g_fedmlp64(out):
+    """the same two-stage flow on a conditioned problem: 64x64 inputs (layer 4 keeps 2x2 pixels,
+    128 values per channel at bs 32), 2 clients x 1024 samples, non-trivial BatchNorm affine."""
+    g_fedmlp_traj(out, C=4, n_cl=2, N=1024, hw=64, data_seed=29, order_seed=212, bn_seed=77, name="traj_fedmlp64")
+
+
+def g_fedmlp_c14(out):
+    """BASELINE configs[2] shape: 14 labels.  3 clients (client i annotates class i, main.py:76) x 448 samples: the
+    classes 3..13 have no active client at all, so their global prototypes are NaN rows (utils/FedAvg.py:85-86) and
+    tagging silently selects nothing for them while classes 0-2 are tagged on the clients that miss them."""
+    g_fedmlp_traj(out, C=14, n_cl=3, N=448, hw=32, data_seed=53, order_seed=222, bn_seed=78, name="traj_fedmlp_c14",
+                  p_pos=0.2)
+
+
+def g_step_full(out):
+    """ONE FedMLP stage-1 step at the benchmarked size through the reference's own train_FedMLP
+    (utils/local_training.py:907-970): bs 128, two 3x224x224 views, C = 5 -- the configuration bench.py times.
+    Records the loss and, from the net object the trainer updated, the gradient of every parameter tensor
+    (L2 norm, sum, first 3 values) plus post-step norms."""
+    C, N, hw = 5, 128, 224
+    args = make_args(n_classes=C, n_clients=1, batch_size=128)
+    ds = SynthDataset(N, C, hw, 61, True)
+    pos, neg = class_lists(ds.targets, C)
+    net = perturb_bn(build_net(C, 1037), 79)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 128, True)
+    work = deepcopy(net)
+    ret = loc.train_FedMLP(0, [0] * C, [], None, None, None, net=work)
+    grads = {k: {"norm": float(torch.linalg.vector_norm(p.grad.double())), "sum": float(p.grad.double().sum()),
+                 "head": [float(v) for v in p.grad.reshape(-1)[:3]], "absmax": float(p.grad.abs().max())}
+             for k, p in work.named_parameters()}
+    rec = {"C": C, "N": N, "hw": hw, "data_seed": 61, "init_seed": 1037, "bn_seed": 79, "bs": 128,
+           "loss": float(ret[1]), "grads": grads, "norms": tensor_norms(ret[0])}
+    json.dump(rec, open(os.path.join(out, "step_full.json"), "w"), indent=1)
 
 
 def g_fixmatch_traj(out):
@@ -459,7 +509,8 @@ def g_baselines(out):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224", "eval", "baselines"]
     fns = {"kat": g_kat, "train": g_train_traj, "fedmlp": g_fedmlp_traj,
-           "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval, "baselines": g_baselines}
+           "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval, "baselines": g_baselines,
+           "fedmlp64": g_fedmlp64, "fedmlp_c14": g_fedmlp_c14, "step_full": g_step_full}
     for w in which:
         print("==> golden:", w, flush=True)
         fns[w](HERE)

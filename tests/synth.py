@@ -20,3 +20,19 @@ def class_lists(targets, C):
     (class_neg_idx[c] = every positive of class c, order irrelevant)."""
     pos = [np.where(targets[:, c] == 1)[0] for c in range(C)]
     return pos, [p.copy() for p in pos]
+
+
+def perturbed_bn(sd_items, seed):
+    """Non-trivial BatchNorm affine for the conditioned goldens: walking the state_dict in key order, every BN
+    weight becomes 1 + 0.1 n and every BN bias 0.1 n (n ~ N(0,1) from RandomState(seed)).  Yields (key, array)
+    only for the entries it replaces.  Used by tests/golden/make_golden.py (on the reference side) and by the GPU
+    tests (on the engine side), so both start from bit-identical weights."""
+    rs = np.random.RandomState(seed)
+    for k, shape in sd_items:
+        if len(shape) != 1:
+            continue
+        is_bn = ("bn" in k) or ("downsample.1" in k)
+        if is_bn and k.endswith(".weight"):
+            yield k, (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+        elif is_bn and k.endswith(".bias"):
+            yield k, (0.1 * rs.standard_normal(shape)).astype(np.float32)

@@ -31,8 +31,8 @@ class SynthDataset:
     """dataset/all_dataset.py:64-83 contract on synthetic tensors, plus an
     HBM-resident cache (`device_views`) so batches are gathered on the GPU."""
 
-    def __init__(self, n, C, hw, seed, two_view):
-        self.targets, x1, x2 = synth_arrays(n, C, hw, seed, two_view)
+    def __init__(self, n, C, hw, seed, two_view, p_pos=0.3):
+        self.targets, x1, x2 = synth_arrays(n, C, hw, seed, two_view, p_pos)
         self.two_view = two_view
         self.x1, self.x2 = torch.from_numpy(x1), (torch.from_numpy(x2) if two_view else None)
         self._views = None

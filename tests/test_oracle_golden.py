@@ -251,3 +251,19 @@ def test_traj_baselines_rscfed_fednoro_cbafed():
     assert_norms_close(norms_of(sd), r["norms"][1], 1e-5)
     assert cnum == r["class_num_list"][1] and dnum == r["data_num"][1]
     np.testing.assert_allclose(cl.loss_w, r["loss_w_after"], rtol=1e-12)
+
+
+def test_augment_oracle_is_bit_exact_with_pillow_fixture():
+    """oracle/augment_ref.py (fixed-point nearest affine + flip + ToTensor + Normalize) against outputs of Pillow
+    itself recorded by tests/golden/make_augment_golden.py: uint8 and float32 bit for bit."""
+    import os
+    from oracle.augment_ref import affine_nearest_u8, augment_ref
+    from fedmlp_amd.augment import IMAGENET_MEAN, IMAGENET_STD
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_pil.npz"))
+    for i in range(len(g["images"])):
+        a = affine_nearest_u8(g["images"][i], g["matrices"][i])
+        if g["flips"][i]:
+            a = a[:, :, ::-1]
+        np.testing.assert_array_equal(a, g["out_u8"][i])
+        np.testing.assert_array_equal(augment_ref(g["images"][i], g["matrices"][i], g["flips"][i], IMAGENET_MEAN,
+                                                  IMAGENET_STD), g["out_f32"][i])
