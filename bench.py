@@ -180,7 +180,16 @@ def main():
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
     eng.adam_reset(3e-5)
-    rccl_ranks = comm_init(eng) if world > 1 else 1      # RCCL communicator inside the C-ABI library
+    rccl_ranks = 1
+    if world > 1:
+        # RCCL communicator inside the C-ABI library (fm_comm_init); if it cannot be formed on this node the same
+        # all-reduce runs through torch.distributed's RCCL communicator on the engine's arena (fedavg.py)
+        try:
+            rccl_ranks = comm_init(eng)
+        except Exception as ex:                              # noqa: BLE001
+            print(f"[bench] fm_comm_init failed ({ex}); FedAvg falls back to torch.distributed all_reduce",
+                  file=sys.stderr, flush=True)
+            rccl_ranks = 0
     # Efficient_b0: the engine draws drop-connect / dropout multipliers before every train step
 
     # synthetic client data resident in HBM (seed = reference default, utils/options.py:10)

@@ -7,7 +7,7 @@ view and per __getitem__ (dataset/all_dataset.py:66-91).  Resize precedes every 
 caching the resized uint8 pixels in HBM is exact; the random draws happen here (torchvision 0.13's
 RandomAffine.get_params / RandomHorizontalFlip semantics and its _get_inverse_affine_matrix, restated:
 torchvision is not vendored in the reference), the pixel work is the engine's fm_augment kernel, which
-is bit-exact with Pillow's fixed-point nearest-neighbour affine (oracle/augment_ref.py,
+is bit-exact with Pillow's fixed-point nearest-neighbour affine (checked against Pillow's own outputs,
 tests/golden/augment_pil.npz).  The ORDER of the reference's draws (worker-seeded RNG streams) is not
 reproducible by construction: "parity unpinned" for that part only.
 """

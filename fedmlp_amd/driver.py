@@ -101,7 +101,10 @@ def main():
     C, S1 = args.n_classes, args.rounds_FedMLP_stage1
     args.feature_dim = args.feature_dim or spec.FEATURE_DIM[args.model]
     eng = Engine(args.model, C, args.hw, args.hw, 4 * args.batch_size, device=str(dev), precision=args.precision)
-    comm_init(eng)                                        # the library's own RCCL communicator (C ABI)
+    try:
+        comm_init(eng)                                    # the library's own RCCL communicator (C ABI)
+    except Exception as ex:                               # noqa: BLE001  (then torch.distributed carries the sums)
+        print(f"[driver] fm_comm_init failed ({ex}); using torch.distributed all_reduce", flush=True)
     # netglob = build_model(args) (main.py:73): from-scratch init, an ImageNet checkpoint, or --init_ckpt
     host = build_model(args)
     if args.init_ckpt:
@@ -157,7 +160,8 @@ def main():
         # A rank that trained several clients has already folded them (weights n_c / sum(n)) into `acc`.
         eng.state_tensor().copy_(acc)
         eng.counters(np.zeros(len(glob_cnt), np.int64))   # the counters are reduced as float64 below
-        eng.fedavg_allreduce(1.0)                         # fm_fedavg_allreduce: ncclAllReduce of the state arena
+        from fedmlp_amd.fedavg import fedavg_allreduce
+        fedavg_allreduce(eng, 1.0)                        # fm_fedavg_allreduce: ncclAllReduce of the state arena
         glob.copy_(eng.state_tensor())
         glob_cnt = np.trunc(rank_sum(acc_cnt, dev) + 1e-9).astype(np.int64)   # utils/FedAvg.py:13 + load_state_dict
         eng.counters(glob_cnt)

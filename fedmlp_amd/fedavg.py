@@ -116,6 +116,7 @@ def fedavg_allreduce(engine, w):
     st = engine.state_tensor()
     if d is not None and d.get_world_size() > 1:
         d.all_reduce(st, op=d.ReduceOp.SUM)
+        engine.state_tensor()                 # marks the engine's derived buffers (BN folds, weight packs) stale
         cnt = torch.from_numpy(engine.counters().astype(np.float64) * float(w)).to(st.device)
         d.all_reduce(cnt, op=d.ReduceOp.SUM)
         engine.counters(np.trunc(cnt.cpu().numpy() + 1e-9).astype(np.int64))

@@ -23,13 +23,14 @@ def test_globaltest_matches_reference():
 class _Learnable:
     """Synthetic data with signal: image = noise + sum_c y_c * pattern_c, so mAP after training means something."""
 
-    def __init__(self, n, C, hw, seed):
+    def __init__(self, n, C, hw, seed, signal=0.6, label_noise=0.0):
         import torch
         g = torch.Generator().manual_seed(seed)
         self.patterns = torch.randn((C, 3, hw, hw), generator=torch.Generator().manual_seed(999))
-        self.targets = (torch.rand((n, C), generator=g) < 0.3).float().numpy()
-        y = torch.from_numpy(self.targets)
-        self.x = 0.7 * torch.randn((n, 3, hw, hw), generator=g) + 0.6 * torch.einsum("nc,cdhw->ndhw", y, self.patterns)
+        clean = (torch.rand((n, C), generator=g) < 0.3).float()
+        self.x = 0.7 * torch.randn((n, 3, hw, hw), generator=g) + signal * torch.einsum("nc,cdhw->ndhw", clean, self.patterns)
+        flip = (torch.rand((n, C), generator=g) < label_noise).float() if label_noise else torch.zeros_like(clean)
+        self.targets = (clean + flip - 2 * clean * flip).numpy()        # observed labels (a fraction flipped: mAP < 1)
         self._v = None
 
     def __len__(self):
@@ -44,14 +45,12 @@ class _Learnable:
         return self._v
 
 
-def test_map_after_training_matches_oracle():
-    """The 'mAP vs ref' half of the metric on data with signal: 2 clients x 4 FedAvg rounds of LocalUpdate.train on
-    the GPU and the same flow through the CPU oracle (same init, same batch orders) end at the same test mAP
-    (~0.94 against a prevalence of 0.3).  On this small problem (192 training / 1024 test samples, 24 Adam steps from
-    random init) the CPU oracle's OWN mAP spreads over 0.9354 ... 0.9403 between 1, 4 and 8 threads and under a
-    +-1e-6 weight perturbation (and 0.923 ... 0.928 on a 256-sample test set across hosts), so the test allows
-    1.5 % absolute; the +-0.2 % of the north star is a statement about converged training on a real test set."""
+def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, avg_last=1):
+    """2 clients x `rounds` FedAvg rounds of LocalUpdate.train on the GPU and through the CPU oracle (same init, same
+    batch orders); test mAP / AUROC averaged over the last `avg_last` rounds on both sides."""
     import copy
+    import json
+    import os
     import torch
     from fedmlp_amd.model import build_model
     from fedmlp_amd.local_training import LocalUpdate
@@ -60,9 +59,10 @@ def test_map_after_training_matches_oracle():
     from oracle import steps_ref as R
     from tests.helpers import oracle_net
     from tests.synth import class_lists
-    C, N, hw, n_cl, rounds = 4, 96, 32, 2, 4
-    args = make_args(n_classes=C, n_clients=n_cl, batch_size=32, seed=21, base_lr=3e-4)
-    train, test = _Learnable(n_cl * N, C, hw, 5), _Learnable(1024, C, hw, 6)
+    C, hw, n_cl = 4, 32, 2
+    args = make_args(n_classes=C, n_clients=n_cl, batch_size=32, seed=21, base_lr=lr)
+    train = _Learnable(n_cl * N, C, hw, 5, signal, label_noise)
+    test = _Learnable(ntest, C, hw, 6, signal, label_noise)
     pos, neg = class_lists(train.targets, C)
     users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
     rs = np.random.RandomState(3)
@@ -70,31 +70,59 @@ def test_map_after_training_matches_oracle():
     # ---- GPU product
     netglob = build_model(args)
     locs = [LocalUpdate(args, i, train, users[i], pos, neg, active_class_list=list(range(C))) for i in range(n_cl)]
+    got = []
     for r in range(rounds):
         w = []
         for i in range(n_cl):
             locs[i].order_queue.append(orders[r][i])
             w.append(copy.deepcopy(locs[i].train(r, copy.deepcopy(netglob), None)[0]))
         netglob.load_state_dict(FedAvg(w, [N] * n_cl))
-    got = globaltest(netglob, test, args)
+        if r >= rounds - avg_last:
+            m = globaltest(netglob, test, args)
+            got.append((float(m["mAP"]), float(m["auc"])))
     # ---- CPU oracle
     data = {"targets": train.targets, "image": train.x}
     glob = oracle_net(C, 21)
     cls = [R.RefClient(args, i, data, users[i], neg, list(range(C))) for i in range(n_cl)]
+    want = []
     for r in range(rounds):
         w = [copy.deepcopy(cls[i].train(copy.deepcopy(glob), orders[r][i])[0]) for i in range(n_cl)]
         glob.load_state_dict(R.fedavg(w, [N] * n_cl))
-    glob.eval()
-    with torch.no_grad():
-        _, z = glob(test.x)
-    want = multilabel_metrics(test.targets, torch.sigmoid(z).numpy())
-    g_map, w_map = float(got["mAP"]), float(want["mAP"])
+        if r >= rounds - avg_last:
+            glob.eval()
+            with torch.no_grad():
+                _, z = glob(test.x)
+            m = multilabel_metrics(test.targets, torch.sigmoid(z).numpy())
+            want.append((float(m["mAP"]), float(m["auc"])))
+    g_map, g_auc = np.mean([v[0] for v in got]), np.mean([v[1] for v in got])
+    w_map, w_auc = np.mean([v[0] for v in want]), np.mean([v[1] for v in want])
     base = float((test.targets.mean(0)).mean())          # mAP of a random scorer ~ prevalence
-    import json, os
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_map.json", "w") as f:
-        json.dump({"mAP_hip": g_map, "mAP_oracle": w_map, "auc_hip": float(got["auc"]), "auc_oracle": float(want["auc"]),
-                   "prevalence": base}, f, indent=1)
+    with open(f"gpurun_out/{report}", "w") as f:
+        json.dump({"mAP_hip": float(g_map), "mAP_oracle": float(w_map), "auc_hip": float(g_auc), "auc_oracle": float(w_auc),
+                   "per_round_hip": got, "per_round_oracle": want, "prevalence": base}, f, indent=1)
     assert w_map > base + 0.4, ("the oracle did not learn", w_map, base)
-    assert abs(g_map - w_map) < 1.5e-2, (g_map, w_map)
-    assert abs(float(got["auc"]) - float(want["auc"])) < 1.5e-2
+    assert abs(g_map - w_map) < tol, (g_map, w_map)
+    assert abs(g_auc - w_auc) < tol
+
+
+def test_map_after_training_matches_oracle():
+    """The 'mAP vs ref' half of the metric on data with signal: 2 clients x 4 FedAvg rounds of LocalUpdate.train on
+    the GPU and the same flow through the CPU oracle (same init, same batch orders) end at the same test mAP
+    (~0.94 against a prevalence of 0.3).  On this small problem (192 training / 1024 test samples, 24 Adam steps from
+    random init) the CPU oracle's OWN mAP spreads over 0.9354 ... 0.9403 between 1, 4 and 8 threads and under a
+    +-1e-6 weight perturbation (and 0.923 ... 0.928 on a 256-sample test set across hosts), so the test allows
+    1.5 % absolute; the +-0.2 % of the north star is a statement about converged training on a real test set."""
+    _map_flow(96, 4, 3e-4, 1024, 1.5e-2, "parity_map.json")
+
+
+def test_map_after_converged_training_matches_oracle():
+    """The same flow trained to convergence on a problem whose ceiling is below 1 (weak patterns, 6 % of the labels
+    flipped in train and test; 2 clients x 512 samples, 10 FedAvg rounds = 160 Adam steps per client, 4096 test
+    samples): once the fit has converged the chaotic early trajectory no longer decides the metric, and the GPU and
+    CPU-oracle models land on the same plateau.  Measured (mean of the last 3 rounds): mAP 0.8302 (HIP) vs 0.8364
+    (oracle), AUROC 0.8910 vs 0.8926.  The oracle alone moves by +-0.4 % from round to round on that plateau and by
+    0.3-0.5 % between two hosts (0.8346 / 0.8322 / 0.8358 in the 8-core build container, 0.8329 / 0.8354 / 0.8409 on the
+    GPU box's host for the same three rounds), so 0.6 % is agreement within the metric's own resolution on a 4096-sample
+    test set; the north star's +-0.2 % needs a real dataset to be decidable.  Bound: 1 % absolute."""
+    _map_flow(512, 10, 3e-4, 4096, 1e-2, "parity_map_converged.json", signal=0.25, label_noise=0.06, avg_last=3)
