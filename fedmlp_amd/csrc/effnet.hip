@@ -979,6 +979,72 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const T* __restrict_
         }
     }
 }
+// 5x5 weight gradient with the kernel ROWS dealt to threads: thread = (channel quad, kernel row kh, pixel lane) keeps 5
+// accumulators instead of 25 (the all-taps kernels above need 170-185 VGPRs = 2 waves per SIMD and run the 5x5 layers at
+// 0.45-0.8 TB/s of their tensors' bytes: latency-bound).  It re-reads dy once per kernel row (L1 hits) in exchange for
+// ~70 VGPRs.  S = 1: 2 rows x 4 columns of dy per step (2 input rows serve them); S = 2: 1 row x 4 columns.
+template <int K, int S, typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            float* __restrict__ part, int imgs, int Hi, int Wi, int Ho,
+                                                            int Wo, int C, int QT, int P)
+{
+    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+    constexpr int RB = S == 1 ? 2 : 1;                         // dy rows per step
+    constexpr int NIN = 3 * S + K;                             // input columns feeding 4 output columns
+    __shared__ f32x4 red[256];
+    const int Q = C >> 2;
+    const int t = threadIdx.x;
+    const int cql = t % QT, kh = (t / QT) % K, pl = t / (QT * K);
+    const int cq = blockIdx.y * QT + cql;
+    const bool act = pl < P && cq < Q;
+    const int WB = (Wo + 3) >> 2, HB = (Ho + RB - 1) / RB;
+    const int npb = imgs * HB * WB, nblk = gridDim.x;
+    const int chunk = (npb + nblk - 1) / nblk;
+    const int pb = blockIdx.x * chunk, pe = min(npb, pb + chunk);
+    f32x4 acc[K];
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) acc[kw] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (act)
+        for (int p = pb + pl; p < pe; p += P) {
+            const int img = p / (HB * WB);
+            const int rem = p - img * HB * WB;
+            const int oh0 = (rem / WB) * RB, ow0 = (rem % WB) * 4;
+            const int iw0 = ow0 * S - PT;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int oh = oh0 + r;
+                const int ih = oh * S + kh - PT;
+                if (oh >= Ho || (unsigned)ih >= (unsigned)Hi) continue;
+                const T* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
+                const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+                f32x4 d[4], xin[NIN];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = ow0 + j < Wo ? ld4(dr + (size_t)(ow0 + j) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const int iw = iw0 + j;
+                    xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[kw] += d[j] * xin[j * S + kw];
+            }
+        }
+    // fold the P pixel lanes (fixed order) and store this thread's kernel row
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+        __syncthreads();
+        red[t] = acc[kw];
+        __syncthreads();
+        if (pl == 0 && t < QT * K && cq < Q) {
+            f32x4 v = red[t];
+            for (int k = 1; k < P; ++k) v += red[k * QT * K + t];
+            st4(part + ((size_t)blockIdx.x * K * K + kh * K + kw) * C + cq * 4, v);
+        }
+    }
+}
+
 // QT = channel quads per block (a divisor of Q, <= 256), P = pixel lanes
 static inline void dw_map(int C, int& QT, int& P, int& ytiles)
 {
@@ -997,6 +1063,21 @@ static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, i
     dw_map(C, QT, P, yt);
     const dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt), blk(QT * P);
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    static const int krows = getenv("FM_DW_WGRAD_ROWS") ? atoi(getenv("FM_DW_WGRAD_ROWS")) : 1;
+    // Measured per layer (bf16, 1024 images): the row-split kernel wins where a block can take >= 42 channel quads of one
+    // pixel (C = 672: 1.08 -> 0.89 ms, its stride-2 layer 0.69 -> 0.41; C = 1152: 0.52 -> 0.30) and loses on the narrower
+    // layers (C = 144 / 240: fewer contiguous bytes per pixel, or a third of the block idle), which keep the all-taps kernel.
+    if (krows && K == 5 && C >= 640 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        // threads = QTr quads x 5 kernel rows x Pr pixel lanes <= 256
+        const int Q = C / 4;
+        int QTr = std::min(Q, 51);
+        while (Q % QTr) --QTr;
+        const int Pr = std::max(1, 256 / (QTr * 5));
+        const dim3 g2(dw_wgrad_blocks(imgs * Ho * Wo), Q / QTr), b2(256);
+        if (stride == 1) hipLaunchKernelGGL((dw_wgrad_rows_kernel<5, 1, T>), g2, b2, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QTr, Pr);
+        else hipLaunchKernelGGL((dw_wgrad_rows_kernel<5, 2, T>), g2, b2, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QTr, Pr);
+        return;
+    }
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         if (K == 3) hipLaunchKernelGGL((dw_wgrad_blk2_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
         else hipLaunchKernelGGL((dw_wgrad_blk2_kernel<5, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
