@@ -47,7 +47,7 @@ def _grads_sd(e):
 GRAD_REPORT = {}
 
 
-def _cmp_grads(e, net, rtol=2e-4, what=""):
+def _cmp_grads(e, net, rtol=5e-5, what=""):
     """max |g_hip - g_oracle| / max |g_oracle| per parameter tensor (fp32 both sides)."""
     import json, os
     gsd = _grads_sd(e)
