@@ -20,6 +20,21 @@ __device__ __forceinline__ f32x4 ld4(const bf16* p)
 {
     return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
 }
+// Bounds-checked load WITHOUT a branch: the caller clamps the address (p is always readable) and passes the predicate;
+// the value is zeroed afterwards.  `cond ? ld4(p) : 0` compiles to a branch + s_waitcnt vmcnt(0) per element for bf16
+// (every load of a depthwise window serialised on the previous one's latency); this form keeps the loads in flight.
+__device__ __forceinline__ f32x4 ld4z(const float* p, bool ok)
+{
+    const f32x4 v = ld4(p);
+    return ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 ld4z(const bf16* p, bool ok)
+{
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    r.x = ok ? r.x : 0u;
+    r.y = ok ? r.y : 0u;
+    return __builtin_convertvector(__builtin_bit_cast(bf16x4, r), f32x4);
+}
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
 // NV consecutive channel quads per thread: one 16-B access per lane in either storage type

@@ -288,6 +288,28 @@ void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const floa
 }
 
 // ------------------------------------------------------------ depthwise conv ---
+// The register-blocked kernels below are straight-line code per thread (branch-free bounds handling, ld4z): without a
+// fence the scheduler hoists the whole (K+1) x (K+3) window of loads to the top and spills; ROW_FENCE keeps one input
+// row's loads + FMAs together (8-11 loads in flight per wave, 4 waves per SIMD).
+// FM_DW_BRANCHFREE 1: bounds handled by address clamp + select (ld4z), rows fenced; measured with the VGPR cap needed for
+// 4 waves per SIMD the 5x5 forms spill, so the shipped stride-2 kernels keep the predicated form (0) and the stride-1
+// layers run through dw_rowu_kernel below.
+#ifndef FM_DW_BRANCHFREE
+#define FM_DW_BRANCHFREE 0
+#endif
+#if FM_DW_BRANCHFREE
+#define LD4Z(row, idx, stride, ok) ld4z((row) + (size_t)((ok) ? (idx) : 0) * (stride), (ok))
+#define ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DW_LB(n) __launch_bounds__(256, n)
+#define ROW_SKIP(rv)
+#define ROW_OK(rv) true
+#else
+#define LD4Z(row, idx, stride, ok) ((ok) ? ld4((row) + (size_t)(idx) * (stride)) : f32x4{0.f, 0.f, 0.f, 0.f})
+#define ROW_FENCE()
+#define DW_LB(n) __launch_bounds__(256)
+#define ROW_SKIP(rv) if (!(rv)) continue
+#define ROW_OK(rv) (rv)
+#endif
 // x [imgs][Hi][Wi][C], w [K*K][C], y [imgs][Ho][Wo][C]; pad_t/pad_l = TF-same top/left padding.
 // Optional fused eval epilogue: y = act(y*scale+shift).
 template <int K, typename T>
@@ -328,7 +350,7 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 // instead of 4*K.  Compile-time TF-"same" padding of an even input: (K-1)/2 at stride 1,
 // (K-2)/2 at stride 2; other paddings take the generic kernels above.
 template <int K, int S, typename T>
-__global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ DW_LB(4) void dw_fwd_blk_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          T* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int imgs, int Hi, int Wi,
                                                          int Ho, int Wo, int C, int act)
@@ -351,14 +373,15 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const T* __restrict__ x
 #pragma unroll
     for (int kh = 0; kh < K; ++kh) {
         const int ih = oh * S + kh - PT;
-        if ((unsigned)ih >= (unsigned)Hi) continue;
-        const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+        const bool rv = (unsigned)ih < (unsigned)Hi;
+        ROW_SKIP(rv);
+        const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
         f32x4 xin[NIN], wr[K];
 #pragma unroll
         for (int j = 0; j < NIN; ++j) {
             const int iw = iw0 + j;
-            xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = rv && (unsigned)iw < (unsigned)Wi;
+            xin[j] = LD4Z(xr, iw, C, ok);
         }
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) wr[kw] = ld4(w + (kh * K + kw) * C + cq * 4);
@@ -366,6 +389,7 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const T* __restrict__ x
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) acc[j] += xin[j * S + kw] * wr[kw];
+        ROW_FENCE();
     }
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) {
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(256) void dw_fwd_blk_kernel(const T* __restrict__ x
 // 5x5 costs 6 loads per output instead of 10 and its weights are read once per 8 outputs -- the 5x5 layers are
 // bound by L1 bandwidth (16 float4 of L1 traffic per float4 of output in the one-row form).
 template <int K, typename T>
-__global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ DW_LB(4) void dw_fwd_blk2_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           T* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int imgs, int Hi, int Wi,
                                                           int Ho, int Wo, int C, int act, int flip)
@@ -439,18 +463,20 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ 
             }
         }
         const int ih = oh0 + ir - PT;
-        if ((unsigned)ih < (unsigned)Hi) {
+        if (ROW_OK((unsigned)ih < (unsigned)Hi)) {
             f32x4 xin[NIN];
             if constexpr (PRELOAD) {
 #pragma unroll
                 for (int j = 0; j < NIN; ++j)
                     xin[j] = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw[ir][j]), f32x4);
             } else {
-                const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+                const bool rv = (unsigned)ih < (unsigned)Hi;
+                const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
 #pragma unroll
                 for (int j = 0; j < NIN; ++j) {
                     const int iw = iw0 + j;
-                    xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool ok = rv && (unsigned)iw < (unsigned)Wi;
+                    xin[j] = LD4Z(xr, iw, C, ok);
                 }
             }
             if (ir < K) {
@@ -468,6 +494,7 @@ __global__ __launch_bounds__(256) void dw_fwd_blk2_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
+        ROW_FENCE();
     }
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) {
@@ -590,6 +617,7 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ x, c
         }
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
+        ROW_FENCE();
     }
     if (c >= C) return;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -640,12 +668,341 @@ static void dw_tile_t(const T* x, const float* w, T* y, const float* scale, cons
     else if (W >= 12) dw_tile_launch<K, 8, 16, 16, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
     else dw_tile_launch<K, 8, 8, 32, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
 }
+// ---- row-uniform stride-1 depthwise convolution -----------------------------------------------------------------------
+// The register-blocked kernels above spend ~5 VALU instructions per FMA on 64-bit addresses, bounds compares / selects
+// and (bf16) one branch + s_waitcnt vmcnt(0) PER LOAD.  Here the geometry is wave-uniform: a wave owns one (image, pair
+// of output rows) at a time and its lanes are (4-column block, channel quad) of that row pair, so
+//  * an input row is ONE buffer descriptor (base = the row, num_records = its bytes; 0 records for rows above / below the
+//    image): the hardware range check returns zeros for the left / right / top / bottom halo and drops the stores of
+//    partial blocks -- no compare, no select, no branch;
+//  * the per-lane byte offsets of the K+3 columns are computed once per kernel (32-bit), the row enters through SGPRs;
+//  * the lane's K*K weights sit in LDS ([tap][lane], staged once per block; the 4 waves of a block share the lane ->
+//    (column block, quad) map and take different row pairs), plus K rows of zeros that serve as "kernel row K";
+//  * rows are double-buffered in packed registers (row r+1 is in flight while row r is computed) and the row loop is a
+//    REAL loop, unrolled by two by hand so the two buffers and the two weight rows (the lower output row uses the
+//    previous input row's weights) alternate without moves.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct RawOf;
+template <> struct RawOf<float> { typedef u32x4 type; };
+template <> struct RawOf<bf16> { typedef u32x2 type; };
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void raw_load(rsrc_t r, int voff, u32x4& v) { v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
+__device__ __forceinline__ void raw_load(rsrc_t r, int voff, u32x2& v) { v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0); }
+__device__ __forceinline__ f32x4 raw_cvt(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+__device__ __forceinline__ f32x4 raw_cvt(u32x2 v)
+{
+    return f32x4{__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                 __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void raw_store(rsrc_t r, int voff, f32x4 v, float*)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void raw_store(rsrc_t r, int voff, f32x4 v, bf16*)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4)), r, voff, 0, 0);
+}
+// descriptor of image row `ih` of image `img` (wave-uniform arguments); rows outside the image get 0 records
+template <typename T>
+__device__ __forceinline__ rsrc_t row_rsrc(const T* x, int img, int ih, int H, int rowelems)
+{
+    const bool ok = (unsigned)ih < (unsigned)H;
+    const T* base = x + ((size_t)img * H + (ok ? ih : 0)) * rowelems;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, ok ? rowelems * (int)sizeof(T) : 0, 0x00020000);
+}
+template <int K, typename T>
+__global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      int nrp, int H, int W, int C, int act, int flip, int nchunk, int rpb)
+{
+    constexpr int PT = (K - 1) / 2, NIN = K + 3, ES = (int)sizeof(T);
+    constexpr bool FAST = VecOf<T>::NV == 2;
+    typedef typename RawOf<T>::type raw_t;
+    __shared__ f32x4 ws[(K * K + K) * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x % nchunk, rg = blockIdx.x / nchunk;
+    const int Q = C >> 2, WB = (W + 3) >> 2, HB = (H + 1) >> 1;
+    const int id = chunk * 64 + lane;
+    const bool lv = id < WB * Q;
+    const int owb = lv ? id / Q : 0, cq = lv ? id - owb * Q : 0;
+    for (int t = wave; t < K * K + K; t += 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < K * K) v = ld4(w + (flip ? K * K - 1 - t : t) * C + cq * 4);
+        ws[t * 64 + lane] = v;
+    }
+    int voff[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) voff[j] = lv ? ((owb * 4 - PT + j) * C + cq * 4) * ES : 0x7f000000;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) { sc = ld4(scale + cq * 4); sh = ld4(shift + cq * 4); }
+    __syncthreads();
+    const int rowelems = W * C;
+    const int rp1 = min(nrp, (rg + 1) * rpb);
+    const f32x4* wl = ws + lane;
+    for (int rp = rg * rpb + wave; rp < rp1; rp += 4) {
+        const int img = rp / HB, oh0 = (rp - img * HB) * 2;
+        f32x4 acc[2][4], wa[K], wb[K];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = acc[1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) wb[kw] = f32x4{0.f, 0.f, 0.f, 0.f};
+        raw_t ra[NIN], rb[NIN];
+        {
+            const rsrc_t r = row_rsrc(x, img, oh0 - PT, H, rowelems);
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) raw_load(r, voff[j], ra[j]);
+        }
+#pragma unroll 1
+        for (int ir = 0; ir <= K; ir += 2) {
+            {   // row ir+1 -> rb (always exists: K is odd)
+                const rsrc_t r = row_rsrc(x, img, oh0 - PT + ir + 1, H, rowelems);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) raw_load(r, voff[j], rb[j]);
+            }
+            {   // compute row ir: taps ir (upper output row, wa) and ir-1 (lower output row, wb)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) wa[kw] = wl[(ir * K + kw) * 64];
+                f32x4 xin[NIN];
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) xin[j] = raw_cvt(ra[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        acc[0][j] += xin[j + kw] * wa[kw];
+                        acc[1][j] += xin[j + kw] * wb[kw];
+                    }
+            }
+            if (ir + 2 <= K) {
+                const rsrc_t r = row_rsrc(x, img, oh0 - PT + ir + 2, H, rowelems);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) raw_load(r, voff[j], ra[j]);
+            }
+            {   // compute row ir+1: taps ir+1 (zeros when ir+1 == K) into wb, previous = wa
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) wb[kw] = wl[((ir + 1) * K + kw) * 64];
+                f32x4 xin[NIN];
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) xin[j] = raw_cvt(rb[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        acc[0][j] += xin[j + kw] * wb[kw];
+                        acc[1][j] += xin[j + kw] * wa[kw];
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const rsrc_t ro = row_rsrc(y, img, oh0 + r, H, rowelems);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[r][j];
+                if (scale) v = act_fwd<FAST>(v * sc + sh, act);
+                raw_store(ro, voff[j + PT], v, (T*)nullptr);
+            }
+        }
+    }
+}
+// stride-2 forward in the same row-uniform form: a wave step = one output row (img, oh), lanes = (4-column block of the
+// output row, channel quad); K input rows of 6 + K columns each, double-buffered (K is odd: the last row is peeled).
+template <int K, typename T, bool PF>
+__global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int nrows, int Hi, int Wi, int Ho, int Wo, int C, int act, int nchunk,
+                                                         int rpb)
+{
+    constexpr int PT = (K - 2) / 2, NIN = 6 + K, ES = (int)sizeof(T);
+    constexpr bool FAST = VecOf<T>::NV == 2;
+    typedef typename RawOf<T>::type raw_t;
+    __shared__ f32x4 ws[K * K * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x % nchunk, rg = blockIdx.x / nchunk;
+    const int Q = C >> 2, WB = (Wo + 3) >> 2;
+    const int id = chunk * 64 + lane;
+    const bool lv = id < WB * Q;
+    const int owb = lv ? id / Q : 0, cq = lv ? id - owb * Q : 0;
+    for (int t = wave; t < K * K; t += 4) ws[t * 64 + lane] = ld4(w + t * C + cq * 4);
+    int voff[NIN], vout[4];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) voff[j] = lv ? ((owb * 8 - PT + j) * C + cq * 4) * ES : 0x7f000000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vout[j] = lv ? ((owb * 4 + j) * C + cq * 4) * ES : 0x7f000000;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) { sc = ld4(scale + cq * 4); sh = ld4(shift + cq * 4); }
+    __syncthreads();
+    const int in_row = Wi * C, out_row = Wo * C;
+    const int r1 = min(nrows, (rg + 1) * rpb);
+    const f32x4* wl = ws + lane;
+    for (int row = rg * rpb + wave; row < r1; row += 4) {
+        const int img = row / Ho, oh = row - img * Ho;
+        const int ih0 = oh * 2 - PT;
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        raw_t ra[NIN], rb[PF ? NIN : 1];
+        auto load = [&](raw_t (&dst)[NIN], int kh) {
+            const rsrc_t r = row_rsrc(x, img, ih0 + kh, Hi, in_row);
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) raw_load(r, voff[j], dst[j]);
+        };
+        auto comp = [&](const raw_t (&src)[NIN], int kh) {
+            f32x4 wr[K], xin[NIN];
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) wr[kw] = wl[(kh * K + kw) * 64];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) xin[j] = raw_cvt(src[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) acc[j] += xin[2 * j + kw] * wr[kw];
+        };
+        if constexpr (PF) {
+            load(ra, 0);
+#pragma unroll 1
+            for (int kh = 0; kh < K - 1; kh += 2) {
+                load(rb, kh + 1);
+                comp(ra, kh);
+                load(ra, kh + 2);
+                comp(rb, kh + 1);
+            }
+            comp(ra, K - 1);
+        } else {
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                load(ra, kh);
+                comp(ra, kh);
+            }
+        }
+        const rsrc_t ro = row_rsrc(y, img, oh, Ho, out_row);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[j];
+            if (scale) v = act_fwd<FAST>(v * sc + sh, act);
+            raw_store(ro, vout[j], v, (T*)nullptr);
+        }
+    }
+}
+// stride-2 data gradient, row-uniform: a wave step = one INPUT row (img, ih), lanes = (4-column block of that row, channel
+// quad).  Only the kernel rows kh with (ih + PT - kh) even reach it -- a wave-uniform choice, (K+1)/2 candidate rows
+// (a candidate beyond the kernel reads a zero tap row and a 0-record descriptor); which (column, kw) pairs are exact
+// divisions is compile-time because the block starts at a multiple of 4.
+template <int K, typename T>
+__global__ __launch_bounds__(256) void dw_rowu_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                               T* __restrict__ dx, int nrows, int Hi, int Wi, int Ho, int Wo,
+                                                               int C, int nchunk, int rpb)
+{
+    constexpr int PT = (K - 2) / 2, ES = (int)sizeof(T);
+    constexpr int OMIN = -((K - PT) / 2), OMAX = (3 + PT) / 2, NC = OMAX - OMIN + 1, NR = (K + 1) / 2;
+    typedef typename RawOf<T>::type raw_t;
+    __shared__ f32x4 ws[(K * K + K) * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x % nchunk, rg = blockIdx.x / nchunk;
+    const int Q = C >> 2, WB = (Wi + 3) >> 2;
+    const int id = chunk * 64 + lane;
+    const bool lv = id < WB * Q;
+    const int iwb = lv ? id / Q : 0, cq = lv ? id - iwb * Q : 0;
+    for (int t = wave; t < K * K + K; t += 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < K * K) v = ld4(w + t * C + cq * 4);
+        ws[t * 64 + lane] = v;
+    }
+    int voff[NC], vout[4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) voff[c] = lv ? ((iwb * 2 + OMIN + c) * C + cq * 4) * ES : 0x7f000000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vout[j] = lv ? ((iwb * 4 + j) * C + cq * 4) * ES : 0x7f000000;
+    __syncthreads();
+    const int in_row = Wi * C, out_row = Wo * C;
+    const int r1 = min(nrows, (rg + 1) * rpb);
+    const f32x4* wl = ws + lane;
+    for (int row = rg * rpb + wave; row < r1; row += 4) {
+        const int img = row / Hi, ih = row - img * Hi;
+        const int kh0 = (ih + PT) & 1;
+        raw_t raw[NR][NC];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int kh = kh0 + 2 * r;
+            const int a = ih + PT - kh;                                   // even; may be negative or beyond the last row
+            const rsrc_t rs = row_rsrc(dy, img, kh < K ? a >> 1 : -1, Ho, out_row);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) raw_load(rs, voff[c], raw[r][c]);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int kh = min(kh0 + 2 * r, K);                           // K = the zero tap row
+            f32x4 wr[K], din[NC];
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) wr[kw] = wl[(kh * K + kw) * 64];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) din[c] = raw_cvt(raw[r][c]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const int d = j + PT - kw;
+                    if (d % 2 != 0) continue;
+                    acc[j] += din[d / 2 - OMIN] * wr[kw];
+                }
+        }
+        const rsrc_t ro = row_rsrc(dx, img, ih, Hi, in_row);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw_store(ro, vout[j], acc[j], (T*)nullptr);
+    }
+}
+static inline int dw_rowu_mode() { static const int v = getenv("FM_DW_ROWU") ? atoi(getenv("FM_DW_ROWU")) : 2; return v; }
+static inline int dw_tile_mode() { static const int v = getenv("FM_DW_TILE") ? atoi(getenv("FM_DW_TILE")) : 1; return v; }
+static inline bool dw_tile_on(int W) { return dw_tile_mode() == 2 || (dw_tile_mode() == 1 && W >= 100); }
+// FM_DW_ROWU: 0 off / 1 wherever the LDS-tiled kernel is not selected / 2 everywhere
+static inline bool dw_rowu_on(int W) { return dw_rowu_mode() == 2 || (dw_rowu_mode() == 1 && !dw_tile_on(W)); }
+template <int K, typename T>
+static void dw_rowu_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int H, int W,
+                           int C, int act, int flip, hipStream_t s)
+{
+    const int WB = (W + 3) / 4, HB = (H + 1) / 2, Q = C / 4;
+    const int nchunk = (WB * Q + 63) / 64, nrp = imgs * HB;
+    static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
+    const int rpb = std::max(4, rpb_env);
+    const dim3 grid(nchunk * ((nrp + rpb - 1) / rpb));
+    hipLaunchKernelGGL((dw_rowu_kernel<K, T>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act, flip, nchunk, rpb);
+}
 // Measured (bf16, 1024 images, FM_DW_TILE=2 forces the tiled kernel everywhere): it beats the register-blocked kernels
 // only where 16x16 tiles of 32 channels fit exactly -- block 0's 112x112x32: 0.61 -> 0.53 ms (3.1 TB/s) -- and loses
 // on every narrower layer (56x56x144: 0.77 -> 1.32 ms; 28x28x240: 0.59 -> 0.66 ms): two blocks per CU (57-76 KB of LDS)
 // with a barrier between staging and compute hide latency worse than 16 independent waves.  Default: tiled for W >= 100.
-static inline int dw_tile_mode() { static const int v = getenv("FM_DW_TILE") ? atoi(getenv("FM_DW_TILE")) : 1; return v; }
-static inline bool dw_tile_on(int W) { return dw_tile_mode() == 2 || (dw_tile_mode() == 1 && W >= 100); }
+
+template <int K, typename T>
+static void dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
+                              int Ho, int Wo, int C, int act, hipStream_t s)
+{
+    const int WB = (Wo + 3) / 4, Q = C / 4;
+    const int nchunk = (WB * Q + 63) / 64, nrows = imgs * Ho;
+    static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
+    static const int pf_env = getenv("FM_DW_PF") ? atoi(getenv("FM_DW_PF")) : -1;
+    const int rpb = std::max(4, rpb_env);
+    const bool pf = pf_env >= 0 ? pf_env != 0 : true;      // fp32 5x5 stride 2: 0.44 -> 0.32 ms with the second row buffer
+    const dim3 grid(nchunk * ((nrows + rpb - 1) / rpb));
+    if (pf) hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, true>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrows, Hi, Wi, Ho, Wo, C, act, nchunk, rpb);
+    else hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, false>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrows, Hi, Wi, Ho, Wo, C, act, nchunk, rpb);
+}
+template <int K, typename T>
+static void dw_rowu_dgrad_s2_launch(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s)
+{
+    const int WB = (Wi + 3) / 4, Q = C / 4;
+    const int nchunk = (WB * Q + 63) / 64, nrows = imgs * Hi;
+    static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
+    const int rpb = std::max(4, rpb_env);
+    const dim3 grid(nchunk * ((nrows + rpb - 1) / rpb));
+    hipLaunchKernelGGL((dw_rowu_dgrad_s2_kernel<K, T>), grid, dim3(256), 0, s, dy, w, dx, nrows, Hi, Wi, Ho, Wo, C, nchunk, rpb);
+}
 
 template <typename T>
 static void dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
@@ -654,6 +1011,16 @@ static void dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
     const dim3 blk(256);
+    if (dw_rowu_on(Wi) && !psc && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        if (K == 3) dw_rowu_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s);
+        else dw_rowu_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s);
+        return;
+    }
+    if (dw_rowu_mode() && !psc && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
+        if (K == 3) dw_rowu_s2_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s);
+        else dw_rowu_s2_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s);
+        return;
+    }
     if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         if (K == 3) dw_tile_t<3, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
         else dw_tile_t<5, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
@@ -721,7 +1088,7 @@ __global__ void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restric
 // kw the output column is (iw0 + j + PT - kw)/S when that is an exact division; iw0 is a multiple
 // of 4, so which (j, kw) pairs are exact and their column offsets are compile-time.
 template <int K, int S, typename T>
-__global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+__global__ DW_LB(4) void dw_dgrad_blk_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                            T* __restrict__ dx, int imgs, int Hi, int Wi, int Ho,
                                                            int Wo, int C)
 {
@@ -753,8 +1120,8 @@ __global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const T* __restrict__
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int ow = cbase + c;
-            din[c] = (unsigned)ow < (unsigned)Wo ? ld4(dr + (size_t)ow * C)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = (unsigned)ow < (unsigned)Wo;
+            din[c] = LD4Z(dr, ow, C, ok);
         }
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) wr[kw] = ld4(w + (kh * K + kw) * C + cq * 4);
@@ -766,6 +1133,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_blk_kernel(const T* __restrict__
                 if (d % S != 0) continue;
                 acc[j] += din[d / S - OMIN] * wr[kw];
             }
+        ROW_FENCE();
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -779,6 +1147,17 @@ static void dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
     const dim3 blk(256);
+    if (dw_rowu_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        const float* nul = nullptr;
+        if (K == 3) dw_rowu_launch<3, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s);
+        else dw_rowu_launch<5, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s);
+        return;
+    }
+    if (dw_rowu_mode() && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
+        if (K == 3) dw_rowu_dgrad_s2_launch<3, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s);
+        else dw_rowu_dgrad_s2_launch<5, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s);
+        return;
+    }
     if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const float* nul = nullptr;
         if (K == 3) dw_tile_t<3, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
@@ -861,7 +1240,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ dy,
 }
 // wgrad, register-blocked: the pixel loop walks blocks of 4 consecutive output columns
 template <int K, int S, typename T>
-__global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ DW_LB(2) void dw_wgrad_blk_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            float* __restrict__ part, int imgs, int Hi, int Wi,
                                                            int Ho, int Wo, int C, int QT, int P)
 {
@@ -883,25 +1262,29 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const T* __restrict__
         const T* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
         f32x4 d[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            d[j] = ow0 + j < Wo ? ld4(dr + (size_t)(ow0 + j) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = ow0 + j < Wo;
+            d[j] = LD4Z(dr, ow0 + j, C, ok);
+        }
         const int iw0 = ow0 * S - PT;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
             const int ih = oh * S + kh - PT;
-            if ((unsigned)ih >= (unsigned)Hi) continue;
-            const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            const bool rv = (unsigned)ih < (unsigned)Hi;
+            ROW_SKIP(rv);
+            const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
             f32x4 xin[NIN];
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int iw = iw0 + j;
-                xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool ok = rv && (unsigned)iw < (unsigned)Wi;
+                xin[j] = LD4Z(xr, iw, C, ok);
             }
 #pragma unroll
             for (int kw = 0; kw < K; ++kw)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[kh * K + kw] += d[j] * xin[j * S + kw];
+            ROW_FENCE();
         }
     }
 #pragma unroll
@@ -918,7 +1301,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk_kernel(const T* __restrict__
 }
 // stride-1 wgrad, pixel blocks of 2 output rows x 4 columns: K+1 input rows serve both rows of dy
 template <int K, typename T>
-__global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ DW_LB(2) void dw_wgrad_blk2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             float* __restrict__ part, int imgs, int Hi, int Wi,
                                                             int Ho, int Wo, int C, int QT, int P)
 {
@@ -942,22 +1325,24 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const T* __restrict_
         for (int r = 0; r < 2; ++r) {
             const T* dr = dy + ((size_t)(img * Ho + min(oh0 + r, Ho - 1)) * Wo) * C + cq * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                d[r][j] = (oh0 + r < Ho && ow0 + j < Wo) ? ld4(dr + (size_t)(ow0 + j) * C)
-                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = oh0 + r < Ho && ow0 + j < Wo;
+                d[r][j] = LD4Z(dr, ow0 + j, C, ok);
+            }
         }
         const int iw0 = ow0 - PT;
 #pragma unroll
         for (int ir = 0; ir <= K; ++ir) {
             const int ih = oh0 + ir - PT;
-            if ((unsigned)ih >= (unsigned)Hi) continue;
-            const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+            const bool rv = (unsigned)ih < (unsigned)Hi;
+            ROW_SKIP(rv);
+            const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
             f32x4 xin[NIN];
 #pragma unroll
             for (int j = 0; j < NIN; ++j) {
                 const int iw = iw0 + j;
-                xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C)
-                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool ok = rv && (unsigned)iw < (unsigned)Wi;
+                xin[j] = LD4Z(xr, iw, C, ok);
             }
             if (ir < K) {                     // kernel row ir against the upper dy row
 #pragma unroll
@@ -971,6 +1356,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const T* __restrict_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[(ir - 1) * K + kw] += d[1][j] * xin[j + kw];
             }
+            ROW_FENCE();
         }
     }
 #pragma unroll
@@ -990,7 +1376,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_blk2_kernel(const T* __restrict_
 // 0.45-0.8 TB/s of their tensors' bytes: latency-bound).  It re-reads dy once per kernel row (L1 hits) in exchange for
 // ~70 VGPRs.  S = 1: 2 rows x 4 columns of dy per step (2 input rows serve them); S = 2: 1 row x 4 columns.
 template <int K, int S, typename T>
-__global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ DW_LB(4) void dw_wgrad_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             float* __restrict__ part, int imgs, int Hi, int Wi, int Ho,
                                                             int Wo, int C, int QT, int P)
 {
@@ -1020,16 +1406,21 @@ __global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const T* __restrict_
             for (int r = 0; r < RB; ++r) {
                 const int oh = oh0 + r;
                 const int ih = oh * S + kh - PT;
-                if (oh >= Ho || (unsigned)ih >= (unsigned)Hi) continue;
-                const T* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
-                const T* xr = x + ((size_t)(img * Hi + ih) * Wi) * C + cq * 4;
+                const bool rv = oh < Ho && (unsigned)ih < (unsigned)Hi;
+                ROW_SKIP(rv);
+                const T* dr = dy + ((size_t)(img * Ho + (rv ? oh : 0)) * Wo) * C + cq * 4;
+                const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
                 f32x4 d[4], xin[NIN];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = ow0 + j < Wo ? ld4(dr + (size_t)(ow0 + j) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rv && ow0 + j < Wo;
+                    d[j] = LD4Z(dr, ow0 + j, C, ok);
+                }
 #pragma unroll
                 for (int j = 0; j < NIN; ++j) {
                     const int iw = iw0 + j;
-                    xin[j] = (unsigned)iw < (unsigned)Wi ? ld4(xr + (size_t)iw * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool ok = rv && (unsigned)iw < (unsigned)Wi;
+                    xin[j] = LD4Z(xr, iw, C, ok);
                 }
 #pragma unroll
                 for (int kw = 0; kw < K; ++kw)
@@ -1051,6 +1442,145 @@ __global__ __launch_bounds__(256) void dw_wgrad_rows_kernel(const T* __restrict_
     }
 }
 
+// ---- row-uniform weight gradient ---------------------------------------------------------------------------------------
+// Same wave geometry as dw_rowu_kernel: a wave step = one (image, RB rows of dy) (RB = 2 at stride 1, 1 at stride 2),
+// lanes = (4-column block of dy, channel quad); every lane keeps ALL K*K tap accumulators of its quad and walks the
+// (RB-1)*S + K input rows of the step (row r+1 in flight while row r is multiplied; rows fenced so the scheduler cannot
+// hoist the whole window).  A block's 4 waves take different steps of the same lanes; they are folded through LDS in a
+// fixed order and written as ONE [K*K][64] record per block; dw_rowu_wgrad_reduce sums the records of a quad (all row
+// groups x all column blocks) in a fixed order -> run-to-run deterministic, no atomics.
+template <int K, int S, typename T>
+__global__ __launch_bounds__(256) void dw_rowu_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            f32x4* __restrict__ part, int nsteps, int Hi, int Wi, int Ho, int Wo,
+                                                            int C, int nchunk, int spb)
+{
+    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
+    constexpr int RB = S == 1 ? 2 : 1;
+    constexpr int NIN = 3 * S + K, NROW = (RB - 1) * S + K, ES = (int)sizeof(T);
+    typedef typename RawOf<T>::type raw_t;
+    __shared__ f32x4 red[3][K][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x % nchunk, rg = blockIdx.x / nchunk;
+    const int Q = C >> 2, WB = (Wo + 3) >> 2, HB = (Ho + RB - 1) / RB;
+    const int id = chunk * 64 + lane;
+    const bool lv = id < WB * Q;
+    const int owb = lv ? id / Q : 0, cq = lv ? id - owb * Q : 0;
+    int voff[NIN], vd[4];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) voff[j] = lv ? ((owb * 4 * S - PT + j) * C + cq * 4) * ES : 0x7f000000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vd[j] = lv ? ((owb * 4 + j) * C + cq * 4) * ES : 0x7f000000;
+    const int in_row = Wi * C, out_row = Wo * C;
+    const int s1 = min(nsteps, (rg + 1) * spb);
+    f32x4 acc[K][K];
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) acc[kh][kw] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int st = rg * spb + wave; st < s1; st += 4) {
+        const int img = st / HB, oh0 = (st - img * HB) * RB;
+        const int ih0 = oh0 * S - PT;
+        raw_t rd[RB][4], ra[NIN], rb[NIN];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const rsrc_t rs = row_rsrc(dy, img, oh0 + r, Ho, out_row);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw_load(rs, vd[j], rd[r][j]);
+        }
+        {
+            const rsrc_t rs = row_rsrc(x, img, ih0, Hi, in_row);
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) raw_load(rs, voff[j], ra[j]);
+        }
+        f32x4 d[RB][4];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[r][j] = raw_cvt(rd[r][j]);
+#pragma unroll
+        for (int ir = 0; ir < NROW; ++ir) {
+            raw_t (&cur)[NIN] = (ir & 1) ? rb : ra;
+            raw_t (&nxt)[NIN] = (ir & 1) ? ra : rb;
+            if (ir + 1 < NROW) {
+                const rsrc_t rs = row_rsrc(x, img, ih0 + ir + 1, Hi, in_row);
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) raw_load(rs, voff[j], nxt[j]);
+            }
+            f32x4 xin[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; ++j) xin[j] = raw_cvt(cur[j]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int kh = ir - r * S;                    // compile-time after unrolling
+                if (kh < 0 || kh >= K) continue;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[kh][kw] += d[r][j] * xin[j * S + kw];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // fold the 4 waves (fixed order) one kernel row at a time and store the block's record
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) red[wave - 1][kw][lane] = acc[kh][kw];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const f32x4 v = ((acc[kh][kw] + red[0][kw][lane]) + red[1][kw][lane]) + red[2][kw][lane];
+                part[((size_t)blockIdx.x * K * K + kh * K + kw) * 64 + lane] = v;
+            }
+        }
+    }
+}
+// out[t][cq] = sum over row groups and column blocks of the block records above.  Block = 16 quads x 16 split lanes.
+__global__ __launch_bounds__(256) void dw_rowu_wgrad_reduce(const f32x4* __restrict__ part, float* __restrict__ out, int KK, int Q,
+                                                            int WB, int nchunk, int nrg)
+{
+    __shared__ f32x4 red[16][16];
+    const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int t = blockIdx.y, cq = blockIdx.x * 16 + ql;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (cq < Q) {
+        const int n = nrg * WB;
+        for (int i = sl; i < n; i += 16) {
+            const int rg = i / WB, m = i - rg * WB;
+            const int id = cq + m * Q;
+            a += part[((size_t)(rg * nchunk + (id >> 6)) * KK + t) * 64 + (id & 63)];
+        }
+    }
+    red[sl][ql] = a;
+    __syncthreads();
+    if (sl == 0 && cq < Q) {
+        f32x4 r = red[0][ql];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) r += red[k][ql];
+        st4(out + ((size_t)t * Q + cq) * 4, r);
+    }
+}
+template <int K, int S, typename T>
+static void dw_rowu_wgrad_launch(const T* dy, const T* x, float* part, float* out, int imgs, int Hi, int Wi, int Ho, int Wo, int C,
+                                 hipStream_t s)
+{
+    constexpr int RB = S == 1 ? 2 : 1;
+    const int WB = (Wo + 3) / 4, HB = (Ho + RB - 1) / RB, Q = C / 4;
+    const int nchunk = (WB * Q + 63) / 64, nsteps = imgs * HB;
+    static const int tgt = getenv("FM_DW_WG_BLOCKS") ? atoi(getenv("FM_DW_WG_BLOCKS")) : 1536;
+    int spb = std::max(8, (int)(((int64_t)nsteps * nchunk + tgt - 1) / tgt));
+    spb = (spb + 3) / 4 * 4;
+    const int nrg = (nsteps + spb - 1) / spb;
+    hipLaunchKernelGGL((dw_rowu_wgrad_kernel<K, S, T>), dim3(nchunk * nrg), dim3(256), 0, s, dy, x, reinterpret_cast<f32x4*>(part),
+                       nsteps, Hi, Wi, Ho, Wo, C, nchunk, spb);
+    hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16, K * K), dim3(256), 0, s, reinterpret_cast<const f32x4*>(part), out,
+                       K * K, Q, WB, nchunk, nrg);
+}
 // QT = channel quads per block (a divisor of Q, <= 256), P = pixel lanes
 static inline void dw_map(int C, int& QT, int& P, int& ytiles)
 {
@@ -1061,6 +1591,29 @@ static inline void dw_map(int C, int& QT, int& P, int& ytiles)
     P = std::max(1, 256 / QT);
 }
 int dw_wgrad_blocks(int npix) { return std::max(1, std::min(2048, npix / 128)); }
+template <typename T>
+static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                       int stride, int pad_t, int pad_l, hipStream_t s);
+template <typename T>
+static void dw_wgrad_full(const T* dy, const T* x, float* part, float* out, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                          int stride, int pad_t, int pad_l, hipStream_t s)
+{
+    // Measured per layer (ms, 1024 bf16 / 512 fp32 images): bf16 every layer 1.9-4x faster than the lane = (pixel lane,
+    // quad) kernels below (block 3: 1.41 -> 0.41, block 9: 0.89 -> 0.22; sum 10.5 -> 4.1); fp32 gains on the 5x5 layers
+    // (0.33 -> 0.17) and loses on the wide 3x3 ones (112x112x32: 0.35 -> 0.63, one row of lookahead is too little in
+    // flight for 16-B loads), so fp32 3x3 keeps the older kernels.  FM_DW_WG_ROWU: 0 never / 1 this rule / 2 always.
+    static const int mode = getenv("FM_DW_WG_ROWU") ? atoi(getenv("FM_DW_WG_ROWU")) : 1;
+    const bool pick = mode == 2 || (mode == 1 && (sizeof(T) == 2 || K == 5));
+    if (pick && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == stride * Wo && Hi == stride * Ho) {
+        if (K == 3 && stride == 1) dw_rowu_wgrad_launch<3, 1, T>(dy, x, part, out, imgs, Hi, Wi, Ho, Wo, C, s);
+        else if (K == 3) dw_rowu_wgrad_launch<3, 2, T>(dy, x, part, out, imgs, Hi, Wi, Ho, Wo, C, s);
+        else if (stride == 1) dw_rowu_wgrad_launch<5, 1, T>(dy, x, part, out, imgs, Hi, Wi, Ho, Wo, C, s);
+        else dw_rowu_wgrad_launch<5, 2, T>(dy, x, part, out, imgs, Hi, Wi, Ho, Wo, C, s);
+        return;
+    }
+    dw_wgrad_t(dy, x, part, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
+    k_reduce_slabs(part, out, dw_wgrad_blocks(imgs * Ho * Wo), (int64_t)K * K * C, s);
+}
 template <typename T>
 static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                        int stride, int pad_t, int pad_l, hipStream_t s)
@@ -1099,11 +1652,11 @@ static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, i
     if (K == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, QT, P);
     else hipLaunchKernelGGL((dw_wgrad_kernel<5, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, QT, P);
 }
-void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
-                int stride, int pad_t, int pad_l, hipStream_t s)
+void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, float* out, int imgs, int Hi, int Wi, int Ho, int Wo, int C,
+                int K, int stride, int pad_t, int pad_l, hipStream_t s)
 {
-    if (dt == DT_F32) dw_wgrad_t(cp<float>(dy), cp<float>(x), part, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
-    else dw_wgrad_t(cp<bf16>(dy), cp<bf16>(x), part, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
+    if (dt == DT_F32) dw_wgrad_full(cp<float>(dy), cp<float>(x), part, out, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
+    else dw_wgrad_full(cp<bf16>(dy), cp<bf16>(x), part, out, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
 }
 
 // per-image channel sums over a chunk of pixels: part[img][chunk][C] = sum_p a[p][c] (* b[p][c]).

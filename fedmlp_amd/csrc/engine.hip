@@ -1133,10 +1133,8 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         { OP("bnact_bwd"); bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
                                      true); }   // d y_d
         const float* a_e = m.c_exp >= 0 ? m.a_e : in;
-        const int nb = dw_wgrad_blocks(imgs * HWo);
-        { OP("k_dw_wgrad"); k_dw_wgrad(e->T_mid, a_e, e->dt, e->ws_slab, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t, m.pad_l,
-                   e->st); }
-        { OP("k_reduce_slabs"); k_reduce_slabs(e->ws_slab, G + m.dw_off, nb, (int64_t)m.k * m.k * m.ce_p, e->st); }
+        { OP("k_dw_wgrad"); k_dw_wgrad(e->T_mid, a_e, e->dt, e->ws_slab, G + m.dw_off, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                   m.pad_t, m.pad_l, e->st); }
         if (m.c_exp >= 0) {
             Conv& ce = e->convs[m.c_exp];
             { OP("k_dw_dgrad"); k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,

@@ -85,8 +85,8 @@ void k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale
 void k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
 int dw_wgrad_blocks(int npix);
-// part [dw_wgrad_blocks][K*K][C]; sum with k_reduce_slabs
-void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+// out [K*K][C] = the weight gradient; part = workspace for the per-block partial sums (reduced inside, fixed order)
+void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, float* out, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
 // squeeze-excite: W1 [Cs][C], W2 [C][Cs]
 // pool_ws: [imgs][16][C] scratch for the per-image channel sums

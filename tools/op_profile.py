@@ -43,7 +43,7 @@ print(f"total timed ops: {tot:.2f} ms/step")
 for k, v in sorted(by_op.items(), key=lambda kv: -kv[1]):
     print(f"{k:28s} {v:8.3f} ms")
 print("--- per op and block (ms/step) ---")
-for lab, n, ms in sorted(rows, key=lambda r: -r[2])[:60]:
+for lab, n, ms in sorted(rows, key=lambda r: -r[2]):
     print(f"{lab:28s} calls {n // a.steps:3d}  {ms / a.steps:8.3f}")
 
 # ---- achieved bandwidth of the big ops (algorithmic bytes of the op's tensors / time) -------------
