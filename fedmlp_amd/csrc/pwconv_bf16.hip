@@ -74,10 +74,14 @@ __device__ __forceinline__ int tile_row_to_channel(int r, int i, int npairs)
 }
 
 // =====================================================================================================
-template <int RT, bool PRO>
+// P = 16-pixel groups per wave iteration, KB = 32-k chunks requested together.  A wave's loads in flight are
+// P x 16 pixels x min(K, 32 KB) x 2 B: with P = 2 a K = 16 layer has ONE KB per wave in flight and the whole kernel
+// crawls along its read latency (block 1's expand conv: 2.7 TB/s of a write-dominated 2.9 GB), so small K takes more
+// pixels per iteration (accumulators are AGPRs) instead of more k-chunks.
+template <int RT, bool PRO, int P = 2, int KB = 4>
 __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
 {
-    constexpr int MT = 16 * RT, P = 2, PPI = 16 * P, KB = 4;
+    constexpr int MT = 16 * RT, PPI = 16 * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -459,6 +463,18 @@ int pw_blocks(int npix_per_group, int groups, int M, int K)
     return (npix_per_group + ppb - 1) / ppb;
 }
 
+template <int RT, int P, int KB>
+static void pw_launch_t(const PwParams& p, bool pro, dim3 grid, size_t lds, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, false, P, KB>), 96 * 1024, "pw_conv_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, true, P, KB>), 96 * 1024, "pw_conv_bf16_kernel");
+        attr_done = true;
+    }
+    if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, true, P, KB>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, false, P, KB>), grid, dim3(256), lds, s, p);
+}
 void launch_pw_conv(PwParams p, hipStream_t s)
 {
     const int RT = pw_rt(p.K);
@@ -468,22 +484,16 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     const bool pro = p.gate != nullptr;
     size_t lds = (size_t)(p.K >> 5) * RT * 1024 + (size_t)RT * 512 + (pro ? (size_t)2 * p.K * 4 : 0);
     lds = std::max<size_t>(lds, (size_t)4 * MT * 2 * 4);
-    static bool attr_done = false;
-    if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<4, false>), 96 * 1024, "pw_conv_bf16_kernel<4,false>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<2, false>), 96 * 1024, "pw_conv_bf16_kernel<2,false>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<4, true>), 96 * 1024, "pw_conv_bf16_kernel<4,true>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<2, true>), 96 * 1024, "pw_conv_bf16_kernel<2,true>");
-        attr_done = true;
-    }
     const dim3 grid((p.M + MT - 1) / MT, p.nblk * p.groups);
-    if (RT == 4) {
-        if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<4, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((pw_conv_bf16_kernel<4, false>), grid, dim3(256), lds, s, p);
-    } else {
-        if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<2, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((pw_conv_bf16_kernel<2, false>), grid, dim3(256), lds, s, p);
-    }
+    // FM_PW_SMALLK: 0 = P 2 everywhere; 2 (default) = 4 pixel groups x 2 k-chunks for K <= 64 (2 waves per SIMD kept:
+    // block 1's expand conv 1.07 -> 0.90 ms, the K <= 64 layers together -1.0 ms per step); 1 = 8 groups for K <= 32
+    // (372 registers = 1 wave per SIMD: slower than 2).  Outputs are bit-identical across the settings; the BN partial
+    // sums are taken in a different (still fixed) order.
+    static const int smallk = getenv("FM_PW_SMALLK") ? atoi(getenv("FM_PW_SMALLK")) : 2;
+    if (RT == 4 && smallk == 1 && p.K <= 32) pw_launch_t<4, 8, 1>(p, pro, grid, lds, s);
+    else if (RT == 4 && smallk && p.K <= 64) pw_launch_t<4, 4, 2>(p, pro, grid, lds, s);
+    else if (RT == 4) pw_launch_t<4, 2, 4>(p, pro, grid, lds, s);
+    else pw_launch_t<2, 2, 4>(p, pro, grid, lds, s);
 }
 
 template <int CC>
