@@ -1941,17 +1941,23 @@ __global__ __launch_bounds__(256) void chan_pool5_kernel(const T* __restrict__ d
         }
     }
 }
-// BN1-backward sums from the per-image partials: part_out[g][0][2][C]; block = (64 channels, group), 4 image lanes
+// BN1-backward sums from the per-image partials: part_out[g][split][2][C]; block = (64 channels, group, split of the
+// group's images), 4 image lanes.  (One block per (64 channels, group) -- 2 to 36 blocks on 256 CUs -- took 2.8 ms per
+// step over the 16 blocks; the splits are folded by the BN-backward finalize like any other per-block partials.)
+int se_bwd_bn1_splits(int ipg) { return std::max(1, std::min(32, ipg / 16)); }
 __global__ void bn1_sums_kernel(const float* __restrict__ pool5, int nch, const float* __restrict__ gate,
                                 const float* __restrict__ ds, float* __restrict__ out, int HW, int C, int ipg)
 {
     __shared__ float red[2][4][64];
     const int g = blockIdx.y, cl = threadIdx.x & 63, il = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    const int nsplit = gridDim.z, sp = blockIdx.z;
+    const int ips = (ipg + nsplit - 1) / nsplit;
+    const int i0 = sp * ips, i1 = min(ipg, i0 + ips);
     const float inv = 1.f / (float)HW;
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
-        for (int i = il; i < ipg; i += 4) {
+        for (int i = i0 + il; i < i1; i += 4) {
             const size_t img = (size_t)g * ipg + i;
             float p1 = 0.f, p2 = 0.f, q1 = 0.f, q2 = 0.f;
             for (int k = 0; k < nch; ++k) {
@@ -1965,11 +1971,13 @@ __global__ void bn1_sums_kernel(const float* __restrict__ pool5, int nch, const 
     red[0][il][cl] = s1; red[1][il][cl] = s2;
     __syncthreads();
     if (il == 0 && c < C) {
-        out[(size_t)g * 2 * C + c] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
-        out[(size_t)g * 2 * C + C + c] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
+        float* o = out + ((size_t)g * nsplit + sp) * 2 * C;
+        o[c] = ((red[0][0][cl] + red[0][1][cl]) + red[0][2][cl]) + red[0][3][cl];
+        o[C + c] = ((red[1][0][cl] + red[1][1][cl]) + red[1][2][cl]) + red[1][3][cl];
     }
 }
-// pool_ws: [imgs][chunks][5][C]; writes dgp/drp/ds like k_se_bwd and the BN1-backward sums to bn_part [groups][1][2][C]
+// pool_ws: [imgs][chunks][5][C]; writes dgp/drp/ds like k_se_bwd and the BN1-backward sums to
+// bn_part [groups][se_bwd_bn1_splits(ipg)][2][C]
 void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, const float* shift, const float* mean,
                   const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
                   const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
@@ -1989,8 +1997,8 @@ void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, c
                            shift, mean, istd, ipg);
     hipLaunchKernelGGL(se_bwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, nch, 5 * C, gate, rpre, W1,
                        W2, dgp, drp, ds, HW, C, Cs);
-    hipLaunchKernelGGL(bn1_sums_kernel, dim3(cdiv(C, 64), imgs / ipg), dim3(256), 0, s, pool_ws, nch, gate, ds, bn_part, HW, C,
-                       ipg);
+    hipLaunchKernelGGL(bn1_sums_kernel, dim3(cdiv(C, 64), imgs / ipg, se_bwd_bn1_splits(ipg)), dim3(256), 0, s, pool_ws, nch, gate,
+                       ds, bn_part, HW, C, ipg);
 }
 
 // dW2[c][j] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]

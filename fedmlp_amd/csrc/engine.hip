@@ -958,15 +958,15 @@ void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per
 // backward through act(bn(y))*rowscale: dz -> dy (may alias dz); writes dgamma/dbeta
 void bnact_bwd(fm_engine* e, int bi, const float* dz, const float* y, float* dy, const float* rowscale, int groups,
                int pix_per_group, int HW, int act, const float* gate = nullptr, const float* dsv = nullptr,
-               int ty = -1, bool sums_ready = false)
+               int ty = -1, int sums_ready = 0)
 {
     Bn& b = e->bns[bi];
     if (ty < 0) ty = e->dt;                  // storage type of y / dy (the stem's are fp32 in every mode)
-    // sums_ready: ws_part already holds the two backward sums as ONE partial per group (k_se_bwd_bn1)
+    // sums_ready > 0: ws_part already holds the two backward sums as that many partials per group (k_se_bwd_bn1)
     if (!sums_ready)
         k_chan_reduce(dz, e->dt, y, ty, b.mean, b.istd, b.scale, b.shift, rowscale, e->ws_part, groups, pix_per_group, HW, b.C,
                       1, act, gate, dsv, e->st);
-    k_bn_bwd_finalize(e->ws_part, groups, sums_ready ? 1 : bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
+    k_bn_bwd_finalize(e->ws_part, groups, sums_ready ? sums_ready : bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
                       e->state + e->off_gamma + b.ch_off, b.mean, b.istd, e->ca, e->cb, e->cc,
                       e->grad + e->off_gamma + b.ch_off, e->grad + e->off_beta + b.ch_off, e->st);
     k_bnact_bwd_apply(dz, e->dt, y, ty, e->ca, e->cb, e->cc, b.scale, b.shift, rowscale, dy, groups, pix_per_group, HW,
@@ -1131,7 +1131,7 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
                    m.ce_p, m.cs, e->st); }
         // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
         { OP("bnact_bwd"); bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
-                                     true); }   // d y_d
+                                     se_bwd_bn1_splits(B)); }   // d y_d
         const float* a_e = m.c_exp >= 0 ? m.a_e : in;
         { OP("k_dw_wgrad"); k_dw_wgrad(e->T_mid, a_e, e->dt, e->ws_slab, G + m.dw_off, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
                    m.pad_t, m.pad_l, e->st); }

@@ -102,6 +102,7 @@ void k_se_bwd(const void* dout, const void* a, int dt, const float* scale, const
               int imgs, int HW, int C, int Cs, hipStream_t s);
 // squeeze-excite backward AND the BN1-backward sums from one pass over (dout = d a_s, y = raw depthwise output);
 // pool_ws [imgs][16][5][C]; bn_part [groups][1][2][C] is what k_bn_bwd_finalize consumes with nblk = 1
+int se_bwd_bn1_splits(int ipg);       // per-group partials k_se_bwd_bn1 leaves in bn_part
 void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, const float* shift, const float* mean,
                   const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
                   const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
