@@ -1127,8 +1127,7 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         // ONE pass over (d a_s, y_d) yields the squeeze-excite backward's pooled sums and the BN1-backward sums
         { OP("k_se_bwd"); k_se_bwd_bn1(e->T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
                      S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
-        { OP("k_se_wgrad"); k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, G + m.w1_off, G + m.b1_off, G + m.w2_off, G + m.b2_off, imgs,
-                   m.ce_p, m.cs, e->st); }
+        { OP("k_se_wgrad"); k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
         // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
         { OP("bnact_bwd"); bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
                                      se_bwd_bn1_splits(B)); }   // d y_d

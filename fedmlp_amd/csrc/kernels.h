@@ -107,8 +107,9 @@ void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, c
                   const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
                   const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
                   hipStream_t s);
-void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* dW1, float* db1,
-                float* dW2, float* db2, int imgs, int C, int Cs, hipStream_t s);
+// dW1 = start of the contiguous [dW1 | db1 (padded to 4) | dW2 | db2] gradient range; part = workspace (16 slabs of it)
+void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* part, float* dW1, int imgs, int C,
+                int Cs, hipStream_t s);
 void k_mul(const float* a, const float* b, float* y, int64_t n, hipStream_t s);
 void k_add_inplace(void* y, const void* a, int dt, int64_t n, hipStream_t s);
 
