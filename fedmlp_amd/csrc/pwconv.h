@@ -23,6 +23,7 @@ struct PwParams {
     const float* psh;
     const float* gate;    // prologue: [imgs][K] or null (no prologue at all)
     int HW;               // pixels per image (gate row = global pixel / HW)
+    int tiles_m, xcd;     // set by the launcher: M-tiles of the launch; 1 = XCD-aware block order
 };
 int pw_blocks(int npix_per_group, int groups, int M, int K);   // nblk the launcher will use (statistics layout)
 int pw_tiles_m(int M, int K);       // M-tiles of the launch: the pixel operand (and its prologue) is read once per M-tile

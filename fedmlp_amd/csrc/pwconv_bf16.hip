@@ -90,8 +90,25 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
     uint4* As = reinterpret_cast<uint4*>(smem);                                       // [nfull][RT][64 lanes] x 16 B
     uint2* At = reinterpret_cast<uint2*>(smem + (size_t)nfull * RT * 1024);           // [RT][64 lanes] x 8 B
     float* psc_l = reinterpret_cast<float*>(smem + (size_t)nfull * RT * 1024 + (size_t)RT * 512);   // [K] x 2 (PRO)
-    const int m0 = blockIdx.x * MT;
-    const int grp = blockIdx.y / p.nblk, blk = blockIdx.y - grp * p.nblk;
+    // 1-D grid -> (M-tile bx, pixel range by).  The M-tiles of one pixel range re-read the same pixels: with consecutive
+    // block ids dealt round-robin to the 8 XCDs they would land on different L2s, so ids are arranged such that the tiles
+    // of a range are congruent mod 8 (same XCD) and close in launch order.
+    int bx, by;
+    {
+        const int id = blockIdx.x, nby = p.nblk * p.groups, tm = p.tiles_m;
+        const int full = p.xcd ? (nby >> 3) << 3 : 0;
+        if (id < full * tm) {
+            const int q = id / (8 * tm), r = id - q * 8 * tm;
+            bx = r >> 3;
+            by = q * 8 + (r & 7);
+        } else {
+            const int r = id - full * tm;
+            by = full + r / tm;
+            bx = r - (r / tm) * tm;
+        }
+    }
+    const int m0 = bx * MT;
+    const int grp = by / p.nblk, blk = by - grp * p.nblk;
     const int pb = blk * p.ppb, pe = min(p.npix, pb + p.ppb);
     const size_t gbase = (size_t)grp * p.npix;
     const int nrt = min(RT, (p.M - m0) >> 4);
@@ -484,7 +501,10 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     const bool pro = p.gate != nullptr;
     size_t lds = (size_t)(p.K >> 5) * RT * 1024 + (size_t)RT * 512 + (pro ? (size_t)2 * p.K * 4 : 0);
     lds = std::max<size_t>(lds, (size_t)4 * MT * 2 * 4);
-    const dim3 grid((p.M + MT - 1) / MT, p.nblk * p.groups);
+    static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
+    p.tiles_m = (p.M + MT - 1) / MT;
+    p.xcd = xcd;
+    const dim3 grid(p.tiles_m * p.nblk * p.groups);
     // FM_PW_SMALLK: 0 = P 2 everywhere; 2 (default) = 4 pixel groups x 2 k-chunks for K <= 64 (2 waves per SIMD kept:
     // block 1's expand conv 1.07 -> 0.90 ms, the K <= 64 layers together -1.0 ms per step); 1 = 8 groups for K <= 32
     // (372 registers = 1 wave per SIMD: slower than 2).  Outputs are bit-identical across the settings; the BN partial
