@@ -711,10 +711,19 @@ __device__ __forceinline__ rsrc_t row_rsrc(const T* x, int img, int ih, int H, i
     const T* base = x + ((size_t)img * H + (ok ? ih : 0)) * rowelems;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, ok ? rowelems * (int)sizeof(T) : 0, 0x00020000);
 }
-template <int K, typename T>
+// ST: train-mode forward -- the per-channel sum and sum of squares of the STORED outputs (BN1's batch statistics) are
+// taken here from the registers instead of by a separate pass over y: every block leaves one [2][64-lane] record
+// (4 waves folded in a fixed order), dw_rowu_wgrad_reduce sums the records of a channel quad per statistics group.
+template <typename T> __device__ __forceinline__ f32x4 stored_value(f32x4 v)
+{
+    if constexpr (sizeof(T) == 2) return __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
+    else return v;
+}
+template <int K, typename T, bool ST = false>
 __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      int nrp, int H, int W, int C, int act, int flip, int nchunk, int rpb)
+                                                      int nrp, int H, int W, int C, int act, int flip, int nchunk, int rpb,
+                                                      f32x4* __restrict__ rec = nullptr)
 {
     constexpr int PT = (K - 1) / 2, NIN = K + 3, ES = (int)sizeof(T);
     constexpr bool FAST = VecOf<T>::NV == 2;
@@ -737,6 +746,10 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
     for (int j = 0; j < NIN; ++j) voff[j] = lv ? ((owb * 4 - PT + j) * C + cq * 4) * ES : 0x7f000000;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) { sc = ld4(scale + cq * 4); sh = ld4(shift + cq * 4); }
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    float cmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cmask[j] = (lv && owb * 4 + j < W) ? 1.f : 0.f;
     __syncthreads();
     const int rowelems = W * C;
     const int rp1 = min(nrp, (rg + 1) * rpb);
@@ -798,22 +811,37 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const rsrc_t ro = row_rsrc(y, img, oh0 + r, H, rowelems);
+            const float rm = oh0 + r < H ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[r][j];
                 if (scale) v = act_fwd<FAST>(v * sc + sh, act);
                 raw_store(ro, voff[j + PT], v, (T*)nullptr);
+                if constexpr (ST) {
+                    const f32x4 q = stored_value<T>(v) * (rm * cmask[j]);
+                    st1 += q;
+                    st2 += q * q;
+                }
             }
+        }
+    }
+    if constexpr (ST) {
+        __shared__ f32x4 red[3][2][64];
+        if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
+        __syncthreads();
+        if (wave == 0) {
+            rec[((size_t)blockIdx.x * 2 + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
         }
     }
 }
 // stride-2 forward in the same row-uniform form: a wave step = one output row (img, oh), lanes = (4-column block of the
 // output row, channel quad); K input rows of 6 + K columns each, double-buffered (K is odd: the last row is peeled).
-template <int K, typename T, bool PF>
+template <int K, typename T, bool PF, bool ST = false>
 __global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int nrows, int Hi, int Wi, int Ho, int Wo, int C, int act, int nchunk,
-                                                         int rpb)
+                                                         int rpb, f32x4* __restrict__ rec = nullptr)
 {
     constexpr int PT = (K - 2) / 2, NIN = 6 + K, ES = (int)sizeof(T);
     constexpr bool FAST = VecOf<T>::NV == 2;
@@ -834,6 +862,10 @@ __global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x
     for (int j = 0; j < 4; ++j) vout[j] = lv ? ((owb * 4 + j) * C + cq * 4) * ES : 0x7f000000;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) { sc = ld4(scale + cq * 4); sh = ld4(shift + cq * 4); }
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    float cmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cmask[j] = (lv && owb * 4 + j < Wo) ? 1.f : 0.f;
     __syncthreads();
     const int in_row = Wi * C, out_row = Wo * C;
     const int r1 = min(nrows, (rg + 1) * rpb);
@@ -884,6 +916,20 @@ __global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x
             f32x4 v = acc[j];
             if (scale) v = act_fwd<FAST>(v * sc + sh, act);
             raw_store(ro, vout[j], v, (T*)nullptr);
+            if constexpr (ST) {
+                const f32x4 q = stored_value<T>(v) * cmask[j];
+                st1 += q;
+                st2 += q * q;
+            }
+        }
+    }
+    if constexpr (ST) {
+        __shared__ f32x4 red[3][2][64];
+        if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
+        __syncthreads();
+        if (wave == 0) {
+            rec[((size_t)blockIdx.x * 2 + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
         }
     }
 }
@@ -963,16 +1009,43 @@ static inline int dw_tile_mode() { static const int v = getenv("FM_DW_TILE") ? a
 static inline bool dw_tile_on(int W) { return dw_tile_mode() == 2 || (dw_tile_mode() == 1 && W >= 100); }
 // FM_DW_ROWU: 0 off / 1 wherever the LDS-tiled kernel is not selected / 2 everywhere
 static inline bool dw_rowu_on(int W) { return dw_rowu_mode() == 2 || (dw_rowu_mode() == 1 && !dw_tile_on(W)); }
+__global__ void dw_rowu_wgrad_reduce(const f32x4* __restrict__ part, float* __restrict__ out, int KK, int Q, int WB, int nchunk,
+                                     int nrg, int nsplit);
+// Train-mode statistics request of a depthwise forward: rec = record workspace, out = [groups][1][2][C] partials for
+// k_bn_finalize (tiles = 1).  Honoured when the row steps of one statistics group fill whole blocks.
+struct DwStats { float* rec; float* out; int groups; };
+constexpr int DW_ST_SPLITS = 8;              // partials per group the statistics reducer leaves (k_bn_finalize tiles)
+// row groups per statistics group: the largest divisor of the group's steps that keeps the launch near 3072 blocks
+// (every block leaves a record: with the forward's 16-step blocks the 112x112 layer would leave 14 336 of them)
+static inline int dw_stats_rowgroups(int steps_per_group, int nchunk, int groups)
+{
+    const int target = std::max(1, 3072 / (nchunk * groups));
+    for (int d = std::min(target, steps_per_group); d >= 1; --d)
+        if (steps_per_group % d == 0) return 4 * d >= target || d == steps_per_group ? d : 0;
+    return 0;
+}
 template <int K, typename T>
-static void dw_rowu_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int H, int W,
-                           int C, int act, int flip, hipStream_t s)
+static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int H, int W,
+                           int C, int act, int flip, hipStream_t s, const DwStats* st = nullptr)
 {
     const int WB = (W + 3) / 4, HB = (H + 1) / 2, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nrp = imgs * HB;
     static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
-    const int rpb = std::max(4, rpb_env);
+    int rpb = std::max(4, rpb_env);
+    if (st && nrp % st->groups == 0) {
+        const int nrg_g = dw_stats_rowgroups(nrp / st->groups, nchunk, st->groups);
+        if (nrg_g) {
+            rpb = nrp / st->groups / nrg_g;
+            hipLaunchKernelGGL((dw_rowu_kernel<K, T, true>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale, shift,
+                               nrp, H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+            hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16 * DW_ST_SPLITS, 2, st->groups), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(st->rec), st->out, 2, Q, WB, nchunk, nrg_g, DW_ST_SPLITS);
+            return true;
+        }
+    }
     const dim3 grid(nchunk * ((nrp + rpb - 1) / rpb));
     hipLaunchKernelGGL((dw_rowu_kernel<K, T>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act, flip, nchunk, rpb);
+    return false;
 }
 // Measured (bf16, 1024 images, FM_DW_TILE=2 forces the tiled kernel everywhere): it beats the register-blocked kernels
 // only where 16x16 tiles of 32 channels fit exactly -- block 0's 112x112x32: 0.61 -> 0.53 ms (3.1 TB/s) -- and loses
@@ -980,18 +1053,30 @@ static void dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
 // with a barrier between staging and compute hide latency worse than 16 independent waves.  Default: tiled for W >= 100.
 
 template <int K, typename T>
-static void dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
-                              int Ho, int Wo, int C, int act, hipStream_t s)
+static bool dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
+                              int Ho, int Wo, int C, int act, hipStream_t s, const DwStats* st = nullptr)
 {
     const int WB = (Wo + 3) / 4, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nrows = imgs * Ho;
     static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
     static const int pf_env = getenv("FM_DW_PF") ? atoi(getenv("FM_DW_PF")) : -1;
-    const int rpb = std::max(4, rpb_env);
+    int rpb = std::max(4, rpb_env);
     const bool pf = pf_env >= 0 ? pf_env != 0 : true;      // fp32 5x5 stride 2: 0.44 -> 0.32 ms with the second row buffer
+    if (st && nrows % st->groups == 0) {
+        const int nrg_g = dw_stats_rowgroups(nrows / st->groups, nchunk, st->groups);
+        if (nrg_g) {
+            rpb = nrows / st->groups / nrg_g;
+            hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, true, true>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale,
+                               shift, nrows, Hi, Wi, Ho, Wo, C, act, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+            hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16 * DW_ST_SPLITS, 2, st->groups), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(st->rec), st->out, 2, Q, WB, nchunk, nrg_g, DW_ST_SPLITS);
+            return true;
+        }
+    }
     const dim3 grid(nchunk * ((nrows + rpb - 1) / rpb));
     if (pf) hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, true>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrows, Hi, Wi, Ho, Wo, C, act, nchunk, rpb);
     else hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, false>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrows, Hi, Wi, Ho, Wo, C, act, nchunk, rpb);
+    return false;
 }
 template <int K, typename T>
 static void dw_rowu_dgrad_s2_launch(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s)
@@ -1004,33 +1089,34 @@ static void dw_rowu_dgrad_s2_launch(const T* dy, const float* w, T* dx, int imgs
     hipLaunchKernelGGL((dw_rowu_dgrad_s2_kernel<K, T>), grid, dim3(256), 0, s, dy, w, dx, nrows, Hi, Wi, Ho, Wo, C, nchunk, rpb);
 }
 
+// returns true when the statistics request `st` was served (st->out then holds one partial per group)
 template <typename T>
-static void dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
+static bool dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
                      int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s,
-                     const float* psc = nullptr, const float* psh = nullptr, int ipg = 1)
+                     const float* psc = nullptr, const float* psh = nullptr, int ipg = 1, const DwStats* st = nullptr)
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    static const int fuse_st = getenv("FM_DW_STATS") ? atoi(getenv("FM_DW_STATS")) : 1;
+    if (!fuse_st) st = nullptr;
     const dim3 blk(256);
     if (dw_rowu_on(Wi) && !psc && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        if (K == 3) dw_rowu_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s);
-        else dw_rowu_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s);
-        return;
+        if (K == 3) return dw_rowu_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s, st);
+        return dw_rowu_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s, st);
     }
     if (dw_rowu_mode() && !psc && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
-        if (K == 3) dw_rowu_s2_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s);
-        else dw_rowu_s2_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s);
-        return;
+        if (K == 3) return dw_rowu_s2_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s, st);
+        return dw_rowu_s2_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s, st);
     }
     if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         if (K == 3) dw_tile_t<3, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
         else dw_tile_t<5, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
-        return;
+        return false;
     }
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const dim3 grid(cdiv((int64_t)imgs * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 4), 256));
         if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
         else hipLaunchKernelGGL((dw_fwd_blk2_kernel<5, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
-        return;
+        return false;
     }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const dim3 grid(cdiv((int64_t)imgs * Ho * ((Wo + 3) / 4) * (C / 4), 256));
@@ -1038,18 +1124,27 @@ static void dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const
         else if (K == 3) hipLaunchKernelGGL((dw_fwd_blk_kernel<3, 2, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
         else if (stride == 1) hipLaunchKernelGGL((dw_fwd_blk_kernel<5, 1, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
         else hipLaunchKernelGGL((dw_fwd_blk_kernel<5, 2, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
-        return;
+        return false;
     }
     const dim3 grid(cdiv((int64_t)imgs * Ho * Wo * (C / 4), 256));
     if (K == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, act);
     else hipLaunchKernelGGL((dw_fwd_kernel<5, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, act);
+    return false;
 }
 // dt: storage type of x and y (DT_F32 / DT_BF16); weights and the BN affine are fp32
-void k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
-              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s)
+// stats_rec != null (train mode): also leave the per-channel sum / sum of squares of y as ONE partial per group in
+// stats_out [groups][dw_stats_tiles()][2][C]; returns false when the launch shape could not do it (the caller then reduces y itself)
+bool k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
+              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s, float* stats_rec,
+              float* stats_out, int groups)
 {
-    if (dt == DT_F32) dw_fwd_t(cp<float>(x), w, mp<float>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s);
-    else dw_fwd_t(cp<bf16>(x), w, mp<bf16>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s);
+    const DwStats st{stats_rec, stats_out, groups};
+    const DwStats* sp = stats_rec ? &st : nullptr;
+    if (dt == DT_F32)
+        return dw_fwd_t(cp<float>(x), w, mp<float>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s, nullptr,
+                        nullptr, 1, sp);
+    return dw_fwd_t(cp<bf16>(x), w, mp<bf16>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s, nullptr,
+                    nullptr, 1, sp);
 }
 
 template <int K, typename T>
@@ -1542,16 +1637,22 @@ __global__ __launch_bounds__(256) void dw_rowu_wgrad_kernel(const T* __restrict_
 }
 // out[t][cq] = sum over row groups and column blocks of the block records above.  Block = 16 quads x 16 split lanes.
 __global__ __launch_bounds__(256) void dw_rowu_wgrad_reduce(const f32x4* __restrict__ part, float* __restrict__ out, int KK, int Q,
-                                                            int WB, int nchunk, int nrg)
+                                                            int WB, int nchunk, int nrg, int nsplit)
 {
+    // blockIdx.x = (16-quad block, split of the row groups), .y = record slot t, .z = statistics group;
+    // out [z][split][KK][Q*4] (the weight gradient uses one group, one split)
     __shared__ f32x4 red[16][16];
     const int ql = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int t = blockIdx.y, cq = blockIdx.x * 16 + ql;
+    const int qb = blockIdx.x / nsplit, sp = blockIdx.x - qb * nsplit;
+    const int t = blockIdx.y, cq = qb * 16 + ql;
+    part += (size_t)blockIdx.z * nrg * nchunk * KK * 64;
+    out += ((size_t)blockIdx.z * nsplit + sp) * KK * Q * 4;
+    const int rg0 = (int)((int64_t)nrg * sp / nsplit), rg1 = (int)((int64_t)nrg * (sp + 1) / nsplit);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (cq < Q) {
-        const int n = nrg * WB;
+        const int n = (rg1 - rg0) * WB;
         for (int i = sl; i < n; i += 16) {
-            const int rg = i / WB, m = i - rg * WB;
+            const int rg = rg0 + i / WB, m = i % WB;
             const int id = cq + m * Q;
             a += part[((size_t)(rg * nchunk + (id >> 6)) * KK + t) * 64 + (id & 63)];
         }
@@ -1579,7 +1680,7 @@ static void dw_rowu_wgrad_launch(const T* dy, const T* x, float* part, float* ou
     hipLaunchKernelGGL((dw_rowu_wgrad_kernel<K, S, T>), dim3(nchunk * nrg), dim3(256), 0, s, dy, x, reinterpret_cast<f32x4*>(part),
                        nsteps, Hi, Wi, Ho, Wo, C, nchunk, spb);
     hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16, K * K), dim3(256), 0, s, reinterpret_cast<const f32x4*>(part), out,
-                       K * K, Q, WB, nchunk, nrg);
+                       K * K, Q, WB, nchunk, nrg, 1);
 }
 // QT = channel quads per block (a divisor of Q, <= 256), P = pixel lanes
 static inline void dw_map(int C, int& QT, int& P, int& ytiles)
@@ -1590,6 +1691,7 @@ static inline void dw_map(int C, int& QT, int& P, int& ytiles)
     QT = Q / ytiles;
     P = std::max(1, 256 / QT);
 }
+int dw_stats_tiles() { return DW_ST_SPLITS; }
 int dw_wgrad_blocks(int npix) { return std::max(1, std::min(2048, npix / 128)); }
 template <typename T>
 static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,

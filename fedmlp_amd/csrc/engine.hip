@@ -943,12 +943,14 @@ void backward_and_step(fm_engine* e, int groups, int B)
 bool fuse_for(fm_engine* e, const MBConv& m) { return e->fuse_gate && pw_tiles_m(m.cout_p, m.ce_p) <= 2; }
 
 // BN over an arbitrary NHWC tensor (depthwise output): statistics by chan_reduce, then the same finalize
-void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per_group, int HW)
+// sums_ready: ws_part already holds dw_stats_tiles() partials per group (left by the depthwise forward)
+void bn_fwd_tensor(fm_engine* e, int bi, const float* y, int groups, int pix_per_group, int HW, bool sums_ready = false)
 {
     Bn& b = e->bns[bi];
-    k_chan_reduce(nullptr, e->dt, y, e->dt, nullptr, nullptr, nullptr, nullptr, nullptr, e->ws_part, groups, pix_per_group,
-                  HW, b.C, 0, 0, nullptr, nullptr, e->st);
-    k_bn_finalize(e->ws_part, groups, bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
+    if (!sums_ready)
+        k_chan_reduce(nullptr, e->dt, y, e->dt, nullptr, nullptr, nullptr, nullptr, nullptr, e->ws_part, groups, pix_per_group,
+                      HW, b.C, 0, 0, nullptr, nullptr, e->st);
+    k_bn_finalize(e->ws_part, groups, sums_ready ? dw_stats_tiles() : bn_bwd_blocks(pix_per_group), b.C, pix_per_group,
                   e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
                   e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale, b.shift,
                   e->bn_eps, e->bn_mom, e->st);
@@ -1000,9 +1002,10 @@ void eff_forward_train(fm_engine* e, int groups, int B)
             { OP("k_bnact_apply"); k_bnact_apply(ce.y, e->dt, b.scale, b.shift, nullptr, nullptr, m.a_e, e->dt, groups, B * HWi, HWi, b.C, 2, e->st); }
             a_e = m.a_e;
         }
-        { OP("k_dw_fwd"); k_dw_fwd(a_e, S + m.dw_off, m.y_d, e->dt, nullptr, nullptr, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
-                 m.pad_t, m.pad_l, 0, e->st); }
-        { OP("bn_fwd_tensor"); bn_fwd_tensor(e, m.bn1, m.y_d, groups, B * HWo, HWo); }
+        bool st_done;
+        { OP("k_dw_fwd"); st_done = k_dw_fwd(a_e, S + m.dw_off, m.y_d, e->dt, nullptr, nullptr, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p,
+                 m.k, m.s, m.pad_t, m.pad_l, 0, e->st, e->ws_slab, e->ws_part, groups); }   // + BN1 batch statistics
+        { OP("bn_fwd_tensor"); bn_fwd_tensor(e, m.bn1, m.y_d, groups, B * HWo, HWo, st_done); }
         {
             // a_d = swish(bn1(y_d)) is never written: the pooling and the gating pass form it on load
             Bn& b = e->bns[m.bn1];

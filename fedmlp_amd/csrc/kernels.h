@@ -80,8 +80,10 @@ void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const floa
                        int pix_per_group, int HW, int C, int act, const float* gate, const float* dsv, hipStream_t s);
 // gate/dsv (optional, [imgs][C]): the incoming gradient is d(a_s); d(a_d) = d(a_s)*gate + dsv/HW is formed on load
 // depthwise KxK (K 3 or 5): x [imgs][Hi][Wi][C], w [K*K][C]; optional fused y = act(y*scale+shift)
-void k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
-              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s);
+int dw_stats_tiles();                 // per-group partials k_dw_fwd leaves in stats_out when it serves the request
+bool k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
+              int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s,
+              float* stats_rec = nullptr, float* stats_out = nullptr, int groups = 1);
 void k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
 int dw_wgrad_blocks(int npix);

@@ -184,14 +184,16 @@ def _grad_report(e, net, what, C=C_):
     """Per-tensor agreement of the bf16 engine's gradients with the fp32 oracle's: largest deviation relative to
     the tensor's max, and the cosine between the two gradient vectors.  Tensors whose gradient is analytically
     zero (`_bn2.bias` without drop-connect: a per-channel constant added in front of a conv + BatchNorm) hold
-    rounding noise on both sides and are skipped when both are below 1e-3 of the typical gradient size."""
+    rounding noise on both sides: the oracle's is < 1e-3 of the typical gradient size, the engine's is the sum of
+    bf16-rounded gradients over all pixels (measured up to 5e-2 of the typical size at 3 x 112 x 112 pixels; bounded
+    here at 0.15) -- they are checked against that bound instead of compared."""
     gsd = spec.flat_to_state_dict("Efficient_b0", C, e.debug_get_grads(), np.zeros(e.ni, np.int64))
     typ = float(np.median([p.grad.abs().max().item() for _, p in net.named_parameters()]))
     errs, cos = {}, {}
     for k, p in net.named_parameters():
         want, got = p.grad.numpy().ravel(), gsd[k].ravel()
-        if np.abs(want).max() < 1e-3 * typ and np.abs(got).max() < 5e-2 * typ:
-            continue                 # analytically zero: fp32 holds ~1e-9 of noise there, bf16 storage ~1e-5
+        if np.abs(want).max() < 1e-3 * typ and np.abs(got).max() < 0.15 * typ:
+            continue                 # analytically zero: fp32 holds ~1e-9 of noise there, bf16 storage ~1e-5 .. 1e-4
         errs[k] = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
         den = np.linalg.norm(got) * np.linalg.norm(want)
         cos[k] = float(np.dot(got, want) / den) if den > 0 else 1.0
