@@ -719,11 +719,16 @@ template <typename T> __device__ __forceinline__ f32x4 stored_value(f32x4 v)
     if constexpr (sizeof(T) == 2) return __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
     else return v;
 }
-template <int K, typename T, bool ST = false>
+// ST = 2 (data gradient of a block with an expand conv): the BN0-backward sums  S1 = sum dz*swish'(v),  S2 = sum dz*swish'(v)*xhat
+// (dz = the gradient this kernel stores, v = y_e*scale+shift, xhat = (y_e-mean)*istd) are taken here as well: y_e is read
+// at the output positions, the separate reduction pass over (dz, y_e) is gone.  bnq = {mean, istd, scale, shift} [groups][C].
+struct BnQuad { const float *mean, *istd, *scale, *shift; };
+template <int K, typename T, int ST = 0>
 __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       int nrp, int H, int W, int C, int act, int flip, int nchunk, int rpb,
-                                                      f32x4* __restrict__ rec = nullptr)
+                                                      f32x4* __restrict__ rec = nullptr, const T* __restrict__ ye = nullptr,
+                                                      BnQuad bnq = BnQuad{nullptr, nullptr, nullptr, nullptr}, int rp_per_group = 1)
 {
     constexpr int PT = (K - 1) / 2, NIN = K + 3, ES = (int)sizeof(T);
     constexpr bool FAST = VecOf<T>::NV == 2;
@@ -808,6 +813,19 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
                     }
             }
         }
+        raw_t rye[ST == 2 ? 2 : 1][4];
+        f32x4 bmu, bis, bsc, bsh;
+        if constexpr (ST == 2) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const rsrc_t ry = row_rsrc(ye, img, oh0 + r, H, rowelems);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw_load(ry, voff[j + PT], rye[r][j]);
+            }
+            const int g = rp / rp_per_group;
+            bmu = ld4(bnq.mean + g * C + cq * 4); bis = ld4(bnq.istd + g * C + cq * 4);
+            bsc = ld4(bnq.scale + g * C + cq * 4); bsh = ld4(bnq.shift + g * C + cq * 4);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const rsrc_t ro = row_rsrc(y, img, oh0 + r, H, rowelems);
@@ -817,15 +835,24 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
                 f32x4 v = acc[r][j];
                 if (scale) v = act_fwd<FAST>(v * sc + sh, act);
                 raw_store(ro, voff[j + PT], v, (T*)nullptr);
-                if constexpr (ST) {
+                if constexpr (ST == 1) {
                     const f32x4 q = stored_value<T>(v) * (rm * cmask[j]);
                     st1 += q;
                     st2 += q * q;
                 }
+                if constexpr (ST == 2) {
+                    const f32x4 yy = raw_cvt(rye[r][j]);
+                    const f32x4 u = yy * bsc + bsh;
+                    f32x4 d = stored_value<T>(v) * (rm * cmask[j]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] *= swish_grad<FAST>(u[k]);
+                    st1 += d;
+                    st2 += d * ((yy - bmu) * bis);
+                }
             }
         }
     }
-    if constexpr (ST) {
+    if constexpr (ST != 0) {
         __shared__ f32x4 red[3][2][64];
         if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
         __syncthreads();
@@ -937,10 +964,13 @@ __global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x
 // quad).  Only the kernel rows kh with (ih + PT - kh) even reach it -- a wave-uniform choice, (K+1)/2 candidate rows
 // (a candidate beyond the kernel reads a zero tap row and a 0-record descriptor); which (column, kw) pairs are exact
 // divisions is compile-time because the block starts at a multiple of 4.
-template <int K, typename T>
+template <int K, typename T, int ST = 0>
 __global__ __launch_bounds__(256) void dw_rowu_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                                T* __restrict__ dx, int nrows, int Hi, int Wi, int Ho, int Wo,
-                                                               int C, int nchunk, int rpb)
+                                                               int C, int nchunk, int rpb, f32x4* __restrict__ rec = nullptr,
+                                                               const T* __restrict__ ye = nullptr,
+                                                               BnQuad bnq = BnQuad{nullptr, nullptr, nullptr, nullptr},
+                                                               int rows_per_group = 1)
 {
     constexpr int PT = (K - 2) / 2, ES = (int)sizeof(T);
     constexpr int OMIN = -((K - PT) / 2), OMAX = (3 + PT) / 2, NC = OMAX - OMIN + 1, NR = (K + 1) / 2;
@@ -963,6 +993,10 @@ __global__ __launch_bounds__(256) void dw_rowu_dgrad_s2_kernel(const T* __restri
     for (int c = 0; c < NC; ++c) voff[c] = lv ? ((iwb * 2 + OMIN + c) * C + cq * 4) * ES : 0x7f000000;
 #pragma unroll
     for (int j = 0; j < 4; ++j) vout[j] = lv ? ((iwb * 4 + j) * C + cq * 4) * ES : 0x7f000000;
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    float cmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cmask[j] = (lv && iwb * 4 + j < Wi) ? 1.f : 0.f;
     __syncthreads();
     const int in_row = Wi * C, out_row = Wo * C;
     const int r1 = min(nrows, (rg + 1) * rpb);
@@ -1002,6 +1036,34 @@ __global__ __launch_bounds__(256) void dw_rowu_dgrad_s2_kernel(const T* __restri
         const rsrc_t ro = row_rsrc(dx, img, ih, Hi, in_row);
 #pragma unroll
         for (int j = 0; j < 4; ++j) raw_store(ro, vout[j], acc[j], (T*)nullptr);
+        if constexpr (ST == 2) {
+            raw_t rye[4];
+            const rsrc_t ry = row_rsrc(ye, img, ih, Hi, in_row);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw_load(ry, vout[j], rye[j]);
+            const int g = row / rows_per_group;
+            const f32x4 bmu = ld4(bnq.mean + g * C + cq * 4), bis = ld4(bnq.istd + g * C + cq * 4);
+            const f32x4 bsc = ld4(bnq.scale + g * C + cq * 4), bsh = ld4(bnq.shift + g * C + cq * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 yy = raw_cvt(rye[j]);
+                const f32x4 u = yy * bsc + bsh;
+                f32x4 d = stored_value<T>(acc[j]) * cmask[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] *= swish_grad<sizeof(T) == 2>(u[k]);
+                st1 += d;
+                st2 += d * ((yy - bmu) * bis);
+            }
+        }
+    }
+    if constexpr (ST != 0) {
+        __shared__ f32x4 red[3][2][64];
+        if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
+        __syncthreads();
+        if (wave == 0) {
+            rec[((size_t)blockIdx.x * 2 + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
+        }
     }
 }
 static inline int dw_rowu_mode() { static const int v = getenv("FM_DW_ROWU") ? atoi(getenv("FM_DW_ROWU")) : 2; return v; }
@@ -1013,7 +1075,7 @@ __global__ void dw_rowu_wgrad_reduce(const f32x4* __restrict__ part, float* __re
                                      int nrg, int nsplit);
 // Train-mode statistics request of a depthwise forward: rec = record workspace, out = [groups][1][2][C] partials for
 // k_bn_finalize (tiles = 1).  Honoured when the row steps of one statistics group fill whole blocks.
-struct DwStats { float* rec; float* out; int groups; };
+struct DwStats { float* rec; float* out; int groups; const void* ye; BnQuad bnq; };   // ye != null: the BN0-backward sums
 constexpr int DW_ST_SPLITS = 8;              // partials per group the statistics reducer leaves (k_bn_finalize tiles)
 // row groups per statistics group: the largest divisor of the group's steps that keeps the launch near 3072 blocks
 // (every block leaves a record: with the forward's 16-step blocks the 112x112 layer would leave 14 336 of them)
@@ -1036,8 +1098,13 @@ static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
         const int nrg_g = dw_stats_rowgroups(nrp / st->groups, nchunk, st->groups);
         if (nrg_g) {
             rpb = nrp / st->groups / nrg_g;
-            hipLaunchKernelGGL((dw_rowu_kernel<K, T, true>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale, shift,
-                               nrp, H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+            if (st->ye)
+                hipLaunchKernelGGL((dw_rowu_kernel<K, T, 2>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale, shift,
+                                   nrp, H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec),
+                                   reinterpret_cast<const T*>(st->ye), st->bnq, nrp / st->groups);
+            else
+                hipLaunchKernelGGL((dw_rowu_kernel<K, T, 1>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale, shift,
+                                   nrp, H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
             hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16 * DW_ST_SPLITS, 2, st->groups), dim3(256), 0, s,
                                reinterpret_cast<const f32x4*>(st->rec), st->out, 2, Q, WB, nchunk, nrg_g, DW_ST_SPLITS);
             return true;
@@ -1079,14 +1146,28 @@ static bool dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* sca
     return false;
 }
 template <int K, typename T>
-static void dw_rowu_dgrad_s2_launch(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s)
+static bool dw_rowu_dgrad_s2_launch(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t s,
+                                    const DwStats* st = nullptr)
 {
     const int WB = (Wi + 3) / 4, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nrows = imgs * Hi;
     static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
-    const int rpb = std::max(4, rpb_env);
+    int rpb = std::max(4, rpb_env);
+    if (st && st->ye && nrows % st->groups == 0) {
+        const int nrg_g = dw_stats_rowgroups(nrows / st->groups, nchunk, st->groups);
+        if (nrg_g) {
+            rpb = nrows / st->groups / nrg_g;
+            hipLaunchKernelGGL((dw_rowu_dgrad_s2_kernel<K, T, 2>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, dy, w, dx, nrows, Hi,
+                               Wi, Ho, Wo, C, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec), reinterpret_cast<const T*>(st->ye), st->bnq,
+                               nrows / st->groups);
+            hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16 * DW_ST_SPLITS, 2, st->groups), dim3(256), 0, s,
+                               reinterpret_cast<const f32x4*>(st->rec), st->out, 2, Q, WB, nchunk, nrg_g, DW_ST_SPLITS);
+            return true;
+        }
+    }
     const dim3 grid(nchunk * ((nrows + rpb - 1) / rpb));
     hipLaunchKernelGGL((dw_rowu_dgrad_s2_kernel<K, T>), grid, dim3(256), 0, s, dy, w, dx, nrows, Hi, Wi, Ho, Wo, C, nchunk, rpb);
+    return false;
 }
 
 // returns true when the statistics request `st` was served (st->out then holds one partial per group)
@@ -1138,7 +1219,7 @@ bool k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s, float* stats_rec,
               float* stats_out, int groups)
 {
-    const DwStats st{stats_rec, stats_out, groups};
+    const DwStats st{stats_rec, stats_out, groups, nullptr, BnQuad{nullptr, nullptr, nullptr, nullptr}};
     const DwStats* sp = stats_rec ? &st : nullptr;
     if (dt == DT_F32)
         return dw_fwd_t(cp<float>(x), w, mp<float>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s, nullptr,
@@ -1237,27 +1318,27 @@ __global__ DW_LB(4) void dw_dgrad_blk_kernel(const T* __restrict__ dy, const flo
 }
 
 template <typename T>
-static void dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
-                       int stride, int pad_t, int pad_l, hipStream_t s)
+static bool dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                       int stride, int pad_t, int pad_l, hipStream_t s, const DwStats* st = nullptr)
 {
     static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
+    static const int fuse_st = getenv("FM_DW_STATS") ? atoi(getenv("FM_DW_STATS")) : 1;
+    if (!fuse_st) st = nullptr;
     const dim3 blk(256);
     if (dw_rowu_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const float* nul = nullptr;
-        if (K == 3) dw_rowu_launch<3, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s);
-        else dw_rowu_launch<5, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s);
-        return;
+        if (K == 3) return dw_rowu_launch<3, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s, st);
+        return dw_rowu_launch<5, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s, st);
     }
     if (dw_rowu_mode() && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
-        if (K == 3) dw_rowu_dgrad_s2_launch<3, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s);
-        else dw_rowu_dgrad_s2_launch<5, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s);
-        return;
+        if (K == 3) return dw_rowu_dgrad_s2_launch<3, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s, st);
+        return dw_rowu_dgrad_s2_launch<5, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s, st);
     }
     if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const float* nul = nullptr;
         if (K == 3) dw_tile_t<3, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
         else dw_tile_t<5, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
-        return;
+        return false;
     }
     if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         // stride 1: dx = dy (*) rot180(w), the forward kernel with the rotated kernel (Hi == Ho, Wi == Wo)
@@ -1265,7 +1346,7 @@ static void dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int
         const float* nul = nullptr;
         if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, dy, w, dx, nul, nul, imgs, Ho, Wo, Hi, Wi, C, 0, 1);
         else hipLaunchKernelGGL((dw_fwd_blk2_kernel<5, T>), grid, blk, 0, s, dy, w, dx, nul, nul, imgs, Ho, Wo, Hi, Wi, C, 0, 1);
-        return;
+        return false;
     }
     if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         const dim3 grid(cdiv((int64_t)imgs * Hi * ((Wi + 3) / 4) * (C / 4), 256));
@@ -1273,17 +1354,23 @@ static void dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int
         else if (K == 3) hipLaunchKernelGGL((dw_dgrad_blk_kernel<3, 2, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
         else if (stride == 1) hipLaunchKernelGGL((dw_dgrad_blk_kernel<5, 1, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
         else hipLaunchKernelGGL((dw_dgrad_blk_kernel<5, 2, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
-        return;
+        return false;
     }
     const dim3 grid(cdiv((int64_t)imgs * Hi * Wi * (C / 4), 256));
     if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l);
     else hipLaunchKernelGGL((dw_dgrad_kernel<5, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l);
+    return false;
 }
-void k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
-                int stride, int pad_t, int pad_l, hipStream_t s)
+// ye != null: dx feeds act(bn0(y_e)) -- also leave the BN0-backward sums (chan_reduce mode 1, swish) as
+// dw_stats_tiles() partials per group in stats_out; returns false when the launch shape could not do it
+bool k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                int stride, int pad_t, int pad_l, hipStream_t s, const void* ye, const float* mean, const float* istd,
+                const float* scale, const float* shift, float* stats_rec, float* stats_out, int groups)
 {
-    if (dt == DT_F32) dw_dgrad_t(cp<float>(dy), w, mp<float>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
-    else dw_dgrad_t(cp<bf16>(dy), w, mp<bf16>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s);
+    const DwStats st{stats_rec, stats_out, groups, ye, BnQuad{mean, istd, scale, shift}};
+    const DwStats* sp = ye ? &st : nullptr;
+    if (dt == DT_F32) return dw_dgrad_t(cp<float>(dy), w, mp<float>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s, sp);
+    return dw_dgrad_t(cp<bf16>(dy), w, mp<bf16>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s, sp);
 }
 
 // dw[kh][kw][c] = sum over output pixels of dy * x(shifted).  Thread = (channel quad, pixel lane):

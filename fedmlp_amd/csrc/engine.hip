@@ -1139,9 +1139,12 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
                    m.pad_t, m.pad_l, e->st); }
         if (m.c_exp >= 0) {
             Conv& ce = e->convs[m.c_exp];
-            { OP("k_dw_dgrad"); k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
-                       m.pad_l, e->st); }                                                   // d a_e
-            { OP("bnact_bwd"); bnact_bwd(e, m.bn0, e->T_big, ce.y, e->T_big, nullptr, groups, B * HWi, HWi, 2); }
+            Bn& b0 = e->bns[m.bn0];
+            bool sums;                           // d a_e, and the BN0-backward sums from the same registers
+            { OP("k_dw_dgrad"); sums = k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+                       m.pad_t, m.pad_l, e->st, ce.y, b0.mean, b0.istd, b0.scale, b0.shift, e->ws_slab, e->ws_part, groups); }
+            { OP("bnact_bwd"); bnact_bwd(e, m.bn0, e->T_big, ce.y, e->T_big, nullptr, groups, B * HWi, HWi, 2, nullptr, nullptr, -1,
+                                         sums ? dw_stats_tiles() : 0); }
             { OP("exp_wgrad"); conv_wgrad(e, m.c_exp, in, e->T_big, imgs); }
             { OP("exp_dgrad"); conv_dgrad(e, m.c_exp, S, e->T_big, gi, imgs, m.skip ? go : nullptr, false); }
         } else {

@@ -84,8 +84,10 @@ int dw_stats_tiles();                 // per-group partials k_dw_fwd leaves in s
 bool k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s,
               float* stats_rec = nullptr, float* stats_out = nullptr, int groups = 1);
-void k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
-                int stride, int pad_t, int pad_l, hipStream_t s);
+bool k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
+                int stride, int pad_t, int pad_l, hipStream_t s, const void* ye = nullptr, const float* mean = nullptr,
+                const float* istd = nullptr, const float* scale = nullptr, const float* shift = nullptr,
+                float* stats_rec = nullptr, float* stats_out = nullptr, int groups = 1);
 int dw_wgrad_blocks(int npix);
 // out [K*K][C] = the weight gradient; part = workspace for the per-block partial sums (reduced inside, fixed order)
 void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, float* out, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
