@@ -24,6 +24,53 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restr
     f32x4 v = {s[0], s[HW], s[2 * (int64_t)HW], 0.f};
     *reinterpret_cast<f32x4*>(y + i * 4) = v;
 }
+// ---- stem im2col for the bf16 configuration --------------------------------------------------------------
+// col[img][oh][ow][kh][kw_p = 4][4] (bf16, 16 B per (kh, kw) pair's 4 channel slots ... 32 B per kernel row) straight from the
+// caller's NCHW fp32 batch: the K axis has exactly the engine's stem-weight layout [cout][kh][kw_p][4], so the stem
+// becomes a K = k*16 pointwise convolution on the bf16 matrix pipe (forward of teacher and student and the weight
+// gradient all read this ONE buffer; the fp32 implicit-GEMM stem cost 5 of the step's 68 ms).  Thread = (pixel, kh).
+__global__ void stem_im2col_kernel(const float* __restrict__ x, bf16* __restrict__ col, int64_t n, int H, int W, int Ho, int Wo,
+                                   int k, int stride, int pad_t, int pad_l)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int kh = (int)(i % k);
+    int64_t p = i / k;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int64_t img = p / Ho;
+    const int ih = oh * stride + kh - pad_t, iw0 = ow * stride - pad_l;
+    const bool rv = (unsigned)ih < (unsigned)H;
+    const float* xi = x + (img * 3) * (int64_t)H * W + (int64_t)(rv ? ih : 0) * W;
+    float v[4][4];
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+        const int iw = iw0 + kw;
+        const bool ok = rv && kw < k && (unsigned)iw < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = xi[(int64_t)c * H * W + (ok ? iw : 0)];
+            v[kw][c] = ok ? t : 0.f;
+        }
+        v[kw][3] = 0.f;
+    }
+    bf16* o = col + i * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4 a = {v[2 * h][0], v[2 * h][1], v[2 * h][2], v[2 * h][3]};
+        const f32x4 b = {v[2 * h + 1][0], v[2 * h + 1][1], v[2 * h + 1][2], v[2 * h + 1][3]};
+        const bf16x4 pa = __builtin_convertvector(a, bf16x4), pb = __builtin_convertvector(b, bf16x4);
+        *reinterpret_cast<bf16x8*>(o + 8 * h) = __builtin_shufflevector(pa, pb, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+void k_stem_im2col(const float* x, void* col, int imgs, int H, int W, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
+                   hipStream_t s)
+{
+    const int64_t n = (int64_t)imgs * Ho * Wo * k;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, reinterpret_cast<bf16*>(col), n, H, W, Ho, Wo, k,
+                       stride, pad_t, pad_l);
+}
+
 void k_nchw_to_nhwc4(const float* x, float* y, int imgs, int H, int W, hipStream_t s)
 {
     int64_t n = (int64_t)imgs * H * W;

@@ -187,7 +187,7 @@ struct fm_engine {
     int n_cast_jobs = 0, n_cast_blocks = 0;
     bool wb_dirty = true, twb_dirty = true;
     bool fuse_gate = false;           // squeeze-excite gate applied on the project conv's operand load (a_s never stored)
-    float* stem_dy = nullptr;         // bf16 mode: fp32 gradient of the stem's raw output (the stem conv stays fp32)
+    float* stem_col = nullptr;        // bf16 mode: [images][hout][wout][k][4][4] bf16 im2col of the input (the stem's X operand)
 };
 
 namespace {
@@ -305,10 +305,12 @@ int build_tables(fm_engine* e)
         long long off = 0;
         int cb = 0;
         for (auto& c : e->convs) {
-            if (c.k != 1) continue;
-            const long long n = (long long)c.cout_p * c.cin_p;
+            const bool stem = c.cin == 3 && e->model == 1;    // the stem runs as a K = k*kw_p*4 pointwise conv on its im2col
+            if (c.k != 1 && !stem) continue;
+            const int Kc = stem ? c.Kw : c.cin_p;
+            const long long n = (long long)c.cout_p * Kc;
             c.wb_off = off; c.wbt_off = off + n;
-            cj.push_back({(long long)c.w_off, c.wb_off, c.wbt_off, c.cout_p, c.cin_p, cb});
+            cj.push_back({(long long)c.w_off, c.wb_off, c.wbt_off, c.cout_p, Kc, cb});
             off += 2 * n;
             cb += (int)((n + 255) / 256);
         }
@@ -516,8 +518,8 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->x4, B * e->H * e->W * 4);
     size_t max_stats = 0, max_slab = 0;
     for (auto& c : e->convs) {
-        if (c.cin == 3) DALLOC(c.y, B * c.hout * c.wout * c.cout_p);       // the stem's raw output is fp32 in every mode
-        else AALLOC(c.y, B * c.hout * c.wout * c.cout_p);
+        AALLOC(c.y, B * c.hout * c.wout * c.cout_p);
+        if (c.cin == 3 && e->precision) AALLOC(e->stem_col, B * c.hout * c.wout * c.Kw);   // bf16 im2col of the input batch
         size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout_p) - 1) / igemm_tile_n(c.cout_p) + 2;
         if (e->precision) tiles = std::max<size_t>(tiles, B * c.hout * c.wout / 128 + 4);   // pw_blocks(): >= 128 pixels per block
         max_stats = std::max(max_stats, (tiles + 2 * 32) * 2 * c.cout_p);   // + folded partials
@@ -540,7 +542,6 @@ int alloc_workspaces(fm_engine* e)
     } else {
         size_t g_io = B * c0.hout * c0.wout * c0.cout_p, t_small = 0, t_mid = 0, t_big = 0, max_ce = 0, max_cs = 0;
         AALLOC(e->a0, g_io);
-        if (e->precision) DALLOC(e->stem_dy, g_io);
         for (auto& m : e->mbs) {
             const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
             if (m.c_exp >= 0) AALLOC(m.a_e, nin * m.ce_p);
@@ -636,11 +637,12 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
               const Prologue* pro = nullptr)
 {
     const Conv& c = e->convs[ci];
-    if (e->precision && c.k == 1) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
+    const bool stem16 = e->precision && c.cin == 3;     // `x` is ignored: the operand is the im2col matrix
+    if (e->precision && (c.k == 1 || stem16)) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
         PwParams q{};
         q.W = shadow_of(e, S) + c.wb_off;
-        q.X = reinterpret_cast<const bf16*>(x); q.Y = reinterpret_cast<bf16*>(y);
-        q.M = c.cout_p; q.K = c.cin_p;
+        q.X = reinterpret_cast<const bf16*>(stem16 ? e->stem_col : x); q.Y = reinterpret_cast<bf16*>(y);
+        q.M = c.cout_p; q.K = stem16 ? c.Kw : c.cin_p;
         q.npix = (imgs / groups) * c.hout * c.wout; q.groups = groups;
         q.scale = scale; q.shift = shift; q.res = reinterpret_cast<const bf16*>(res); q.act = relu;
         q.stats = stats;
@@ -675,7 +677,8 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
 int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
 {
     const Conv& c = e->convs[ci];
-    if (e->precision && c.k == 1) return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin_p);
+    if (e->precision && (c.k == 1 || c.cin == 3))
+        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p);
     const int bn = igemm_tile_n(c.cout_p);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
@@ -725,10 +728,11 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
                 int pix_per_group = 0)
 {
     const Conv& c = e->convs[ci];
-    if (e->precision && c.k == 1) {
+    const bool stem16 = e->precision && c.cin == 3;
+    if (e->precision && (c.k == 1 || stem16)) {
         PwWgradParams q{};
-        q.dY = reinterpret_cast<const bf16*>(dy); q.X = reinterpret_cast<const bf16*>(x);
-        q.slab = e->ws_slab; q.M = c.cout_p; q.K = c.cin_p; q.npix = imgs * c.hout * c.wout;
+        q.dY = reinterpret_cast<const bf16*>(dy); q.X = reinterpret_cast<const bf16*>(stem16 ? e->stem_col : x);
+        q.slab = e->ws_slab; q.M = c.cout_p; q.K = stem16 ? c.Kw : c.cin_p; q.npix = imgs * c.hout * c.wout;
         if (pro && pro->gate) { q.psc = pro->psc; q.psh = pro->psh; q.gate = pro->gate; }
         q.HW = c.hout * c.wout; q.pix_per_group = pix_per_group ? pix_per_group : q.npix;
         const int sk = launch_pw_wgrad(q, e->slab_floats, e->st);
@@ -800,6 +804,13 @@ void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, fl
 
 void to_nhwc4(fm_engine* e, const float* const* xs, int groups, int B)
 {
+    if (e->precision && e->model == 1) {      // bf16 EfficientNet: the stem reads an im2col matrix (teacher, student and wgrad share it)
+        const Conv& c = e->convs[e->c_stem];
+        for (int g = 0; g < groups; ++g)
+            k_stem_im2col(xs[g], reinterpret_cast<bf16*>(e->stem_col) + (size_t)g * B * c.hout * c.wout * c.Kw, B, e->H, e->W, c.hout,
+                          c.wout, c.k, c.stride, c.pad, c.pad, e->st);
+        return;
+    }
     for (int g = 0; g < groups; ++g)
         k_nchw_to_nhwc4(xs[g], e->x4 + (size_t)g * B * e->H * e->W * 4, B, e->H, e->W, e->st);
 }
@@ -985,7 +996,7 @@ void eff_forward_train(fm_engine* e, int groups, int B)
     { OP("bn_fwd_finalize"); bn_fwd_finalize(e, e->c_stem, groups, B); }
     {
         Bn& b = e->bns[e->bn_stem];
-        { OP("k_bnact_apply"); k_bnact_apply(cs.y, DT_F32, b.scale, b.shift, nullptr, nullptr, e->a0, e->dt, groups, B * cs.hout * cs.wout,
+        { OP("k_bnact_apply"); k_bnact_apply(cs.y, e->dt, b.scale, b.shift, nullptr, nullptr, e->a0, e->dt, groups, B * cs.hout * cs.wout,
                       cs.hout * cs.wout, b.C, 2, e->st); }
     }
     const float* cur = e->a0;
@@ -1057,13 +1068,7 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
     }
     auto sc = [&](int bi) { return evs + e->bns[bi].ch_off; };
     auto sh = [&](int bi) { return evh + e->bns[bi].ch_off; };
-    if (e->precision) {      // the stem conv is fp32: raw output, then BN + Swish into the bf16 activation
-        Conv& cs = e->convs[e->c_stem];
-        { OP("conv_fwd"); conv_fwd(e, e->c_stem, S, e->x4, cs.y, imgs, 1, nullptr, nullptr, nullptr, 0, nullptr); }
-        { OP("k_bnact_apply"); k_bnact_apply(cs.y, DT_F32, sc(e->bn_stem), sh(e->bn_stem), nullptr, nullptr, e->a0, e->dt, 1, imgs * cs.hout * cs.wout,
-                      cs.hout * cs.wout, e->bns[e->bn_stem].C, 2, e->st); }
-    } else
-        { OP("conv_fwd"); conv_fwd(e, e->c_stem, S, e->x4, e->a0, imgs, 1, sc(e->bn_stem), sh(e->bn_stem), nullptr, 2, nullptr); }
+    { OP("conv_fwd"); conv_fwd(e, e->c_stem, S, e->x4, e->a0, imgs, 1, sc(e->bn_stem), sh(e->bn_stem), nullptr, 2, nullptr); }
     const float* cur = e->a0;
     e->ctx = 200;
     for (auto& m : e->mbs) {
@@ -1156,10 +1161,8 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     }
     Conv& cs = e->convs[e->c_stem];
     e->ctx = 399;
-    float* sdy = e->precision ? e->stem_dy : go;        // fp32 gradient of the stem's fp32 raw output
-    { OP("bnact_bwd"); bnact_bwd(e, e->bn_stem, go, cs.y, sdy, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2, nullptr, nullptr,
-              DT_F32); }
-    { OP("conv_wgrad"); conv_wgrad(e, e->c_stem, e->x4, sdy, imgs); }
+    { OP("bnact_bwd"); bnact_bwd(e, e->bn_stem, go, cs.y, go, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2); }
+    { OP("conv_wgrad"); conv_wgrad(e, e->c_stem, e->x4, go, imgs); }
     { OP("adam_step"); adam_step(e); }
 }
 

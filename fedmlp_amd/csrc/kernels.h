@@ -13,6 +13,9 @@ struct TapList { int t[9]; int n; };
 
 // ---- layout -----------------------------------------------------------------
 void k_nchw_to_nhwc4(const float* x, float* y, int imgs, int H, int W, hipStream_t s);
+// bf16 stem: col [imgs][Ho][Wo][k][4][4] bf16 from the NCHW fp32 batch (kw_p = 4, 3 channels + 1 zero slot)
+void k_stem_im2col(const float* x, void* col, int imgs, int H, int W, int Ho, int Wo, int k, int stride, int pad_t, int pad_l,
+                   hipStream_t s);
 // dst[o][h][w(Wpad)][i(Ipad)] <- src[o][i][h][w]  (zero padded) and its inverse
 void k_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s);
 void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s);
