@@ -840,6 +840,7 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
                     st1 += q;
                     st2 += q * q;
                 }
+                if constexpr (ST == 3) st1 += stored_value<T>(v) * (rm * cmask[j]);     // eval: squeeze-excite pooling
                 if constexpr (ST == 2) {
                     const f32x4 yy = raw_cvt(rye[r][j]);
                     const f32x4 u = yy * bsc + bsh;
@@ -857,14 +858,16 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
         if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
         __syncthreads();
         if (wave == 0) {
-            rec[((size_t)blockIdx.x * 2 + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
-            rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
+            constexpr int NR = ST == 3 ? 1 : 2;       // the pooling record holds the sum only
+            rec[((size_t)blockIdx.x * NR + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            if constexpr (ST != 3)
+                rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
         }
     }
 }
 // stride-2 forward in the same row-uniform form: a wave step = one output row (img, oh), lanes = (4-column block of the
 // output row, channel quad); K input rows of 6 + K columns each, double-buffered (K is odd: the last row is peeled).
-template <int K, typename T, bool PF, bool ST = false>
+template <int K, typename T, bool PF, int ST = 0>
 __global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int nrows, int Hi, int Wi, int Ho, int Wo, int C, int act, int nchunk,
@@ -943,20 +946,23 @@ __global__ __launch_bounds__(256) void dw_rowu_s2_kernel(const T* __restrict__ x
             f32x4 v = acc[j];
             if (scale) v = act_fwd<FAST>(v * sc + sh, act);
             raw_store(ro, vout[j], v, (T*)nullptr);
-            if constexpr (ST) {
+            if constexpr (ST == 1) {
                 const f32x4 q = stored_value<T>(v) * cmask[j];
                 st1 += q;
                 st2 += q * q;
             }
+            if constexpr (ST == 3) st1 += stored_value<T>(v) * cmask[j];
         }
     }
-    if constexpr (ST) {
+    if constexpr (ST != 0) {
         __shared__ f32x4 red[3][2][64];
         if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
         __syncthreads();
         if (wave == 0) {
-            rec[((size_t)blockIdx.x * 2 + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
-            rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
+            constexpr int NR = ST == 3 ? 1 : 2;       // the pooling record holds the sum only
+            rec[((size_t)blockIdx.x * NR + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            if constexpr (ST != 3)
+                rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
         }
     }
 }
@@ -1061,8 +1067,10 @@ __global__ __launch_bounds__(256) void dw_rowu_dgrad_s2_kernel(const T* __restri
         if (wave > 0) { red[wave - 1][0][lane] = st1; red[wave - 1][1][lane] = st2; }
         __syncthreads();
         if (wave == 0) {
-            rec[((size_t)blockIdx.x * 2 + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
-            rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
+            constexpr int NR = ST == 3 ? 1 : 2;       // the pooling record holds the sum only
+            rec[((size_t)blockIdx.x * NR + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            if constexpr (ST != 3)
+                rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
         }
     }
 }
@@ -1075,7 +1083,14 @@ __global__ void dw_rowu_wgrad_reduce(const f32x4* __restrict__ part, float* __re
                                      int nrg, int nsplit);
 // Train-mode statistics request of a depthwise forward: rec = record workspace, out = [groups][1][2][C] partials for
 // k_bn_finalize (tiles = 1).  Honoured when the row steps of one statistics group fill whole blocks.
-struct DwStats { float* rec; float* out; int groups; const void* ye; BnQuad bnq; };   // ye != null: the BN0-backward sums
+struct DwStats { float* rec; float* out; int groups; const void* ye; BnQuad bnq; float* pool; };   // ye: the BN0-backward sums;
+// pool != null (eval forward): per-image channel sums of the activated output -> pool [imgs][C] (the squeeze-excite pooling)
+static inline int dw_pool_rpb(int steps_per_image)
+{
+    for (int r = std::min(16, steps_per_image); r >= 1; --r)
+        if (steps_per_image % r == 0) return r;
+    return 1;
+}
 constexpr int DW_ST_SPLITS = 8;              // partials per group the statistics reducer leaves (k_bn_finalize tiles)
 // row groups per statistics group: the largest divisor of the group's steps that keeps the launch near 3072 blocks
 // (every block leaves a record: with the forward's 16-step blocks the 112x112 layer would leave 14 336 of them)
@@ -1094,6 +1109,15 @@ static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
     const int nchunk = (WB * Q + 63) / 64, nrp = imgs * HB;
     static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
     int rpb = std::max(4, rpb_env);
+    if (st && st->pool) {          // eval: blocks stay inside one image, one record each, summed per image
+        rpb = dw_pool_rpb(HB);
+        const int gpi = HB / rpb;
+        hipLaunchKernelGGL((dw_rowu_kernel<K, T, 3>), dim3(nchunk * gpi * imgs), dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act,
+                           flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+        hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16, 1, imgs), dim3(256), 0, s, reinterpret_cast<const f32x4*>(st->rec),
+                           st->pool, 1, Q, WB, nchunk, gpi, 1);
+        return true;
+    }
     if (st && nrp % st->groups == 0) {
         const int nrg_g = dw_stats_rowgroups(nrp / st->groups, nchunk, st->groups);
         if (nrg_g) {
@@ -1129,11 +1153,20 @@ static bool dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* sca
     static const int pf_env = getenv("FM_DW_PF") ? atoi(getenv("FM_DW_PF")) : -1;
     int rpb = std::max(4, rpb_env);
     const bool pf = pf_env >= 0 ? pf_env != 0 : true;      // fp32 5x5 stride 2: 0.44 -> 0.32 ms with the second row buffer
+    if (st && st->pool) {
+        rpb = dw_pool_rpb(Ho);
+        const int gpi = Ho / rpb;
+        hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, true, 3>), dim3(nchunk * gpi * imgs), dim3(256), 0, s, x, w, y, scale, shift, nrows, Hi,
+                           Wi, Ho, Wo, C, act, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+        hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16, 1, imgs), dim3(256), 0, s, reinterpret_cast<const f32x4*>(st->rec),
+                           st->pool, 1, Q, WB, nchunk, gpi, 1);
+        return true;
+    }
     if (st && nrows % st->groups == 0) {
         const int nrg_g = dw_stats_rowgroups(nrows / st->groups, nchunk, st->groups);
         if (nrg_g) {
             rpb = nrows / st->groups / nrg_g;
-            hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, true, true>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale,
+            hipLaunchKernelGGL((dw_rowu_s2_kernel<K, T, true, 1>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale,
                                shift, nrows, Hi, Wi, Ho, Wo, C, act, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
             hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16 * DW_ST_SPLITS, 2, st->groups), dim3(256), 0, s,
                                reinterpret_cast<const f32x4*>(st->rec), st->out, 2, Q, WB, nchunk, nrg_g, DW_ST_SPLITS);
@@ -1213,13 +1246,15 @@ static bool dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const
     return false;
 }
 // dt: storage type of x and y (DT_F32 / DT_BF16); weights and the BN affine are fp32
+// pool_out != null (eval mode, with stats_rec as record workspace): also leave the per-image channel SUMS of the stored
+// (activated) output in pool_out [imgs][C] -- the squeeze-excite pooling without another pass over y.
 // stats_rec != null (train mode): also leave the per-channel sum / sum of squares of y as ONE partial per group in
 // stats_out [groups][dw_stats_tiles()][2][C]; returns false when the launch shape could not do it (the caller then reduces y itself)
 bool k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s, float* stats_rec,
-              float* stats_out, int groups)
+              float* stats_out, int groups, float* pool_out)
 {
-    const DwStats st{stats_rec, stats_out, groups, nullptr, BnQuad{nullptr, nullptr, nullptr, nullptr}};
+    const DwStats st{stats_rec, stats_out, groups, nullptr, BnQuad{nullptr, nullptr, nullptr, nullptr}, pool_out};
     const DwStats* sp = stats_rec ? &st : nullptr;
     if (dt == DT_F32)
         return dw_fwd_t(cp<float>(x), w, mp<float>(y), scale, shift, imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, act, s, nullptr,
@@ -1367,7 +1402,7 @@ bool k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int 
                 int stride, int pad_t, int pad_l, hipStream_t s, const void* ye, const float* mean, const float* istd,
                 const float* scale, const float* shift, float* stats_rec, float* stats_out, int groups)
 {
-    const DwStats st{stats_rec, stats_out, groups, ye, BnQuad{mean, istd, scale, shift}};
+    const DwStats st{stats_rec, stats_out, groups, ye, BnQuad{mean, istd, scale, shift}, nullptr};
     const DwStats* sp = ye ? &st : nullptr;
     if (dt == DT_F32) return dw_dgrad_t(cp<float>(dy), w, mp<float>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s, sp);
     return dw_dgrad_t(cp<bf16>(dy), w, mp<bf16>(dx), imgs, Hi, Wi, Ho, Wo, C, K, stride, pad_t, pad_l, s, sp);
@@ -1960,12 +1995,13 @@ __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const flo
         gate[(size_t)img * C + c] = sigm(t);
     }
 }
+// pooled: pool_ws [imgs][C] already holds the per-image channel sums (left by the eval-mode depthwise forward)
 void k_se_fwd(const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
               const float* b1, const float* W2, const float* b2, float* sq, float* rpre, float* gate, int imgs, int HW,
-              int C, int Cs, hipStream_t s)
+              int C, int Cs, hipStream_t s, bool pooled)
 {
-    k_chan_pool(a, nullptr, dt, pool_ws, imgs, HW, C, scale ? 1 : 0, scale, shift, ipg, s);
-    hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, chan_pool_chunks(HW),
+    if (!pooled) k_chan_pool(a, nullptr, dt, pool_ws, imgs, HW, C, scale ? 1 : 0, scale, shift, ipg, s);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(imgs), dim3(256), (C + Cs) * sizeof(float), s, pool_ws, pooled ? 1 : chan_pool_chunks(HW),
                        W1, b1, W2, b2, sq, rpre, gate, HW, C, Cs);
 }
 

@@ -1079,10 +1079,11 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
             { OP("exp_fwd"); conv_fwd(e, m.c_exp, S, cur, m.a_e, imgs, 1, sc(m.bn0), sh(m.bn0), nullptr, 2, nullptr); }
             a_e = m.a_e;
         }
-        { OP("k_dw_fwd"); k_dw_fwd(a_e, S + m.dw_off, m.y_d, e->dt, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
-                 m.pad_t, m.pad_l, 2, e->st); }          // eval: y_d holds swish(bn1(.)) directly
+        bool pooled;                      // eval: y_d holds swish(bn1(.)) directly; its per-image channel sums come with it
+        { OP("k_dw_fwd"); pooled = k_dw_fwd(a_e, S + m.dw_off, m.y_d, e->dt, sc(m.bn1), sh(m.bn1), imgs, m.hin, m.win, m.hout, m.wout, m.ce_p,
+                 m.k, m.s, m.pad_t, m.pad_l, 2, e->st, e->ws_slab, nullptr, 1, e->se_pool); }
         { OP("k_se_fwd"); k_se_fwd(m.y_d, e->dt, nullptr, nullptr, 1, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq,
-                 m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st); }
+                 m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st, pooled); }
         if (fuse_for(e, m)) {      // the gate multiplies the activation on the project conv's operand load
             const Prologue pro{nullptr, nullptr, m.gate};
             { OP("proj_fwd"); conv_fwd(e, m.c_proj, S, m.y_d, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr, &pro); }

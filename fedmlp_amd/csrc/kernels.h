@@ -86,7 +86,7 @@ void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const floa
 int dw_stats_tiles();                 // per-group partials k_dw_fwd leaves in stats_out when it serves the request
 bool k_dw_fwd(const void* x, const float* w, void* y, int dt, const float* scale, const float* shift, int imgs, int Hi,
               int Wi, int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s,
-              float* stats_rec = nullptr, float* stats_out = nullptr, int groups = 1);
+              float* stats_rec = nullptr, float* stats_out = nullptr, int groups = 1, float* pool_out = nullptr);
 bool k_dw_dgrad(const void* dy, const float* w, void* dx, int dt, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s, const void* ye = nullptr, const float* mean = nullptr,
                 const float* istd = nullptr, const float* scale = nullptr, const float* shift = nullptr,
@@ -101,7 +101,7 @@ void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, float* out, 
 // as swish(a*scale+shift) -- the post-BN activation is not materialised in the train path
 void k_se_fwd(const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws, const float* W1,
               const float* b1, const float* W2, const float* b2, float* sq, float* rpre, float* gate, int imgs, int HW,
-              int C, int Cs, hipStream_t s);
+              int C, int Cs, hipStream_t s, bool pooled = false);
 void k_se_scale(const void* a, int dt, const float* scale, const float* shift, int ipg, const float* gate, void* out, int imgs,
                 int HW, int C, hipStream_t s);
 void k_se_bwd(const void* dout, const void* a, int dt, const float* scale, const float* shift, int ipg, float* pool_ws,
