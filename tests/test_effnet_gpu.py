@@ -342,6 +342,49 @@ def test_step_bce_generic_depthwise_kernels(eng, monkeypatch):
     _cmp_grads(eng, net)
 
 
+@pytest.mark.parametrize("hw,views", [(224, 1), (160, 1), (96, 2)])
+def test_step_odd_spatial_sizes(hw, views):
+    """The benchmark's spatial sizes are 112 / 56 / 28 / 14 / 7; the 64 x 64 tests above only see powers of two.  At
+    224 x 224 the blocks run at exactly those sizes (odd rows and 7 % 4 = 3 partial column blocks in the row-uniform
+    depthwise kernels, their fused BN statistics and per-image pooling records); 160 x 160 gives 80 / 40 / 20 / 10 / 5 and
+    96 x 96 gives 48 / 24 / 12 / 6 / 3 with two statistics groups (a stage-1 step).  fp32, oracle bounds."""
+    from fedmlp_amd.engine import Engine
+    e = Engine(M, C_, hw, hw, 8)
+    try:
+        e.stochastic = False
+        net = _load(e)
+        g = torch.Generator().manual_seed(100 + hw)
+        B = 2 if hw > 200 else 3
+        xs = [torch.randn((B, 3, hw, hw), generator=g) for _ in range(views)]
+        y = (torch.rand((B, C_), generator=g) < 0.3).float()
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+        lo = torch.zeros(1, device="cuda")
+        if views == 1:
+            pw = [3.0, 1.5, 4.0, 2.0, 2.5]
+            _, z = net(xs[0])
+            loss = R.loss_train(z, y, pw, 4, C_)
+            opt.zero_grad(); loss.backward(); opt.step()
+            e.step_bce(xs[0].cuda(), y.cuda(), pw, 4, lo)
+        else:
+            import copy
+            glob = copy.deepcopy(net).eval()
+            e.teacher_snapshot()
+            act, neg = [1], [0, 2, 3, 4]
+            _, z1 = net(xs[0]); _, z2 = net(xs[1])
+            with torch.no_grad():
+                _, g1 = glob(xs[0]); _, g2 = glob(xs[1])
+            loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 4, 1)
+            opt.zero_grad(); loss.backward(); opt.step()
+            mask = [1.0 if c in act else 0.0 for c in range(C_)]
+            e.step_stage1(xs[0].cuda(), xs[1].cuda(), y.cuda(), mask, 1, 4, lo)
+        assert abs(lo.item() - loss.item()) < 5e-5 * abs(loss.item()) + 1e-7
+        _cmp_grads(e, net)
+        _cmp_state(e, net, atol_w=2.5 * LR)
+    finally:
+        e.close()
+
+
 def test_step_is_run_to_run_deterministic(eng):
     (x,), y = _data(6, 42)
     outs = []
