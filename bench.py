@@ -128,6 +128,18 @@ def cpu_baseline(args):
                       f"arithmetic, no DataLoader; {dt:.1f} s"}
 
 
+def family_traffic(prefix, args):
+    """launch-weighted mean HBM bytes per launch over every profiled kernel whose name contains `prefix`"""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            doc = json.load(f).get(workload_key(args))
+        ks = [v for k, v in doc["kernels"].items() if prefix in k.replace(" ", "")]
+        n = sum(v["launches"] for v in ks)
+        return int(sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for v in ks) / n) if n else None
+    except Exception:
+        return None
+
+
 def measured_traffic(kernel_name, args):
     """HBM-side bytes per launch of the dominant kernel.  NOT measured in this run: read from the
     committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate passes over this
@@ -288,6 +300,7 @@ def main():
                     "kernel": name, "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
                     "all_kernels": allk}
             if args.workload == "conv_fwd":
+                roof["traffic"] = family_traffic("igemm_kernel<", args)     # mean over the 20 conv launches of a pass
                 roof["algorithmic_flop_per_pass"] = RESNET_FWD_FLOP * B
                 roof["whole_pass_tflops"] = round(RESNET_FWD_FLOP * B / (dt / args.steps) / 1e12, 3)
     lv = losses.cpu().numpy()
