@@ -435,6 +435,123 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const WgArgs p)
     }
 }
 
+// ---- weight gradient of the small high-resolution layers: one wave per pixel tile, no block barrier -----------------
+// With L <= 144 and S <= 32 channels (blocks 0-3: 16x32 ... 32x144 weights over 3-13 M pixels) the kernel above moves a
+// 32-pixel tile per step through a block-wide barrier pair and gives each wave ONE to two MFMAs (half the waves none when
+// L = 32): it ran at 1.4-1.7 TB/s.  Here every wave owns its own pixel tiles and ALL L x S of the product: it stages a
+// 32-pixel tile of both operands in a wave-private LDS region (no __syncthreads: a wave's LDS operations execute in order,
+// so the next tile is written right after the transposed reads of the current one were issued), its global loads for
+// tile s+1 fly during the MFMAs of tile s, and it leaves its own slab (4 x blocks slabs, fixed-order reduction as before).
+template <int NRT, int CC, bool PRO>
+__global__ __launch_bounds__(256) void pw_wgrad_wave_kernel(const WgArgs p, int strideB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int strideS = p.strideS;
+    unsigned char* base = smem + wave * 32 * (strideB + strideS);
+    unsigned char* sbase = base + 32 * strideB;
+    const int ws = blockIdx.x * 4 + wave, nws = gridDim.x * 4;
+    const int tsteps = (p.npix + 31) >> 5;
+    const int nsteps = ws < tsteps ? (tsteps - ws + nws - 1) / nws : 0;
+    constexpr int CPB = 2 * NRT, CPS = 2 * CC;              // 16-B chunks per row of the Big / Small tile
+    constexpr int NBG = (32 * CPB + 63) / 64, NSM = (32 * CPS + 63) / 64;
+    const int L = 16 * NRT, S = 16 * CC;
+    uint4 vb[NBG], vs[NSM];
+    auto xform = [&](uint4 v, int pix, int ch) {
+        const int g = pix / p.pix_per_group;
+        const float* gt = p.gate + (size_t)(pix / p.HW) * p.K + ch;
+        const bool affine = p.psc != nullptr;
+        const float* sc = affine ? p.psc + g * p.K + ch : nullptr;
+        const float* sh = affine ? p.psh + g * p.K + ch : nullptr;
+        const f32x4 lo = pro4(lo4(v), sc, sh, gt, affine);
+        const f32x4 hi = pro4(hi4(v), affine ? sc + 4 : nullptr, affine ? sh + 4 : nullptr, gt + 4, affine);
+        return pack8(lo, hi);
+    };
+    auto gload = [&](int s) {
+        const int pb = (ws + s * nws) * 32;
+#pragma unroll
+        for (int q = 0; q < NBG; ++q) {
+            const int c = lane + 64 * q;
+            const int row = c / CPB, cb = c - row * CPB;
+            const int pix = pb + row;
+            vb[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < 32 * CPB && pix < p.npix) {
+                vb[q] = *reinterpret_cast<const uint4*>(p.Big + (size_t)pix * L + 8 * cb);
+                if constexpr (PRO) { if (p.swap) vb[q] = xform(vb[q], pix, 8 * cb); }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NSM; ++q) {
+            const int c = lane + 64 * q;
+            const int row = c / CPS, cb = c - row * CPS;
+            const int pix = pb + row;
+            vs[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < 32 * CPS && pix < p.npix) {
+                vs[q] = *reinterpret_cast<const uint4*>(p.Small + (size_t)pix * S + 8 * cb);
+                if constexpr (PRO) { if (!p.swap) vs[q] = xform(vs[q], pix, 8 * cb); }
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NBG; ++q) {
+            const int c = lane + 64 * q;
+            const int row = c / CPB, cb = c - row * CPB;
+            if (c < 32 * CPB) *reinterpret_cast<uint4*>(base + row * strideB + cb * 16) = vb[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NSM; ++q) {
+            const int c = lane + 64 * q;
+            const int row = c / CPS, cb = c - row * CPS;
+            if (c < 32 * CPS) *reinterpret_cast<uint4*>(sbase + row * strideS + cb * 16) = vs[q];
+        }
+    };
+    f32x4 acc[NRT][CC];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) { gload(0); lstore(); }
+    const int trow = 4 * lg + (li >> 2), tcol = 4 * (li & 3);
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) gload(s + 1);
+        uint4 b[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const unsigned char* bb = sbase + trow * strideS + (16 * c + tcol) * 2;
+            const uint2 b0 = ds_read_tr16(bb), b1 = ds_read_tr16(bb + 16 * strideS);
+            b[c] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        }
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            const unsigned char* ab = base + trow * strideB + (16 * r + tcol) * 2;
+            const uint2 a0 = ds_read_tr16(ab), a1 = ds_read_tr16(ab + 16 * strideB);
+            const uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[r][c] = mfma32(a, b[c], acc[r][c]);
+        }
+        if (s + 1 < nsteps) lstore();
+    }
+    // acc[r][c][q] = P[l = 16 r + 4 lg + q][s = 16 c + li]; this wave's slab (zeros when it had no tile)
+    float* slab = p.slab + (size_t)ws * p.M * p.K;
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) {
+        const int l = 16 * r + 4 * lg;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int sc = 16 * c + li;
+            if (p.swap) {
+                *reinterpret_cast<f32x4*>(slab + (size_t)sc * p.K + l) = acc[r][c];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) slab[(size_t)(l + q) * p.K + sc] = acc[r][c][q];
+            }
+        }
+    }
+}
+
 // smallest 32 x odd >= bytes
 int odd32(int bytes)
 {
@@ -540,6 +657,40 @@ int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
     a.slab = w.slab; a.M = w.M; a.K = w.K; a.npix = w.npix;
     a.psc = w.psc; a.psh = w.psh; a.gate = w.gate; a.HW = w.HW; a.pix_per_group = w.pix_per_group;
     const int cc = a.S / 16;
+    {   // small high-resolution layers: the barrier-free one-wave-per-tile kernel
+        static const int wave_on = getenv("FM_PW_WG_WAVE") ? atoi(getenv("FM_PW_WG_WAVE")) : 1;
+        const int nrt = a.L / 16;
+        const bool shape = (nrt == 2 && cc == 1) || (nrt == 6 && (cc == 1 || cc == 2)) || (nrt == 9 && cc == 2);
+        // measured (ms, 1024 images): without prologue 96x16 0.77 -> 0.55, 144x32 0.35 -> 0.31; with the gate prologue 32x16
+        // 0.89 -> 0.65 but 96x32 0.48 -> 0.69 and 144x32 0.68 -> 1.26 (all of a tile's BN / gate operands per lane: 204-276
+        // registers), so the prologue variants keep the block kernel except for the smallest shape
+        if (wave_on && shape && (w.gate == nullptr || nrt == 2)) {
+            a.strideS = odd32(2 * a.S);
+            const int strideB = odd32(2 * a.L);
+            const int tsteps = (w.npix + 31) / 32;
+            int nblk = std::max(1, std::min(768, tsteps / 32));
+            nblk = (int)std::min<size_t>(nblk, std::max<size_t>(1, slab_floats / ((size_t)4 * w.M * w.K)));
+            const size_t lds = (size_t)4 * 32 * (strideB + a.strideS);
+            const bool pro = w.gate != nullptr;
+#define WG_WAVE(N, C)                                                                                                      \
+    do {                                                                                                                   \
+        static bool done_ = false;                                                                                         \
+        if (!done_) {                                                                                                      \
+            set_max_dyn_lds(reinterpret_cast<const void*>(&pw_wgrad_wave_kernel<N, C, false>), 64 * 1024, "pw_wgrad_wave");  \
+            set_max_dyn_lds(reinterpret_cast<const void*>(&pw_wgrad_wave_kernel<N, C, true>), 64 * 1024, "pw_wgrad_wave");   \
+            done_ = true;                                                                                                  \
+        }                                                                                                                  \
+        if (pro) hipLaunchKernelGGL((pw_wgrad_wave_kernel<N, C, true>), dim3(nblk), dim3(256), lds, s, a, strideB);        \
+        else hipLaunchKernelGGL((pw_wgrad_wave_kernel<N, C, false>), dim3(nblk), dim3(256), lds, s, a, strideB);           \
+    } while (0)
+            if (nrt == 2) WG_WAVE(2, 1);
+            else if (nrt == 6 && cc == 1) WG_WAVE(6, 1);
+            else if (nrt == 6) WG_WAVE(6, 2);
+            else WG_WAVE(9, 2);
+#undef WG_WAVE
+            return 4 * nblk;
+        }
+    }
     static const int avail[] = {1, 2, 3, 5, 7, 12, 20};
     int CCi = 20;
     for (int v : avail) if (v >= cc) { CCi = v; break; }
