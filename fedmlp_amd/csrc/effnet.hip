@@ -288,12 +288,12 @@ void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const floa
 }
 
 // ------------------------------------------------------------ depthwise conv ---
-// The register-blocked kernels below are straight-line code per thread (branch-free bounds handling, ld4z): without a
-// fence the scheduler hoists the whole (K+1) x (K+3) window of loads to the top and spills; ROW_FENCE keeps one input
-// row's loads + FMAs together (8-11 loads in flight per wave, 4 waves per SIMD).
-// FM_DW_BRANCHFREE 1: bounds handled by address clamp + select (ld4z), rows fenced; measured with the VGPR cap needed for
-// 4 waves per SIMD the 5x5 forms spill, so the shipped stride-2 kernels keep the predicated form (0) and the stride-1
-// layers run through dw_rowu_kernel below.
+// Three generations of kernels live here; the shipped path for EfficientNet-B0's shapes (TF-"same" padding of even inputs)
+// is the row-uniform family dw_rowu_* further down.  The register-blocked kernels (dw_*_blk*, round 1) and the generic
+// per-pixel ones remain as the fallback for other paddings / odd inputs and behind FM_DW_ROWU=0 / FM_DW_GENERIC=1.
+// FM_DW_BRANCHFREE=1 (compile time) builds the register-blocked kernels with address clamp + select (ld4z) and fenced
+// rows instead of predicated loads: measured, with the VGPR cap needed for 4 waves per SIMD the 5x5 forms spill
+// (straight-line code lets the scheduler hoist the whole (K+1) x (K+3) window), so it stays off.
 #ifndef FM_DW_BRANCHFREE
 #define FM_DW_BRANCHFREE 0
 #endif
