@@ -305,6 +305,48 @@ def test_bf16_training_reduces_the_loss_like_fp32(eng):
     np.testing.assert_allclose(got[-1], want[-1], rtol=0.05)           # ... and wash out again as the fit converges
 
 
+def test_bf16_vs_fp32_engine_mid_size():
+    """bf16 storage vs the fp32 ENGINE (itself pinned on the oracle at this size by
+    tests/test_effnet_gpu.py::test_stage1_step_mid_size_224) on a stage-1 step at 224 x 224 with 16 images per view:
+    the multi-row-group statistics / reducer-split / multi-block shapes of the benchmark in bf16.  Loss within 5e-3,
+    per-tensor gradient cosine median > 0.99 and > 0.9 everywhere (analytically-zero `_bn2.bias` tensors excluded as in
+    _grad_report)."""
+    from fedmlp_amd.engine import Engine
+    B, hw = 16, 224
+    g = torch.Generator().manual_seed(4242)
+    x1 = torch.randn((B, 3, hw, hw), generator=g); x2 = torch.randn((B, 3, hw, hw), generator=g)
+    y = (torch.rand((B, C_), generator=g) < 0.3).float()
+    mask = [0.0, 1.0, 0.0, 0.0, 0.0]
+    out = {}
+    for prec in ("fp32", "bf16"):
+        e = Engine("Efficient_b0", C_, hw, hw, 4 * B, precision=prec)
+        try:
+            e.stochastic = False
+            _load(e)
+            e.teacher_snapshot()
+            lo = torch.zeros(1, device=e.device)
+            e.step_stage1(x1.to(e.device), x2.to(e.device), y.to(e.device), mask, 1, B, lo)
+            out[prec] = (lo.item(), spec.flat_to_state_dict("Efficient_b0", C_, e.debug_get_grads(), np.zeros(e.ni, np.int64)))
+        finally:
+            e.close()
+    (l32, g32), (l16, g16) = out["fp32"], out["bf16"]
+    assert abs(l16 - l32) < 5e-3 * abs(l32), (l16, l32)
+    typ = float(np.median([np.abs(v).max() for v in g32.values() if v.dtype.kind == "f" and v.size]))
+    cos = {}
+    for k, want in g32.items():
+        if want.dtype.kind != "f" or want.size == 0:
+            continue
+        want, got = want.ravel(), g16[k].ravel()
+        if np.abs(want).max() < 1e-3 * typ:
+            continue
+        den = np.linalg.norm(got) * np.linalg.norm(want)
+        cos[k] = float(np.dot(got, want) / den) if den > 0 else 1.0
+    REPORT["mid_size_224"] = {"loss_fp32": l32, "loss_bf16": l16, "median_cosine": float(np.median(list(cos.values()))),
+                              "lowest_cosines": {k: cos[k] for k in sorted(cos, key=cos.get)[:5]}}
+    _dump()
+    assert np.median(list(cos.values())) > 0.99 and min(cos.values()) > 0.9, REPORT["mid_size_224"]
+
+
 def test_bf16_224_eval_and_step_are_finite_and_close(eng):
     from fedmlp_amd.engine import Engine
     e = Engine("Efficient_b0", C_, 224, 224, 8, precision="bf16")

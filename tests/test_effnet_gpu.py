@@ -385,6 +385,40 @@ def test_step_odd_spatial_sizes(hw, views):
         e.close()
 
 
+def test_stage1_step_mid_size_224(tmp_path):
+    """A stage-1 step at 224 x 224 with 16 images per view (32 train-mode + 32 teacher images): large enough that the
+    depthwise kernels' fused BN statistics run with many row groups per statistics group, several reducer splits and
+    multi-block squeeze-excite / pointwise launches -- the shapes of the benchmark, not of the 3-image tests.  fp32 engine
+    vs the fp32 oracle at the step bounds."""
+    from fedmlp_amd.engine import Engine
+    B, hw = 16, 224
+    e = Engine(M, C_, hw, hw, 4 * B)
+    try:
+        e.stochastic = False
+        net = _load(e)
+        g = torch.Generator().manual_seed(4242)
+        x1 = torch.randn((B, 3, hw, hw), generator=g); x2 = torch.randn((B, 3, hw, hw), generator=g)
+        y = (torch.rand((B, C_), generator=g) < 0.3).float()
+        glob = copy.deepcopy(net).eval()
+        e.teacher_snapshot()
+        act, neg = [1], [0, 2, 3, 4]
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
+        _, z1 = net(x1); _, z2 = net(x2)
+        with torch.no_grad():
+            _, g1 = glob(x1); _, g2 = glob(x2)
+        loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, B, 1)
+        opt.zero_grad(); loss.backward(); opt.step()
+        mask = [1.0 if c in act else 0.0 for c in range(C_)]
+        lo = torch.zeros(1, device="cuda")
+        e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, B, lo)
+        assert abs(lo.item() - loss.item()) < 5e-5 * abs(loss.item()) + 1e-7
+        _cmp_grads(e, net)
+        _cmp_state(e, net, atol_w=2.5 * LR)
+    finally:
+        e.close()
+
+
 def test_step_is_run_to_run_deterministic(eng):
     (x,), y = _data(6, 42)
     outs = []
