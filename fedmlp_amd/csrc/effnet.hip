@@ -1958,7 +1958,7 @@ void k_chan_pool(const void* a, const void* b, int dt, float* part, int imgs, in
 
 // ------------------------------------------------------------ squeeze-excite ---
 // one block per image: s = mean_hw(a) (from chan_pool partials [img][nch][C]); r_pre = W1 s + b1;
-// g = sigmoid(W2 swish(r_pre) + b2).  W1 [Cs][C], W2 [C][Cs].  Stores s [imgs][C], r_pre [imgs][Cs], g [imgs][C].
+// g = sigmoid(W2 swish(r_pre) + b2).  W1 [Cs][C], W2 stored transposed [Cs][C] (lanes = channels: coalesced).  Stores s [imgs][C], r_pre [imgs][Cs], g [imgs][C].
 __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const float* __restrict__ W1,
                               const float* __restrict__ b1, const float* __restrict__ W2,
                               const float* __restrict__ b2, float* __restrict__ sq, float* __restrict__ rpre,
@@ -1991,7 +1991,7 @@ __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const flo
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float t = b2[c];
-        for (int j = 0; j < Cs; ++j) t += W2[(size_t)c * Cs + j] * r_[j];
+        for (int j = 0; j < Cs; ++j) t += W2[(size_t)j * C + c] * r_[j];
         gate[(size_t)img * C + c] = sigm(t);
     }
 }
@@ -2065,7 +2065,7 @@ __global__ void se_bwd_kernel(const float* __restrict__ pool, int nch, int pstri
     __syncthreads();
     for (int j = wave; j < Cs; j += 4) {
         float t = 0.f;
-        for (int c = lane; c < C; c += 64) t += W2[(size_t)c * Cs + j] * g_[c];
+        for (int c = lane; c < C; c += 64) t += W2[(size_t)j * C + c] * g_[c];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
         if (lane == 0) {
@@ -2226,11 +2226,11 @@ void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, c
                        ds, bn_part, HW, C, ipg);
 }
 
-// dW2[c][j] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]
+// dW2^T[j][c] = sum_img dgp[img][c]*swish(rpre[img][j]); db2[c]; dW1[j][c] = sum_img drp[img][j]*s[img][c]; db1[j]
 // Block = 64 channels x 4 lanes of squeezed channels j, one of SE_SPLITS image ranges; the per-image squeezed vectors
 // (swish(rpre), drp) of 16 images at a time sit in LDS (a wave reads one address: broadcast), the per-channel operands are
 // coalesced 256-B rows.  Each split writes a slab laid out like the four gradient tensors themselves
-// ([cs][C] | b1 padded to 4 | [C][cs] | [C]: they are contiguous in the arena), summed by k_reduce_slabs in a fixed order.
+// ([cs][C] | b1 padded to 4 | [cs][C] (W2 is stored transposed) | [C]: they are contiguous in the arena), summed by k_reduce_slabs in a fixed order.
 // (The earlier form -- 16 lanes per (c, j) pair striding over the images -- took 143 us per block, 2.3 ms per step.)
 constexpr int SE_SPLITS = 16, SE_TI = 16, SE_NJ = 12;          // squeezed channels <= 48
 __global__ __launch_bounds__(256) void se_wgrad_part_kernel(const float* __restrict__ dgp, const float* __restrict__ drp,
@@ -2280,7 +2280,7 @@ __global__ __launch_bounds__(256) void se_wgrad_part_kernel(const float* __restr
         for (int k = 0; k < SE_NJ; ++k) {
             const int j = jl + 4 * k;
             if (j < Cs) {
-                slab[o_w2 + (size_t)c * Cs + j] = acc2[k];
+                slab[o_w2 + (size_t)j * C + c] = acc2[k];
                 slab[(size_t)j * C + c] = acc1[k];
             }
         }

@@ -490,7 +490,9 @@ int build_effnet_b0(fm_engine* e)
         push_bn(m.bn1);
         e->entries.push_back({0, -1, m.w1_off, (size_t)m.cs * m.ce, -1, m.cs, m.ce, 1, 1, 1, m.ce_p});
         e->entries.push_back({1, -1, m.b1_off, (size_t)m.cs, -1});
-        e->entries.push_back({1, -1, m.w2_off, (size_t)m.ce * m.cs, -1});     // [ce][cs]: rows past ce stay 0
+        // _se_expand.weight [ce][cs][1][1] is kept TRANSPOSED, [cs][ce_p] like W1 (every squeeze-excite kernel then reads both
+        // matrices with the channel index on the lanes): an "OIHW" view O = 1, I = ce, H = cs, W = 1 -> [1][cs][1][ce_p]
+        e->entries.push_back({0, -1, m.w2_off, (size_t)m.ce * m.cs, -1, 1, m.ce, m.cs, 1, 1, m.ce_p});
         e->entries.push_back({1, -1, m.b2_off, (size_t)m.ce, -1});
         push_conv(m.c_proj); push_bn(m.bn2);
     }
