@@ -94,6 +94,9 @@ struct MBConv {               // EfficientNet block (efficientnet-pytorch MBConv
     size_t dw_off, w1_off, b1_off, w2_off, b2_off;
     float *a_e = nullptr, *y_d = nullptr, *a_s = nullptr, *out = nullptr;
     float *sq = nullptr, *rpre = nullptr, *gate = nullptr;
+    // second set for the teacher's eval forward when it runs on the side stream next to the student's train forward
+    float *t_a_e = nullptr, *t_y_d = nullptr, *t_a_s = nullptr, *t_out = nullptr;
+    float *t_sq = nullptr, *t_rpre = nullptr, *t_gate = nullptr;
 };
 
 struct StateEntry {           // one state_dict entry, in reference key order
@@ -187,6 +190,12 @@ struct fm_engine {
     int n_cast_jobs = 0, n_cast_blocks = 0;
     bool wb_dirty = true, twb_dirty = true;
     bool fuse_gate = false;           // squeeze-excite gate applied on the project conv's operand load (a_s never stored)
+    // stage-1 steps of EfficientNet-B0: the frozen teacher's forward is independent of the student's until the loss, so it is
+    // enqueued on a side stream with its own activation / workspace set (FM_SIDE_TEACHER=0: one stream, shared buffers)
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_in = nullptr, ev_t = nullptr;
+    bool side_ok = false;
+    float *t_a0 = nullptr, *t_Tmid = nullptr, *t_se_pool = nullptr, *t_rec = nullptr;
     float* stem_col = nullptr;        // bf16 mode: [images][hout][wout][k][4][4] bf16 im2col of the input (the stem's X operand)
 };
 
@@ -562,6 +571,26 @@ int alloc_workspaces(fm_engine* e)
         AALLOC(e->T_small, t_small); AALLOC(e->T_mid, t_mid); AALLOC(e->T_big, t_big);
         DALLOC(e->se_dgp, B * max_ce); DALLOC(e->se_drp, B * max_cs); DALLOC(e->se_ds, B * max_ce);
         DALLOC(e->se_pool, B * 16 * 5 * max_ce);       // [imgs][<=16 chunks][5 sums][C]
+        {
+            const int side = getenv("FM_SIDE_TEACHER") ? atoi(getenv("FM_SIDE_TEACHER")) : 1;     // read per engine
+            if (side) {
+                for (auto& m : e->mbs) {
+                    const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
+                    if (m.c_exp >= 0) AALLOC(m.t_a_e, nin * m.ce_p);
+                    AALLOC(m.t_y_d, nout * m.ce_p); AALLOC(m.t_a_s, nout * m.ce_p);
+                    AALLOC(m.t_out, nout * m.cout_p);
+                    DALLOC(m.t_sq, B * m.ce_p); DALLOC(m.t_rpre, B * m.cs); DALLOC(m.t_gate, B * m.ce_p);
+                }
+                AALLOC(e->t_a0, B * c0.hout * c0.wout * c0.cout_p);
+                AALLOC(e->t_Tmid, t_mid);
+                DALLOC(e->t_se_pool, B * 16 * max_ce);
+                DALLOC(e->t_rec, (size_t)16 << 20);           // pooling records of the eval depthwise forward (<= 33 MB)
+                HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&e->ev_t, hipEventDisableTiming));
+                e->side_ok = true;
+            }
+        }
         DALLOC(e->hfeat, B * e->D);
     }
     DALLOC(e->ws_stats, max_stats);
@@ -1189,6 +1218,30 @@ void net_forward_eval(fm_engine* e, bool teacher, int imgs)
     if (e->model == 1) eff_forward_eval(e, S, evs, evh, dirty, imgs, feat, logits);
     else forward_eval(e, S, evs, evh, dirty, imgs, feat, logits);
 }
+// teacher forward on the side stream: same code, the teacher's buffer set and stream swapped in while it is enqueued
+void swap_teacher_ws(fm_engine* e)
+{
+    for (auto& m : e->mbs) {
+        std::swap(m.a_e, m.t_a_e); std::swap(m.y_d, m.t_y_d); std::swap(m.a_s, m.t_a_s); std::swap(m.out, m.t_out);
+        std::swap(m.sq, m.t_sq); std::swap(m.rpre, m.t_rpre); std::swap(m.gate, m.t_gate);
+    }
+    std::swap(e->a0, e->t_a0); std::swap(e->T_mid, e->t_Tmid); std::swap(e->se_pool, e->t_se_pool);
+    std::swap(e->ws_slab, e->t_rec);
+}
+int teacher_forward_side(fm_engine* e, int imgs)
+{
+    ensure_teacher_shadow(e);                                   // weight shadows on the main stream, before the fork
+    HIPCHK(hipEventRecord(e->ev_in, e->st));
+    HIPCHK(hipStreamWaitEvent(e->st2, e->ev_in, 0));
+    hipStream_t main_st = e->st;
+    e->st = e->st2;
+    swap_teacher_ws(e);
+    net_forward_eval(e, true, imgs);
+    swap_teacher_ws(e);
+    e->st = main_st;
+    HIPCHK(hipEventRecord(e->ev_t, e->st2));
+    return FM_OK;
+}
 void net_backward_and_step(fm_engine* e, int groups, int B)
 {
     ensure_packed(e);
@@ -1238,6 +1291,9 @@ int fm_destroy(fm_engine* e)
 {
     if (!e) return FM_OK;
     (void)hipStreamSynchronize(e->st);
+    if (e->st2) { (void)hipStreamSynchronize(e->st2); (void)hipStreamDestroy(e->st2); }
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_t) (void)hipEventDestroy(e->ev_t);
     if (e->comm) { (void)fmcomm_destroy(e->comm); e->comm = nullptr; }
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& p : e->evs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1499,9 +1555,17 @@ int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const
     for (int c = 0; c < e->C; ++c) n_neg += active_mask_host[c] == 0.f;
     const float* xs[2] = {x1_dev, x2_dev};
     to_nhwc4(e, xs, 2, B);
-    // frozen teacher first (eval mode; its activations may be overwritten by the student)
-    net_forward_eval(e, true, 2 * B);
-    net_forward_train(e, 2, B);
+    if (e->side_ok && e->model == 1) {
+        // frozen teacher on the side stream (own buffers), student on the main stream; they meet at the loss
+        const int rc = teacher_forward_side(e, 2 * B);
+        if (rc != FM_OK) return rc;
+        net_forward_train(e, 2, B);
+        HIPCHK(hipStreamWaitEvent(e->st, e->ev_t, 0));
+    } else {
+        // frozen teacher first (eval mode; its activations may be overwritten by the student)
+        net_forward_eval(e, true, 2 * B);
+        net_forward_train(e, 2, B);
+    }
     k_loss_stage1(e->logits, e->tlogits, y_dev, to_cv(active_mask_host, e->C), B, e->C,
                   1.f / ((float)bs_norm * (float)annotation_num),
                   n_neg ? 1.f / ((float)bs_norm * (float)n_neg) : 0.f, e->dlogits, loss_dev, e->st);

@@ -433,6 +433,33 @@ def test_step_is_run_to_run_deterministic(eng):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
 
 
+def test_stage1_two_stream_step_is_deterministic_and_equals_one_stream(monkeypatch):
+    """Stage-1 steps enqueue the frozen teacher's forward on a side stream with its own buffers next to the student's
+    train forward.  Three steps twice from the same state must agree bit for bit (no race between the streams), and with
+    the one-stream order (FM_SIDE_TEACHER=0, shared buffers) as well: the arithmetic is the same."""
+    from fedmlp_amd.engine import Engine
+    (x1, x2), y = _data(6, 43, views=2)
+    mask = [0.0, 1.0, 0.0, 0.0, 0.0]
+    outs = []
+    for side in ("1", "1", "0"):
+        monkeypatch.setenv("FM_SIDE_TEACHER", side)
+        e = Engine(M, C_, HW, HW, 16)
+        try:
+            e.stochastic = False
+            _load(e)
+            e.teacher_snapshot()
+            lo = torch.zeros(3, device="cuda")
+            for s_ in range(3):
+                e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo[s_:s_ + 1])
+            flat, _ = e.get_state()
+            outs.append((flat.copy(), lo.cpu().numpy().copy()))
+        finally:
+            e.close()
+    for k in (1, 2):
+        np.testing.assert_array_equal(outs[0][1], outs[k][1])
+        np.testing.assert_array_equal(outs[0][0], outs[k][0])
+
+
 def test_build_model_call_surface():
     """net = build_model(args); net.eval(); feature, logits = net(x) -- the eval-mode call of
     utils/evaluations.py:25 -- for --model Efficient_b0 (feature width 1280)."""
