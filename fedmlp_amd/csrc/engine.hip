@@ -83,6 +83,7 @@ struct Block {
     int c1, c2, ds;
     float* z1 = nullptr;
     float* out = nullptr;
+    float *t_z1 = nullptr, *t_out = nullptr, *t_dsy = nullptr;     // the side-stream teacher's set (see fm_engine::st2)
 };
 
 struct MBConv {               // EfficientNet block (efficientnet-pytorch MBConvBlock)
@@ -196,6 +197,9 @@ struct fm_engine {
     hipEvent_t ev_in = nullptr, ev_t = nullptr;
     bool side_ok = false;
     float *t_a0 = nullptr, *t_Tmid = nullptr, *t_se_pool = nullptr, *t_rec = nullptr;
+    float *t_c0y = nullptr, *t_p0 = nullptr;                        // ResNet-18: stem output / pooled stem of the teacher
+    float* sk_slab2 = nullptr;                                       // stream-K fix-up workspace of igemm launches on st2
+    int* sk_counters2 = nullptr;
     float* stem_col = nullptr;        // bf16 mode: [images][hout][wout][k][4][4] bf16 im2col of the input (the stem's X operand)
 };
 
@@ -606,6 +610,34 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);   // [blocks][2][BM*BN]
     DALLOC(e->sk_counters, (size_t)1 << 20);
     HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
+    {
+        const int side = getenv("FM_SIDE_TEACHER") ? atoi(getenv("FM_SIDE_TEACHER")) : 1;     // read per engine
+        if (side) {
+            DALLOC(e->sk_slab2, (size_t)igemm_max_blocks() * 2 * 16384);
+            DALLOC(e->sk_counters2, (size_t)1 << 20);
+            HIPCHK(hipMemset(e->sk_counters2, 0, ((size_t)1 << 20) * 4));
+            // ResNet-18 (MFMA-bound, persistent 512-block kernels): measured 40.70 -> 39.54 ms per stage-1 step with the teacher
+            // on the side stream, but co-running kernels stretch each other's launch windows, so the per-kernel HIP-event /
+            // rocprof durations behind bench.py's roofline line stop describing a kernel alone (0.716 -> 0.49 for the same
+            // code).  Default: EfficientNet only (its roofline is the whole step); FM_SIDE_TEACHER=2 turns it on here too.
+            if (e->model == 0 && side >= 2) {
+                const Conv& c0 = e->convs[0];
+                const size_t pooled = B * (c0.hout / 2) * (c0.wout / 2) * 64;
+                DALLOC(e->t_c0y, B * c0.hout * c0.wout * c0.cout_p);
+                DALLOC(e->t_p0, pooled);
+                for (auto& blk : e->blocks) {
+                    const Conv& c = e->convs[blk.c1];
+                    const size_t n = B * c.hout * c.wout * c.cout;
+                    DALLOC(blk.t_z1, n); DALLOC(blk.t_out, n);
+                    if (blk.ds >= 0) DALLOC(blk.t_dsy, n);
+                }
+                HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&e->ev_t, hipEventDisableTiming));
+                e->side_ok = true;
+            }
+        }
+    }
     HIPCHK(hipMemset(e->zeros, 0, 64 * 4));
     return FM_OK;
 }
@@ -1225,6 +1257,15 @@ void swap_teacher_ws(fm_engine* e)
         std::swap(m.a_e, m.t_a_e); std::swap(m.y_d, m.t_y_d); std::swap(m.a_s, m.t_a_s); std::swap(m.out, m.t_out);
         std::swap(m.sq, m.t_sq); std::swap(m.rpre, m.t_rpre); std::swap(m.gate, m.t_gate);
     }
+    std::swap(e->sk_slab, e->sk_slab2); std::swap(e->sk_counters, e->sk_counters2);
+    if (e->model == 0) {
+        std::swap(e->convs[0].y, e->t_c0y); std::swap(e->p0, e->t_p0);
+        for (auto& blk : e->blocks) {
+            std::swap(blk.z1, blk.t_z1); std::swap(blk.out, blk.t_out);
+            if (blk.ds >= 0) std::swap(e->convs[blk.ds].y, blk.t_dsy);
+        }
+        return;
+    }
     std::swap(e->a0, e->t_a0); std::swap(e->T_mid, e->t_Tmid); std::swap(e->se_pool, e->t_se_pool);
     std::swap(e->ws_slab, e->t_rec);
 }
@@ -1555,7 +1596,7 @@ int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const
     for (int c = 0; c < e->C; ++c) n_neg += active_mask_host[c] == 0.f;
     const float* xs[2] = {x1_dev, x2_dev};
     to_nhwc4(e, xs, 2, B);
-    if (e->side_ok && e->model == 1) {
+    if (e->side_ok) {
         // frozen teacher on the side stream (own buffers), student on the main stream; they meet at the loss
         const int rc = teacher_forward_side(e, 2 * B);
         if (rc != FM_OK) return rc;

@@ -298,3 +298,28 @@ def test_step_is_run_to_run_deterministic(eng):
         outs.append((flat.copy(), lo.item()))
     assert outs[0][1] == outs[1][1]
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
+
+
+def test_stage1_two_stream_teacher_equals_one_stream(monkeypatch):
+    """FM_SIDE_TEACHER=2 runs ResNet-18's frozen-teacher forward on a side stream (own activations and stream-K workspace)
+    next to the student's train forward; the default keeps one stream.  Both orders must give the same bits, twice."""
+    from fedmlp_amd.engine import Engine
+    (x1, x2), y = _data(6, 44, views=2)
+    mask = [0.0, 1.0, 0.0, 0.0, 0.0]
+    outs = []
+    for side in ("2", "2", "0"):
+        monkeypatch.setenv("FM_SIDE_TEACHER", side)
+        e = Engine("Resnet18", C_, HW, HW, 16)
+        try:
+            _load(e)
+            e.teacher_snapshot()
+            lo = torch.zeros(3, device="cuda")
+            for s_ in range(3):
+                e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo[s_:s_ + 1])
+            flat, _ = e.get_state()
+            outs.append((flat.copy(), lo.cpu().numpy().copy()))
+        finally:
+            e.close()
+    for k in (1, 2):
+        np.testing.assert_array_equal(outs[0][1], outs[k][1])
+        np.testing.assert_array_equal(outs[0][0], outs[k][0])
