@@ -198,6 +198,11 @@ struct fm_engine {
     bool side_ok = false;
     float *t_a0 = nullptr, *t_Tmid = nullptr, *t_se_pool = nullptr, *t_rec = nullptr;
     float *t_c0y = nullptr, *t_p0 = nullptr;                        // ResNet-18: stem output / pooled stem of the teacher
+    // EfficientNet backward: the weight gradients of the 1x1 and depthwise convs run on the side stream next to the
+    // data-gradient chain; the gradient tensors they read are double-buffered by block parity (FM_SIDE_WGRAD=0: inline)
+    bool side_w = false;
+    float *T_small2 = nullptr, *T_mid2 = nullptr, *T_big2 = nullptr, *ws_slab2 = nullptr;
+    hipEvent_t ev_p[3][2] = {}, ev_c[3][2] = {}, ev_wdone = nullptr;
     float* sk_slab2 = nullptr;                                       // stream-K fix-up workspace of igemm launches on st2
     int* sk_counters2 = nullptr;
     float* stem_col = nullptr;        // bf16 mode: [images][hout][wout][k][4][4] bf16 im2col of the input (the stem's X operand)
@@ -593,6 +598,17 @@ int alloc_workspaces(fm_engine* e)
                 HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&e->ev_t, hipEventDisableTiming));
                 e->side_ok = true;
+                const int sidew = getenv("FM_SIDE_WGRAD") ? atoi(getenv("FM_SIDE_WGRAD")) : 1;
+                if (sidew) {
+                    AALLOC(e->T_small2, t_small); AALLOC(e->T_mid2, t_mid); AALLOC(e->T_big2, t_big);
+                    for (int k = 0; k < 3; ++k)
+                        for (int q = 0; q < 2; ++q) {
+                            HIPCHK(hipEventCreateWithFlags(&e->ev_p[k][q], hipEventDisableTiming));
+                            HIPCHK(hipEventCreateWithFlags(&e->ev_c[k][q], hipEventDisableTiming));
+                        }
+                    HIPCHK(hipEventCreateWithFlags(&e->ev_wdone, hipEventDisableTiming));
+                    e->side_w = true;          // ws_slab2 is allocated with ws_slab below
+                }
             }
         }
         DALLOC(e->hfeat, B * e->D);
@@ -601,6 +617,7 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->ws_part, (size_t)2 * (1024 + 32) * 2 * e->maxC);   // per-block partials + folded partials
     e->slab_floats = std::max<size_t>(max_slab * 8, (size_t)48 << 20);   // >= 192 MB of partial slabs
     DALLOC(e->ws_slab, e->slab_floats);
+    if (e->side_w) DALLOC(e->ws_slab2, e->slab_floats);
     DALLOC(e->ca, 2 * e->maxC); DALLOC(e->cb, 2 * e->maxC); DALLOC(e->cc, 2 * e->maxC);
     DALLOC(e->feat, B * e->D); DALLOC(e->tfeat, B * e->D);
     DALLOC(e->logits, B * e->C); DALLOC(e->tlogits, B * e->C); DALLOC(e->dlogits, B * e->C);
@@ -1172,6 +1189,30 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     Conv& ch = e->convs[e->c_head];
     const int HWh = ch.hout * ch.wout;
     const float* h = e->drop_dev ? e->hfeat : e->feat;
+    // Weight gradients on the side stream (side_w): each reads a gradient tensor the data-gradient chain has just produced
+    // -- T_small (d y_p) for the project conv, T_mid (d y_d) for the depthwise conv, T_big (d y_e) for the expand conv --
+    // and nothing downstream waits for it before Adam.  The three tensors are double-buffered by block parity; "produced"
+    // events release the side stream, "consumed" events guard the overwrite two blocks later; the side stream has its own
+    // slab workspace.  Arithmetic and summation orders are those of the inline order: results are bit-identical.
+    const bool sw = e->side_w;
+    float* Tsm[2] = {e->T_small, sw ? e->T_small2 : e->T_small};
+    float* Tmd[2] = {e->T_mid, sw ? e->T_mid2 : e->T_mid};
+    float* Tbg[2] = {e->T_big, sw ? e->T_big2 : e->T_big};
+    hipStream_t main_st = e->st;
+    auto side_begin = [&](int k, int par) {          // main has produced tensor k of parity par
+        if (!sw) return;
+        (void)hipEventRecord(e->ev_p[k][par], main_st);
+        (void)hipStreamWaitEvent(e->st2, e->ev_p[k][par], 0);
+        e->st = e->st2;
+        std::swap(e->ws_slab, e->ws_slab2);
+    };
+    auto side_end = [&](int k, int par) {
+        if (!sw) return;
+        std::swap(e->ws_slab, e->ws_slab2);
+        (void)hipEventRecord(e->ev_c[k][par], e->st2);
+        e->st = main_st;
+    };
+    auto guard = [&](int k, int par) { if (sw) (void)hipStreamWaitEvent(main_st, e->ev_c[k][par], 0); };
     e->ctx = 500;
     { OP("k_fc_bwd"); k_fc_bwd(e->dlogits, h, S + e->off_fcw, e->drop_dev, G + e->off_fcw, G + e->off_fcb, e->T_mid, e->dt, imgs, e->D, e->C,
              HWh, e->st); }
@@ -1182,42 +1223,53 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     for (int i = (int)e->mbs.size() - 1; i >= 0; --i) {
         MBConv& m = e->mbs[i];
         e->ctx = 400 + i;                          // backward ops @400..@415 (head @500, stem @399)
+        const int par = i & 1;
+        float *T_small = Tsm[par], *T_mid = Tmd[par], *T_big = Tbg[par];
         const float* in = i == 0 ? e->a0 : e->mbs[i - 1].out;
         const int HWi = m.hin * m.win, HWo = m.hout * m.wout;
         Conv& cp = e->convs[m.c_proj];
         const float* dc = (m.skip && e->dc_dev) ? e->dc_dev + (size_t)i * imgs : nullptr;
         // out = bn2(y_p)*dc + in
-        { OP("bnact_bwd"); bnact_bwd(e, m.bn2, go, cp.y, e->T_small, dc, groups, B * HWo, HWo, 0); }
+        guard(0, par);
+        { OP("bnact_bwd"); bnact_bwd(e, m.bn2, go, cp.y, T_small, dc, groups, B * HWo, HWo, 0); }
         Bn& b1 = e->bns[m.bn1];
+        side_begin(0, par);
         if (fuse_for(e, m)) {      // the project conv's operand a_s was never stored: re-formed from y_d on load
             const Prologue pro{b1.scale, b1.shift, m.gate};
-            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.y_d, e->T_small, imgs, &pro, B * HWo); }
+            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.y_d, T_small, imgs, &pro, B * HWo); }
         } else
-            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.a_s, e->T_small, imgs); }
-        { OP("proj_dgrad"); conv_dgrad(e, m.c_proj, S, e->T_small, e->T_mid, imgs, nullptr, false); }          // d a_s
+            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.a_s, T_small, imgs); }
+        side_end(0, par);
+        guard(1, par);
+        { OP("proj_dgrad"); conv_dgrad(e, m.c_proj, S, T_small, T_mid, imgs, nullptr, false); }          // d a_s
         // a_s = a_d * gate(a_d)
         // ONE pass over (d a_s, y_d) yields the squeeze-excite backward's pooled sums and the BN1-backward sums
-        { OP("k_se_bwd"); k_se_bwd_bn1(e->T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
+        { OP("k_se_bwd"); k_se_bwd_bn1(T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
                      S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
         { OP("k_se_wgrad"); k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
         // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
-        { OP("bnact_bwd"); bnact_bwd(e, m.bn1, e->T_mid, m.y_d, e->T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
+        { OP("bnact_bwd"); bnact_bwd(e, m.bn1, T_mid, m.y_d, T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
                                      se_bwd_bn1_splits(B)); }   // d y_d
         const float* a_e = m.c_exp >= 0 ? m.a_e : in;
-        { OP("k_dw_wgrad"); k_dw_wgrad(e->T_mid, a_e, e->dt, e->ws_slab, G + m.dw_off, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+        side_begin(1, par);
+        { OP("k_dw_wgrad"); k_dw_wgrad(T_mid, a_e, e->dt, e->ws_slab, G + m.dw_off, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
                    m.pad_t, m.pad_l, e->st); }
+        side_end(1, par);
         if (m.c_exp >= 0) {
             Conv& ce = e->convs[m.c_exp];
             Bn& b0 = e->bns[m.bn0];
             bool sums;                           // d a_e, and the BN0-backward sums from the same registers
-            { OP("k_dw_dgrad"); sums = k_dw_dgrad(e->T_mid, S + m.dw_off, e->T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
+            guard(2, par);
+            { OP("k_dw_dgrad"); sums = k_dw_dgrad(T_mid, S + m.dw_off, T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
                        m.pad_t, m.pad_l, e->st, ce.y, b0.mean, b0.istd, b0.scale, b0.shift, e->ws_slab, e->ws_part, groups); }
-            { OP("bnact_bwd"); bnact_bwd(e, m.bn0, e->T_big, ce.y, e->T_big, nullptr, groups, B * HWi, HWi, 2, nullptr, nullptr, -1,
+            { OP("bnact_bwd"); bnact_bwd(e, m.bn0, T_big, ce.y, T_big, nullptr, groups, B * HWi, HWi, 2, nullptr, nullptr, -1,
                                          sums ? dw_stats_tiles() : 0); }
-            { OP("exp_wgrad"); conv_wgrad(e, m.c_exp, in, e->T_big, imgs); }
-            { OP("exp_dgrad"); conv_dgrad(e, m.c_exp, S, e->T_big, gi, imgs, m.skip ? go : nullptr, false); }
+            side_begin(2, par);
+            { OP("exp_wgrad"); conv_wgrad(e, m.c_exp, in, T_big, imgs); }
+            side_end(2, par);
+            { OP("exp_dgrad"); conv_dgrad(e, m.c_exp, S, T_big, gi, imgs, m.skip ? go : nullptr, false); }
         } else {
-            { OP("k_dw_dgrad"); k_dw_dgrad(e->T_mid, S + m.dw_off, gi, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
+            { OP("k_dw_dgrad"); k_dw_dgrad(T_mid, S + m.dw_off, gi, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
                        m.pad_l, e->st); }
             if (m.skip) k_add_inplace(gi, go, e->dt, (int64_t)imgs * HWi * m.cin_p, e->st);
         }
@@ -1227,6 +1279,10 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     e->ctx = 399;
     { OP("bnact_bwd"); bnact_bwd(e, e->bn_stem, go, cs.y, go, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2); }
     { OP("conv_wgrad"); conv_wgrad(e, e->c_stem, e->x4, go, imgs); }
+    if (sw) {                                    // every weight gradient is in G before the optimizer reads it
+        (void)hipEventRecord(e->ev_wdone, e->st2);
+        (void)hipStreamWaitEvent(main_st, e->ev_wdone, 0);
+    }
     { OP("adam_step"); adam_step(e); }
 }
 
@@ -1335,6 +1391,12 @@ int fm_destroy(fm_engine* e)
     if (e->st2) { (void)hipStreamSynchronize(e->st2); (void)hipStreamDestroy(e->st2); }
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_t) (void)hipEventDestroy(e->ev_t);
+    for (int k = 0; k < 3; ++k)
+        for (int q = 0; q < 2; ++q) {
+            if (e->ev_p[k][q]) (void)hipEventDestroy(e->ev_p[k][q]);
+            if (e->ev_c[k][q]) (void)hipEventDestroy(e->ev_c[k][q]);
+        }
+    if (e->ev_wdone) (void)hipEventDestroy(e->ev_wdone);
     if (e->comm) { (void)fmcomm_destroy(e->comm); e->comm = nullptr; }
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& p : e->evs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

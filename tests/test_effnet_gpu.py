@@ -435,14 +435,16 @@ def test_step_is_run_to_run_deterministic(eng):
 
 def test_stage1_two_stream_step_is_deterministic_and_equals_one_stream(monkeypatch):
     """Stage-1 steps enqueue the frozen teacher's forward on a side stream with its own buffers next to the student's
-    train forward.  Three steps twice from the same state must agree bit for bit (no race between the streams), and with
-    the one-stream order (FM_SIDE_TEACHER=0, shared buffers) as well: the arithmetic is the same."""
+    train forward, and the backward's weight gradients on the side stream next to the data-gradient chain (gradient
+    tensors double-buffered by block parity).  Three steps twice from the same state must agree bit for bit (no race
+    between the streams), and with the inline / one-stream orders (FM_SIDE_WGRAD=0, FM_SIDE_TEACHER=0) as well."""
     from fedmlp_amd.engine import Engine
     (x1, x2), y = _data(6, 43, views=2)
     mask = [0.0, 1.0, 0.0, 0.0, 0.0]
     outs = []
-    for side in ("1", "1", "0"):
+    for side, sidew in (("1", "1"), ("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("FM_SIDE_TEACHER", side)
+        monkeypatch.setenv("FM_SIDE_WGRAD", sidew)      # weight gradients of the backward on the side stream as well
         e = Engine(M, C_, HW, HW, 16)
         try:
             e.stochastic = False
@@ -455,7 +457,7 @@ def test_stage1_two_stream_step_is_deterministic_and_equals_one_stream(monkeypat
             outs.append((flat.copy(), lo.cpu().numpy().copy()))
         finally:
             e.close()
-    for k in (1, 2):
+    for k in (1, 2, 3):
         np.testing.assert_array_equal(outs[0][1], outs[k][1])
         np.testing.assert_array_equal(outs[0][0], outs[k][0])
 
