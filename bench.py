@@ -140,6 +140,39 @@ def family_traffic(prefix, args):
         return None
 
 
+def two_stream_extra(args, eng, step_fn, B, max_images, dev):
+    """ResNet-18's optional two-stream mode (FM_SIDE_TEACHER=2: frozen teacher + weight gradients on a side stream,
+    bit-identical results), timed on a second engine after the main region.  It is NOT the default -- and not `value` --
+    because co-running MFMA kernels stretch each other's launch windows, so the per-kernel durations behind `roofline`
+    stop describing a kernel alone."""
+    import torch
+    from fedmlp_amd.engine import Engine
+    os.environ["FM_SIDE_TEACHER"] = "2"
+    try:
+        e2 = Engine(args.model, args.classes, args.hw, args.hw, max_images, device=dev)
+    finally:
+        del os.environ["FM_SIDE_TEACHER"]
+    try:
+        flat, cnt = eng.get_state()
+        e2.set_state(flat, cnt)
+        e2.teacher_snapshot()
+        e2.adam_reset(3e-5)
+        n, w = 20, 5
+        for i in range(w):
+            step_fn(i, i, e2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step_fn(i, w + i, e2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        e2.close()
+    return {"env": "FM_SIDE_TEACHER=2", "steps": n, "ms_per_step": round(dt / n * 1e3, 4),
+            "images_per_sec_per_client": round(B * n / dt, 3),
+            "note": "teacher forward and weight gradients on a side stream; same bits as the default one-stream order"}
+
+
 def measured_traffic(kernel_name, args):
     """HBM-side bytes per launch of the dominant kernel.  NOT measured in this run: read from the
     committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate passes over this
@@ -223,17 +256,18 @@ def main():
     feat_out = torch.empty((B, eng.feature_dim), device=dev)
     logit_out = torch.empty((B, C), device=dev)
 
-    def step(i, k):
+    def step(i, k, en=None):
+        en = en or eng
         lo = losses[k:k + 1]
         j = i % npool
         if args.workload == "stage1":
-            eng.step_stage1(x1[j], x2[j], ys[j], mask, 1, B, lo)
+            en.step_stage1(x1[j], x2[j], ys[j], mask, 1, B, lo)
         elif args.workload == "train":
-            eng.step_bce(x1[j], ys[j], [1.0] * C, B, lo)
+            en.step_bce(x1[j], ys[j], [1.0] * C, B, lo)
         elif args.workload == "stage2":
-            eng.step_stage2(x1[j], ys[j], dist_mask[j], lo)
+            en.step_stage2(x1[j], ys[j], dist_mask[j], lo)
         else:
-            eng.forward_eval_into(x1[j], feat_out, logit_out)
+            en.forward_eval_into(x1[j], feat_out, logit_out)
 
     def fedavg():
         if world > 1 and args.workload != "conv_fwd":
@@ -324,6 +358,9 @@ def main():
                           "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3)},
                "roofline": roof,
                "last_loss": float(lv[-1])}
+        if world == 1 and args.model == "Resnet18" and args.workload != "conv_fwd" and not args.no_profile \
+                and os.environ.get("FM_SIDE_TEACHER") is None:
+            out["config"]["two_stream_mode"] = two_stream_extra(args, eng, step, B, views * B, str(dev))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         else:

@@ -202,6 +202,7 @@ struct fm_engine {
     // data-gradient chain; the gradient tensors they read are double-buffered by block parity (FM_SIDE_WGRAD=0: inline)
     bool side_w = false;
     float *T_small2 = nullptr, *T_mid2 = nullptr, *T_big2 = nullptr, *ws_slab2 = nullptr;
+    float *GB2 = nullptr, *GC2 = nullptr, *GD2 = nullptr;           // ResNet-18 (FM_SIDE_TEACHER=2): the same for d y2 / d y_ds / d y1
     hipEvent_t ev_p[3][2] = {}, ev_c[3][2] = {}, ev_wdone = nullptr;
     float* sk_slab2 = nullptr;                                       // stream-K fix-up workspace of igemm launches on st2
     int* sk_counters2 = nullptr;
@@ -652,6 +653,18 @@ int alloc_workspaces(fm_engine* e)
                 HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&e->ev_t, hipEventDisableTiming));
                 e->side_ok = true;
+                const int sidew = getenv("FM_SIDE_WGRAD") ? atoi(getenv("FM_SIDE_WGRAD")) : 1;
+                if (sidew) {
+                    DALLOC(e->GB2, pooled); DALLOC(e->GC2, pooled); DALLOC(e->GD2, pooled);
+                    DALLOC(e->ws_slab2, e->slab_floats);
+                    for (int k = 0; k < 3; ++k)
+                        for (int q = 0; q < 2; ++q) {
+                            HIPCHK(hipEventCreateWithFlags(&e->ev_p[k][q], hipEventDisableTiming));
+                            HIPCHK(hipEventCreateWithFlags(&e->ev_c[k][q], hipEventDisableTiming));
+                        }
+                    HIPCHK(hipEventCreateWithFlags(&e->ev_wdone, hipEventDisableTiming));
+                    e->side_w = true;
+                }
             }
         }
     }
@@ -998,25 +1011,56 @@ void backward_and_step(fm_engine* e, int groups, int B)
     const int imgs = groups * B;
     const float* S = e->state;
     const Conv& cl = e->convs[e->blocks.back().c2];
+    // side_w (FM_SIDE_TEACHER=2): the weight gradients run on the side stream next to the BN-backward / data-gradient chain
+    // (d y2, d y_ds, d y1 double-buffered by block parity, own slab workspace) -- same scheme as eff_backward_and_step
+    const bool sw = e->side_w;
+    float* GBp[2] = {e->GB, sw ? e->GB2 : e->GB};
+    float* GCp[2] = {e->GC, sw ? e->GC2 : e->GC};
+    float* GDp[2] = {e->GD, sw ? e->GD2 : e->GD};
+    hipStream_t main_st = e->st;
+    auto side_begin = [&](int k, int par) {
+        if (!sw) return;
+        (void)hipEventRecord(e->ev_p[k][par], main_st);
+        (void)hipStreamWaitEvent(e->st2, e->ev_p[k][par], 0);
+        e->st = e->st2;
+        std::swap(e->ws_slab, e->ws_slab2);
+    };
+    auto side_end = [&](int k, int par) {
+        if (!sw) return;
+        std::swap(e->ws_slab, e->ws_slab2);
+        (void)hipEventRecord(e->ev_c[k][par], e->st2);
+        e->st = main_st;
+    };
+    auto guard = [&](int k, int par) { if (sw) (void)hipStreamWaitEvent(main_st, e->ev_c[k][par], 0); };
     k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, nullptr, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, DT_F32, imgs,
              512, e->C, cl.hout * cl.wout, e->st);
     float *ga = e->GA, *ge = e->GE;
     for (int b = (int)e->blocks.size() - 1; b >= 0; --b) {
         Block& blk = e->blocks[b];
+        const int par = b & 1;
+        float *GB = GBp[par], *GC = GCp[par], *GD = GDp[par];
         const float* in = b == 0 ? e->p0 : e->blocks[b - 1].out;
         // out = relu(bn2(y2) + identity): masked grad dyh goes to bn2 and to the identity path
-        bn_bwd(e, blk.c2, ga, blk.out, e->GB, ga, groups, B);
-        if (blk.ds >= 0) bn_bwd(e, blk.ds, ga, nullptr, e->GC, nullptr, groups, B);
-        conv_wgrad(e, blk.c2, blk.z1, e->GB, imgs);
-        conv_dgrad(e, blk.c2, S, e->GB, e->GD, imgs, nullptr, false);
-        bn_bwd(e, blk.c1, e->GD, blk.z1, e->GD, nullptr, groups, B);
-        conv_wgrad(e, blk.c1, in, e->GD, imgs);
+        guard(0, par);
+        bn_bwd(e, blk.c2, ga, blk.out, GB, ga, groups, B);
+        if (blk.ds >= 0) { guard(1, par); bn_bwd(e, blk.ds, ga, nullptr, GC, nullptr, groups, B); }
+        side_begin(0, par);
+        conv_wgrad(e, blk.c2, blk.z1, GB, imgs);
+        side_end(0, par);
+        guard(2, par);
+        conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false);
+        bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B);
+        side_begin(2, par);
+        conv_wgrad(e, blk.c1, in, GD, imgs);
+        side_end(2, par);
         if (blk.ds >= 0) {
-            conv_wgrad(e, blk.ds, in, e->GC, imgs);
-            conv_dgrad(e, blk.ds, S, e->GC, ge, imgs, nullptr, false);   // writes parity class (0,0)
-            conv_dgrad(e, blk.c1, S, e->GD, ge, imgs, nullptr, true);    // all classes, (0,0) accumulates
+            side_begin(1, par);
+            conv_wgrad(e, blk.ds, in, GC, imgs);
+            side_end(1, par);
+            conv_dgrad(e, blk.ds, S, GC, ge, imgs, nullptr, false);   // writes parity class (0,0)
+            conv_dgrad(e, blk.c1, S, GD, ge, imgs, nullptr, true);    // all classes, (0,0) accumulates
         } else {
-            conv_dgrad(e, blk.c1, S, e->GD, ge, imgs, ga, false);
+            conv_dgrad(e, blk.c1, S, GD, ge, imgs, ga, false);
         }
         std::swap(ga, ge);
     }
@@ -1024,6 +1068,10 @@ void backward_and_step(fm_engine* e, int groups, int B)
     k_stem_pool_bwd(ga, e->p0, e->idx0, e->dyh0, imgs, c0.hout, c0.wout, 64, e->st);
     bn_bwd(e, 0, e->dyh0, nullptr, e->dyh0, nullptr, groups, B);
     conv_wgrad(e, 0, e->x4, e->dyh0, imgs);
+    if (sw) {
+        (void)hipEventRecord(e->ev_wdone, e->st2);
+        (void)hipStreamWaitEvent(main_st, e->ev_wdone, 0);
+    }
     adam_step(e);      // optimizer.step()
 }
 
