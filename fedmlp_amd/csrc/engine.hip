@@ -203,7 +203,8 @@ struct fm_engine {
     bool side_w = false;
     float *T_small2 = nullptr, *T_mid2 = nullptr, *T_big2 = nullptr, *ws_slab2 = nullptr;
     float *GB2 = nullptr, *GC2 = nullptr, *GD2 = nullptr;           // ResNet-18 (FM_SIDE_TEACHER=2): the same for d y2 / d y_ds / d y1
-    hipEvent_t ev_p[3][2] = {}, ev_c[3][2] = {}, ev_wdone = nullptr;
+    hipEvent_t ev_p[4][2] = {}, ev_c[4][2] = {}, ev_wdone = nullptr;    // [tensor: d y_p, d y_d, d y_e, SE vectors][block parity]
+    float *se_dgp2 = nullptr, *se_drp2 = nullptr;
     float* sk_slab2 = nullptr;                                       // stream-K fix-up workspace of igemm launches on st2
     int* sk_counters2 = nullptr;
     float* stem_col = nullptr;        // bf16 mode: [images][hout][wout][k][4][4] bf16 im2col of the input (the stem's X operand)
@@ -602,7 +603,8 @@ int alloc_workspaces(fm_engine* e)
                 const int sidew = getenv("FM_SIDE_WGRAD") ? atoi(getenv("FM_SIDE_WGRAD")) : 1;
                 if (sidew) {
                     AALLOC(e->T_small2, t_small); AALLOC(e->T_mid2, t_mid); AALLOC(e->T_big2, t_big);
-                    for (int k = 0; k < 3; ++k)
+                    DALLOC(e->se_dgp2, B * max_ce); DALLOC(e->se_drp2, B * max_cs);
+                    for (int k = 0; k < 4; ++k)
                         for (int q = 0; q < 2; ++q) {
                             HIPCHK(hipEventCreateWithFlags(&e->ev_p[k][q], hipEventDisableTiming));
                             HIPCHK(hipEventCreateWithFlags(&e->ev_c[k][q], hipEventDisableTiming));
@@ -657,7 +659,7 @@ int alloc_workspaces(fm_engine* e)
                 if (sidew) {
                     DALLOC(e->GB2, pooled); DALLOC(e->GC2, pooled); DALLOC(e->GD2, pooled);
                     DALLOC(e->ws_slab2, e->slab_floats);
-                    for (int k = 0; k < 3; ++k)
+                    for (int k = 0; k < 4; ++k)
                         for (int q = 0; q < 2; ++q) {
                             HIPCHK(hipEventCreateWithFlags(&e->ev_p[k][q], hipEventDisableTiming));
                             HIPCHK(hipEventCreateWithFlags(&e->ev_c[k][q], hipEventDisableTiming));
@@ -1292,9 +1294,14 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         { OP("proj_dgrad"); conv_dgrad(e, m.c_proj, S, T_small, T_mid, imgs, nullptr, false); }          // d a_s
         // a_s = a_d * gate(a_d)
         // ONE pass over (d a_s, y_d) yields the squeeze-excite backward's pooled sums and the BN1-backward sums
+        float* dgp = (sw && par) ? e->se_dgp2 : e->se_dgp;       // the squeeze-excite gradient vectors alternate too
+        float* drp = (sw && par) ? e->se_drp2 : e->se_drp;
+        guard(3, par);
         { OP("k_se_bwd"); k_se_bwd_bn1(T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
-                     S + m.w1_off, S + m.w2_off, e->se_dgp, e->se_drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
-        { OP("k_se_wgrad"); k_se_wgrad(e->se_dgp, e->se_drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
+                     S + m.w1_off, S + m.w2_off, dgp, drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
+        side_begin(3, par);
+        { OP("k_se_wgrad"); k_se_wgrad(dgp, drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
+        side_end(3, par);
         // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
         { OP("bnact_bwd"); bnact_bwd(e, m.bn1, T_mid, m.y_d, T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
                                      se_bwd_bn1_splits(B)); }   // d y_d
@@ -1439,7 +1446,7 @@ int fm_destroy(fm_engine* e)
     if (e->st2) { (void)hipStreamSynchronize(e->st2); (void)hipStreamDestroy(e->st2); }
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_t) (void)hipEventDestroy(e->ev_t);
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
         for (int q = 0; q < 2; ++q) {
             if (e->ev_p[k][q]) (void)hipEventDestroy(e->ev_p[k][q]);
             if (e->ev_c[k][q]) (void)hipEventDestroy(e->ev_c[k][q]);
