@@ -433,26 +433,29 @@ def test_step_is_run_to_run_deterministic(eng):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
 
 
-def test_stage1_two_stream_step_is_deterministic_and_equals_one_stream(monkeypatch):
+@pytest.mark.parametrize("hw,B", [(64, 6), (224, 16)])
+def test_stage1_two_stream_step_is_deterministic_and_equals_one_stream(monkeypatch, hw, B):
     """Stage-1 steps enqueue the frozen teacher's forward on a side stream with its own buffers next to the student's
     train forward, and the backward's weight gradients on the side stream next to the data-gradient chain (gradient
     tensors double-buffered by block parity).  Three steps twice from the same state must agree bit for bit (no race
     between the streams), and with the inline / one-stream orders (FM_SIDE_WGRAD=0, FM_SIDE_TEACHER=0) as well."""
     from fedmlp_amd.engine import Engine
-    (x1, x2), y = _data(6, 43, views=2)
+    g = torch.Generator().manual_seed(43)
+    x1 = torch.randn((B, 3, hw, hw), generator=g); x2 = torch.randn((B, 3, hw, hw), generator=g)
+    y = (torch.rand((B, C_), generator=g) < 0.3).float()
     mask = [0.0, 1.0, 0.0, 0.0, 0.0]
     outs = []
     for side, sidew in (("1", "1"), ("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("FM_SIDE_TEACHER", side)
         monkeypatch.setenv("FM_SIDE_WGRAD", sidew)      # weight gradients of the backward on the side stream as well
-        e = Engine(M, C_, HW, HW, 16)
+        e = Engine(M, C_, hw, hw, 4 * B)
         try:
             e.stochastic = False
             _load(e)
             e.teacher_snapshot()
             lo = torch.zeros(3, device="cuda")
             for s_ in range(3):
-                e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo[s_:s_ + 1])
+                e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, B, lo[s_:s_ + 1])
             flat, _ = e.get_state()
             outs.append((flat.copy(), lo.cpu().numpy().copy()))
         finally:
