@@ -11,7 +11,7 @@
 //   one batch of 2B images with per-view ("group") BN statistics.
 //   EfficientNet-B0 (model 1): channel counts are padded to multiples of 16 inside the engine
 //   (24->32, 40->48; padded weights/gamma/beta are 0 and stay 0 under Adam, so padded channels
-//   carry exact zeros); depthwise weights are [k*k][C]; squeeze-excite W1 [Cs][C], W2 [C][Cs].
+//   carry exact zeros); depthwise weights are [k*k][C]; squeeze-excite W1 [Cs][C], W2 kept transposed [Cs][C].
 #include <math.h>
 #include <stdio.h>
 #include <string.h>

@@ -95,7 +95,7 @@ int dw_wgrad_blocks(int npix);
 // out [K*K][C] = the weight gradient; part = workspace for the per-block partial sums (reduced inside, fixed order)
 void k_dw_wgrad(const void* dy, const void* x, int dt, float* part, float* out, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                 int stride, int pad_t, int pad_l, hipStream_t s);
-// squeeze-excite: W1 [Cs][C], W2 [C][Cs]
+// squeeze-excite: W1 [Cs][C], W2 stored transposed [Cs][C]
 // pool_ws: [imgs][16][C] scratch for the per-image channel sums
 // scale/shift (optional, [groups][C], ipg images per group): `a` is the raw depthwise output and is read
 // as swish(a*scale+shift) -- the post-BN activation is not materialised in the train path
