@@ -88,6 +88,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # every RNG the flow draws from (batch orders: torch; class draws: random; numpy) is seeded like main.py seeds its
+    # process, offset by the rank: a run is reproducible bit for bit
+    import random
+    random.seed(args.seed + rank); np.random.seed(args.seed + rank)
+    torch.manual_seed(args.seed + rank); torch.cuda.manual_seed_all(args.seed + rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
