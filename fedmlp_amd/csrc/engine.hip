@@ -583,7 +583,19 @@ int alloc_workspaces(fm_engine* e)
         DALLOC(e->se_dgp, B * max_ce); DALLOC(e->se_drp, B * max_cs); DALLOC(e->se_ds, B * max_ce);
         DALLOC(e->se_pool, B * 16 * 5 * max_ce);       // [imgs][<=16 chunks][5 sums][C]
         {
-            const int side = getenv("FM_SIDE_TEACHER") ? atoi(getenv("FM_SIDE_TEACHER")) : 1;     // read per engine
+            int side = getenv("FM_SIDE_TEACHER") ? atoi(getenv("FM_SIDE_TEACHER")) : 1;     // read per engine
+            if (side) {
+                // the second buffer sets roughly double the activation footprint: keep one stream when they would not fit
+                // next to what is still to be allocated (slabs, statistics: < 2 GB) with 4 GB to spare
+                size_t need = 0, free_b = 0, total_b = 0;
+                const size_t es = e->precision ? 2 : 4;
+                for (auto& m : e->mbs) {
+                    const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
+                    need += ((m.c_exp >= 0 ? nin * m.ce_p : 0) + 2 * nout * m.ce_p + nout * m.cout_p) * es;
+                }
+                need += (t_small + 2 * t_mid + t_big) * es + 2 * ((size_t)48 << 22);
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)6 << 30)) side = 0;
+            }
             if (side) {
                 for (auto& m : e->mbs) {
                     const size_t nin = B * m.hin * m.win, nout = B * m.hout * m.wout;
