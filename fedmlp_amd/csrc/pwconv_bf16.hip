@@ -78,10 +78,13 @@ __device__ __forceinline__ int tile_row_to_channel(int r, int i, int npairs)
 // P x 16 pixels x min(K, 32 KB) x 2 B: with P = 2 a K = 16 layer has ONE KB per wave in flight and the whole kernel
 // crawls along its read latency (block 1's expand conv: 2.7 TB/s of a write-dominated 2.9 GB), so small K takes more
 // pixels per iteration (accumulators are AGPRs) instead of more k-chunks.
-template <int RT, bool PRO, int P = 2, int KB = 4>
-__global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
+// NW = waves per block (4, or 8 for the K > 640 layers: the weight slice of a 64-channel M-tile is then 86-147 KB of LDS,
+// one block per CU, and eight waves share it -- half the M-tiles, i.e. half the re-reads of the pixel operand, of the
+// 32-channel tiles two 4-wave blocks would use).
+template <int RT, bool PRO, int P = 2, int KB = 4, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
 {
-    constexpr int MT = 16 * RT, PPI = 16 * P;
+    constexpr int MT = 16 * RT, PPI = 16 * P, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
 
     // ---- stage the weight slice once, in fragment order ------------------------------------------
     const int cpr = K >> 3;                                  // 16-B chunks per weight row
-    for (int idx = tid; idx < MT * cpr; idx += 256) {
+    for (int idx = tid; idx < MT * cpr; idx += NT) {
         const int crel = idx / cpr, c = idx - crel * cpr;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (m0 + crel < p.M) v = *reinterpret_cast<const uint4*>(p.W + (size_t)(m0 + crel) * K + 8 * c);
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
     }
     if constexpr (PRO) {
         if (p.psc)
-            for (int k = tid; k < K; k += 256) {
+            for (int k = tid; k < K; k += NT) {
                 psc_l[k] = p.psc[grp * K + k];
                 psc_l[K + k] = p.psh[grp * K + k];
             }
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
     }
 
     const int n_iter = (pe - pb + PPI - 1) / PPI;
-    for (int it = wave; it < n_iter; it += 4) {
+    for (int it = wave; it < n_iter; it += NW) {
         const int pix0 = pb + it * PPI;
         bool pv[P];
         const bf16* xp[P];
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
     // ---- BN statistics: fold the 16 pixel lanes, then the 4 waves (fixed order) -----------------------
     if (p.stats) {
         __syncthreads();                       // every wave is done with the weight slice: reuse the LDS
-        float* red = reinterpret_cast<float*>(smem);          // [4 waves][MT][2]
+        float* red = reinterpret_cast<float*>(smem);          // [NW waves][MT][2]
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void pw_conv_bf16_kernel(const PwParams p)
         if (tid < 16 * nrt) {
             float u = 0.f, v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 u += red[(w * MT + tid) * 2 + 0];
                 v += red[(w * MT + tid) * 2 + 1];
             }
@@ -578,7 +581,10 @@ __global__ void cast_weights_kernel(const float* __restrict__ state, bf16* __res
 }  // namespace
 
 // ---- launchers ------------------------------------------------------------------------------------------
-static int pw_rt(int K) { return K <= 640 ? 4 : 2; }           // weight slice <= 80 KB of LDS
+// row tiles per block: 4 (64 channels).  K > 640: the slice is 86-147 KB -- one 8-wave block per CU (FM_PW_W8=0: two
+// 4-wave blocks of 32-channel tiles, the round-2 first form)
+static int pw_w8() { static const int v = getenv("FM_PW_W8") ? atoi(getenv("FM_PW_W8")) : 1; return v; }
+static int pw_rt(int K) { return (K <= 640 || (pw_w8() && K <= 1152)) ? 4 : 2; }     // K = 1280 (head dgrad): 164 KB, stays 32-channel
 static int pw_ppb(int npix_per_group, int groups, int M, int K)
 {
     const int MT = 16 * pw_rt(K);
@@ -597,17 +603,18 @@ int pw_blocks(int npix_per_group, int groups, int M, int K)
     return (npix_per_group + ppb - 1) / ppb;
 }
 
-template <int RT, int P, int KB>
+template <int RT, int P, int KB, int NW = 4>
 static void pw_launch_t(const PwParams& p, bool pro, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool attr_done = false;
+    constexpr int cap = NW == 8 ? 156 * 1024 : 96 * 1024;
     if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, false, P, KB>), 96 * 1024, "pw_conv_bf16_kernel");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, true, P, KB>), 96 * 1024, "pw_conv_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, false, P, KB, NW>), cap, "pw_conv_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, true, P, KB, NW>), cap, "pw_conv_bf16_kernel");
         attr_done = true;
     }
-    if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, true, P, KB>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, false, P, KB>), grid, dim3(256), lds, s, p);
+    if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, true, P, KB, NW>), grid, dim3(64 * NW), lds, s, p);
+    else hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, false, P, KB, NW>), grid, dim3(64 * NW), lds, s, p);
 }
 void launch_pw_conv(PwParams p, hipStream_t s)
 {
@@ -617,7 +624,7 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     p.nblk = (p.npix + p.ppb - 1) / p.ppb;
     const bool pro = p.gate != nullptr;
     size_t lds = (size_t)(p.K >> 5) * RT * 1024 + (size_t)RT * 512 + (pro ? (size_t)2 * p.K * 4 : 0);
-    lds = std::max<size_t>(lds, (size_t)4 * MT * 2 * 4);
+    lds = std::max<size_t>(lds, (size_t)8 * MT * 2 * 4);
     static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
     p.tiles_m = (p.M + MT - 1) / MT;
     p.xcd = xcd;
@@ -629,6 +636,7 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     static const int smallk = getenv("FM_PW_SMALLK") ? atoi(getenv("FM_PW_SMALLK")) : 2;
     if (RT == 4 && smallk == 1 && p.K <= 32) pw_launch_t<4, 8, 1>(p, pro, grid, lds, s);
     else if (RT == 4 && smallk && p.K <= 64) pw_launch_t<4, 4, 2>(p, pro, grid, lds, s);
+    else if (RT == 4 && p.K > 640) pw_launch_t<4, 2, 4, 8>(p, pro, grid, lds, s);
     else if (RT == 4) pw_launch_t<4, 2, 4>(p, pro, grid, lds, s);
     else pw_launch_t<2, 2, 4>(p, pro, grid, lds, s);
 }
