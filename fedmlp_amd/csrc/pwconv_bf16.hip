@@ -320,6 +320,7 @@ struct WgArgs {
     const float* psh;
     const float* gate;
     int HW, pix_per_group;
+    int tilesL, nsplit, xcd;   // launch geometry (1-D grid)
 };
 constexpr int WG_STRIDE_BIG = 160;          // 64 channels x 2 B = 128 B of data per pixel row, padded to 32 B x 5
 
@@ -339,8 +340,24 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(const WgArgs p)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int l0 = blockIdx.x * 64;
-    const int split = blockIdx.y, nsplit = gridDim.y;
+    // 1-D grid -> (64-channel tile of Big, pixel split).  The tiles of a split all re-read the split's Small rows: block
+    // ids are arranged so that they are congruent mod 8 = on ONE XCD's L2 (p.xcd; same scheme as pw_conv_bf16_kernel)
+    int tile, split;
+    const int nsplit = p.nsplit;
+    {
+        const int T = p.tilesL, id = blockIdx.x;
+        const int full = p.xcd ? (nsplit >> 3) << 3 : 0;
+        if (id < full * T) {
+            const int q = id >> 3, x = id & 7;
+            split = (q / T) * 8 + x;
+            tile = q - (q / T) * T;
+        } else {
+            const int r = id - full * T;
+            split = full + r / T;
+            tile = r - (r / T) * T;
+        }
+    }
+    const int l0 = tile * 64;
     const int tsteps = (p.npix + 31) >> 5;
     const int nsteps = split < tsteps ? (tsteps - split + nsplit - 1) / nsplit : 0;   // 32-pixel steps dealt round-robin
     const int strideS = p.strideS;
@@ -712,7 +729,9 @@ int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
     splits = std::min(splits, std::max(1, tsteps / 8));
     splits = (int)std::min<size_t>(splits, std::max<size_t>(1, slab_floats / ((size_t)w.M * w.K)));
     const size_t lds = (size_t)2 * (32 * WG_STRIDE_BIG + 32 * a.strideS);
-    const dim3 grid(tilesL, splits);
+    static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
+    a.tilesL = tilesL; a.nsplit = splits; a.xcd = xcd;
+    const dim3 grid(tilesL * splits);
     const bool pro = w.gate != nullptr;
     switch (CCi) {
     case 1: wg_launch<1>(a, pro, grid, lds, s); break;
