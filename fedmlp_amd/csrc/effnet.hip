@@ -719,6 +719,27 @@ template <typename T> __device__ __forceinline__ f32x4 stored_value(f32x4 v)
     if constexpr (sizeof(T) == 2) return __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4);
     else return v;
 }
+// (channel chunk, row group) of this block.  xr > 0: XCD-aware order -- the blocks of xr consecutive row groups (all their
+// channel chunks) get ids congruent mod 8, i.e. ONE XCD: neighbouring row groups share their K-1 halo rows through that
+// L2 instead of fetching them twice.  The grid is padded to whole batches of 8 groups; false = a padding block.
+__device__ __forceinline__ bool rowu_block(int nchunk, int nrg, int xr, int& chunk, int& rg)
+{
+    const int id = blockIdx.x;
+    if (xr <= 0) { chunk = id % nchunk; rg = id / nchunk; return rg < nrg; }
+    const int G = nchunk * xr;
+    const int x = id & 7, q = id >> 3;
+    const int g = (q / G) * 8 + x, within = q - (q / G) * G;
+    rg = g * xr + within / nchunk;
+    chunk = within - (within / nchunk) * nchunk;
+    return rg < nrg;
+}
+static inline int rowu_grid(int nchunk, int nrg, int xr)
+{
+    if (xr <= 0) return nchunk * nrg;
+    const int ngroups = (nrg + xr - 1) / xr;
+    return (ngroups + 7) / 8 * 8 * nchunk * xr;
+}
+static inline int rowu_xr() { static const int v = getenv("FM_DW_XR") ? atoi(getenv("FM_DW_XR")) : 4; return v; }
 // ST = 2 (data gradient of a block with an expand conv): the BN0-backward sums  S1 = sum dz*swish'(v),  S2 = sum dz*swish'(v)*xhat
 // (dz = the gradient this kernel stores, v = y_e*scale+shift, xhat = (y_e-mean)*istd) are taken here as well: y_e is read
 // at the output positions, the separate reduction pass over (dz, y_e) is gone.  bnq = {mean, istd, scale, shift} [groups][C].
@@ -728,7 +749,8 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       int nrp, int H, int W, int C, int act, int flip, int nchunk, int rpb,
                                                       f32x4* __restrict__ rec = nullptr, const T* __restrict__ ye = nullptr,
-                                                      BnQuad bnq = BnQuad{nullptr, nullptr, nullptr, nullptr}, int rp_per_group = 1)
+                                                      BnQuad bnq = BnQuad{nullptr, nullptr, nullptr, nullptr}, int rp_per_group = 1,
+                                                      int xr = 0)
 {
     constexpr int PT = (K - 1) / 2, NIN = K + 3, ES = (int)sizeof(T);
     constexpr bool FAST = VecOf<T>::NV == 2;
@@ -736,7 +758,9 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
     __shared__ f32x4 ws[(K * K + K) * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunk = blockIdx.x % nchunk, rg = blockIdx.x / nchunk;
+    int chunk, rg;
+    if (!rowu_block(nchunk, (nrp + rpb - 1) / rpb, xr, chunk, rg)) return;
+    const int bidx = rg * nchunk + chunk;                      // record slot (independent of the block order)
     const int Q = C >> 2, WB = (W + 3) >> 2, HB = (H + 1) >> 1;
     const int id = chunk * 64 + lane;
     const bool lv = id < WB * Q;
@@ -859,9 +883,9 @@ __global__ __launch_bounds__(256) void dw_rowu_kernel(const T* __restrict__ x, c
         __syncthreads();
         if (wave == 0) {
             constexpr int NR = ST == 3 ? 1 : 2;       // the pooling record holds the sum only
-            rec[((size_t)blockIdx.x * NR + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
+            rec[((size_t)bidx * NR + 0) * 64 + lane] = ((st1 + red[0][0][lane]) + red[1][0][lane]) + red[2][0][lane];
             if constexpr (ST != 3)
-                rec[((size_t)blockIdx.x * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
+                rec[((size_t)bidx * 2 + 1) * 64 + lane] = ((st2 + red[0][1][lane]) + red[1][1][lane]) + red[2][1][lane];
         }
     }
 }
@@ -1109,11 +1133,14 @@ static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
     const int nchunk = (WB * Q + 63) / 64, nrp = imgs * HB;
     static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
     int rpb = std::max(4, rpb_env);
+    const int xr = rowu_xr();
+    const BnQuad nobn{nullptr, nullptr, nullptr, nullptr};
+    const T* noy = nullptr;
     if (st && st->pool) {          // eval: blocks stay inside one image, one record each, summed per image
         rpb = dw_pool_rpb(HB);
         const int gpi = HB / rpb;
-        hipLaunchKernelGGL((dw_rowu_kernel<K, T, 3>), dim3(nchunk * gpi * imgs), dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act,
-                           flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+        hipLaunchKernelGGL((dw_rowu_kernel<K, T, 3>), dim3(rowu_grid(nchunk, gpi * imgs, xr)), dim3(256), 0, s, x, w, y, scale, shift, nrp,
+                           H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec), noy, nobn, 1, xr);
         hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16, 1, imgs), dim3(256), 0, s, reinterpret_cast<const f32x4*>(st->rec),
                            st->pool, 1, Q, WB, nchunk, gpi, 1);
         return true;
@@ -1122,20 +1149,22 @@ static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
         const int nrg_g = dw_stats_rowgroups(nrp / st->groups, nchunk, st->groups);
         if (nrg_g) {
             rpb = nrp / st->groups / nrg_g;
+            const dim3 grid(rowu_grid(nchunk, nrg_g * st->groups, xr));
             if (st->ye)
-                hipLaunchKernelGGL((dw_rowu_kernel<K, T, 2>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale, shift,
-                                   nrp, H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec),
-                                   reinterpret_cast<const T*>(st->ye), st->bnq, nrp / st->groups);
+                hipLaunchKernelGGL((dw_rowu_kernel<K, T, 2>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act, flip, nchunk,
+                                   rpb, reinterpret_cast<f32x4*>(st->rec), reinterpret_cast<const T*>(st->ye), st->bnq,
+                                   nrp / st->groups, xr);
             else
-                hipLaunchKernelGGL((dw_rowu_kernel<K, T, 1>), dim3(nchunk * nrg_g * st->groups), dim3(256), 0, s, x, w, y, scale, shift,
-                                   nrp, H, W, C, act, flip, nchunk, rpb, reinterpret_cast<f32x4*>(st->rec));
+                hipLaunchKernelGGL((dw_rowu_kernel<K, T, 1>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act, flip, nchunk,
+                                   rpb, reinterpret_cast<f32x4*>(st->rec), noy, nobn, 1, xr);
             hipLaunchKernelGGL(dw_rowu_wgrad_reduce, dim3((Q + 15) / 16 * DW_ST_SPLITS, 2, st->groups), dim3(256), 0, s,
                                reinterpret_cast<const f32x4*>(st->rec), st->out, 2, Q, WB, nchunk, nrg_g, DW_ST_SPLITS);
             return true;
         }
     }
-    const dim3 grid(nchunk * ((nrp + rpb - 1) / rpb));
-    hipLaunchKernelGGL((dw_rowu_kernel<K, T>), grid, dim3(256), 0, s, x, w, y, scale, shift, nrp, H, W, C, act, flip, nchunk, rpb);
+    f32x4* norec = nullptr;
+    hipLaunchKernelGGL((dw_rowu_kernel<K, T>), dim3(rowu_grid(nchunk, (nrp + rpb - 1) / rpb, xr)), dim3(256), 0, s, x, w, y, scale, shift,
+                       nrp, H, W, C, act, flip, nchunk, rpb, norec, noy, nobn, 1, xr);
     return false;
 }
 // Measured (bf16, 1024 images, FM_DW_TILE=2 forces the tiled kernel everywhere): it beats the register-blocked kernels
