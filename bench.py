@@ -35,8 +35,8 @@ sys.path.insert(0, ROOT)
 
 # kernel families of fm_profile_read (names as rocprofv3 prints them for the ResNet-18 workload, where every
 # conv has Ci % 32 == 0 and runs the 32-k-stage instantiation)
-KERNEL_NAMES = {0: "igemm_kernel<128,128,2,false,2,32>", 1: "igemm_kernel<64,256,4,false,2,32>",
-                2: "igemm_kernel<64,256,4,true,4,16>", 3: "wgrad_kernel<128,128,2>", 4: "wgrad_kernel<64,256,4>"}
+KERNEL_NAMES = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,256,4,0,2,32>",
+                2: "igemm_kernel<64,256,4,1,4,16>", 3: "wgrad_kernel<128,128,2>", 4: "wgrad_kernel<64,256,4>"}
 NFAM = len(KERNEL_NAMES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
@@ -133,7 +133,8 @@ def family_traffic(prefix, args):
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             doc = json.load(f).get(workload_key(args))
-        ks = [v for k, v in doc["kernels"].items() if prefix in k.replace(" ", "")]
+        ks = [v for k, v in doc["kernels"].items()
+              if prefix in k.replace(" ", "").replace("false", "0").replace("true", "1")]   # (older profiles: bool STEM)
         n = sum(v["launches"] for v in ks)
         return int(sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for v in ks) / n) if n else None
     except Exception:
@@ -185,7 +186,7 @@ def measured_traffic(kernel_name, args):
             return None
         key = kernel_name.replace(" ", "")
         for k, v in doc["kernels"].items():
-            if key in k.replace(" ", ""):
+            if key in k.replace(" ", "").replace("false", "0").replace("true", "1"):     # (older profiles: bool STEM)
                 return v["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass

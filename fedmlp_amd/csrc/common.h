@@ -90,6 +90,8 @@ struct IgemmParams {
     int tn_fast;          // tile order: pixel tiles fastest within an M-tile (weight slice stays in L2)
     int stem_kw, stem_pad;
     int stem_h2;          // 1: kernel width padded to 8 (two 16-k steps per kernel row), 0: padded to 4
+    int stem3;            // 1: packed 7x7 stem -- X is a zero-framed NHWC3 image (Hi, Wi = framed sizes, Ci = 3), K = kernel
+                          // rows of 24 floats (7 taps x 3 channels + 1 zero tap) = 6 chunks each, 16-B chunks at 4-B alignment
     const float* zeros;   // >= 16 B of zeros (source of padded / out-of-range chunks)
     const float* res;     // optional residual, indexed like Y (may alias Y)
     const float* scale;   // optional per-m affine (eval-mode BN folded), else null

@@ -77,8 +77,9 @@ void k_nchw_to_nhwc4(const float* x, float* y, int imgs, int H, int W, hipStream
     hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, n, H * W);
 }
 
+// engine row o starts at o*Ostride (Ostride >= H*Wpad*Ipad; the tail of a row, if any, is padding the caller keeps zero)
 __global__ void oihw_to_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int I, int H,
-                                    int W, int Wpad, int Ipad, int inverse)
+                                    int W, int Wpad, int Ipad, int Ostride, int inverse)
 {
     int64_t n = (int64_t)O * H * Wpad * Ipad;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,18 +91,59 @@ __global__ void oihw_to_ohwi_kernel(const float* __restrict__ src, float* __rest
     int o = t / H;
     const bool real = wp < W && ip < I;
     const int64_t j = (((int64_t)o * I + ip) * H + h) * W + wp;     // OIHW index
-    if (!inverse) dst[i] = real ? src[j] : 0.f;
-    else if (real) dst[j] = src[i];
+    const int64_t d = (int64_t)o * Ostride + ((int64_t)h * Wpad + wp) * Ipad + ip;
+    if (!inverse) dst[d] = real ? src[j] : 0.f;
+    else if (real) dst[j] = src[d];
 }
-void k_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s)
+void k_oihw_to_ohwi(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s, int Ostride)
 {
     int64_t n = (int64_t)O * H * Wpad * Ipad;
-    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, O, I, H, W, Wpad, Ipad, 0);
+    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, O, I, H, W, Wpad, Ipad,
+                       Ostride ? Ostride : H * Wpad * Ipad, 0);
 }
-void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s)
+void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, int Wpad, int Ipad, hipStream_t s, int Ostride)
 {
     int64_t n = (int64_t)O * H * Wpad * Ipad;
-    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, O, I, H, W, Wpad, Ipad, 1);
+    hipLaunchKernelGGL(oihw_to_ohwi_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, O, I, H, W, Wpad, Ipad,
+                       Ostride ? Ostride : H * Wpad * Ipad, 1);
+}
+
+// input of the packed 7x7 stem: y [imgs][H + 2*fr_t...] -- a zero-framed NHWC3 image (frame written once at allocation,
+// only the interior here).  src_nhwc3 = 0: x is the caller's NCHW fp32 batch; 1: x is [imgs][H][W][3] (test hook).
+__global__ void frame_nhwc3_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int H, int W, int Hp, int Wp,
+                                   int top, int left, int src_nhwc3)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (img, h, w)
+    if (i >= n) return;
+    const int w = (int)(i % W);
+    const int64_t t = i / W;
+    const int h = (int)(t % H);
+    const int64_t img = t / H;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        v[c] = src_nhwc3 ? x[i * 3 + c] : x[((img * 3 + c) * H + h) * (int64_t)W + w];
+    float* o = y + ((img * Hp + h + top) * (int64_t)Wp + w + left) * 3;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+}
+// packed stem: the 8th tap slot of every kernel row multiplies real pixels (the window over-reads one pixel) with a zero
+// weight; its weight GRADIENT is not zero by itself and must not reach Adam
+__global__ void stem3_mask_grad_kernel(float* __restrict__ g, int O)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (o, kh, 3 floats)
+    if (i >= O * 7 * 3) return;
+    const int o = i / 21, r = i - o * 21;
+    g[o * 176 + (r / 3) * 24 + 21 + r % 3] = 0.f;
+}
+void k_stem3_mask_grad(float* g, int O, hipStream_t s)
+{
+    hipLaunchKernelGGL(stem3_mask_grad_kernel, dim3(cdiv(O * 21, 256)), dim3(256), 0, s, g, O);
+}
+void k_frame_nhwc3(const float* x, float* y, int imgs, int H, int W, int Hp, int Wp, int top, int left, int src_nhwc3,
+                   hipStream_t s)
+{
+    const int64_t n = (int64_t)imgs * H * W;
+    hipLaunchKernelGGL(frame_nhwc3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, n, H, W, Hp, Wp, top, left, src_nhwc3);
 }
 
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int T, int Ci, TapList taps)

@@ -43,14 +43,16 @@
 
 #include "common.h"
 
-template <int BM, int BN, int WN, bool STEM, int NS = 4, int KS = 16>
+// STEM: 0 = 3x3 / 1x1 convs, 1 = stem with K = [kh][kw padded][4] (EfficientNet's 3x3, ResNet's padded form), 2 = ResNet's
+// packed 7x7 stem over the zero-framed NHWC3 input
+template <int BM, int BN, int WN, int STEM, int NS = 4, int KS = 16>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__     // the host pass only needs the launch stub (the body uses gfx950-only builtins)
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
     static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
-    static_assert(KS == 16 || (KS == 32 && !STEM), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
+    static_assert(KS == 16 || (KS == 32 && STEM == 0), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
     constexpr int D = NS - 1;                   // LDS ring of NS stages of KS k; DMA runs D steps ahead
     constexpr int STG_A = BM * KS, STG_B = BN * KS;   // floats per stage
     constexpr int CPR = KS / 4;                 // 16-B chunks per row of a stage (4 or 8)
@@ -159,7 +161,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         auto issue = [&](int s) {
             const int slot = (s - k0) % NS;
             typedef __attribute__((address_space(3))) void lds_void;
-            if constexpr (STEM) {
+            if constexpr (STEM != 0) {
+              if constexpr (STEM == 2) {
+                // packed 7x7 stem: chunk c of K = floats 4j .. 4j+3 of kernel row kh's 24-float window, which starts at the
+                // framed pixel (2 oh + kh, 2 ow): no bounds to check, chunks past the 42 real ones read the zero page
+                const int c = 4 * s + (csrc >> 2);
+                const int kh = c / 6, j = c - 6 * kh;
+                const bool cv = c < 42;
+                const int koff = s * 16;
+#pragma unroll
+                for (int q = 0; q < GA; ++q)
+                    __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
+                                                     (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const float* src = (rv[q] && cv) ? p.X + (size_t)(xb[q] + ((ih0[q] + kh) * p.Wi + iw0[q]) * 3 + 4 * j) : p.zeros;
+                    __builtin_amdgcn_global_load_lds(src, (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
+                }
+              } else {
                 // stem: K = (kh, kw padded to 8 or 4, ci padded to 4); step = (half) a kernel row, chunk = kw
                 const int kw = ((s & p.stem_h2) << 2) + (csrc >> 2);
                 const int dh = (s >> p.stem_h2) - p.stem_pad, dw = kw - p.stem_pad;
@@ -176,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     const float* src = ok ? p.X + (size_t)(xb[q] + (ih * p.Wi + iw) * p.Ci) : p.zeros;
                     __builtin_amdgcn_global_load_lds(src, (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
                 }
+              }
             } else {
                 const unsigned f = (unsigned)(p.tapcode >> (4 * it)) & 15u;
                 const int dh = (int)(f & 3u) - 1, dw = (int)(f >> 2) - 1;
@@ -379,11 +399,12 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
     if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false>), LDS_L, "igemm_kernel<128, 128, 2, false>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false>), LDS_S, "igemm_kernel<64, 256, 4, false>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, false, 2, 32>), LDS_L, "igemm_kernel<128, 128, 2, false, 2, 32>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, false, 2, 32>), LDS_S, "igemm_kernel<64, 256, 4, false, 2, 32>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, true>), LDS_S, "igemm_kernel<64, 256, 4, true>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0>), LDS_L, "igemm_kernel<128, 128, 2, 0>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0>), LDS_S, "igemm_kernel<64, 256, 4, 0>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 1>), LDS_S, "igemm_kernel<64, 256, 4, 1>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 2>), LDS_S, "igemm_kernel<64, 256, 4, 2>");
         attr_done = true;
     }
     // K per LDS stage: 32 (two stages) stages a whole 128-B line per DMA row -- the L1 hands out whole
@@ -409,14 +430,16 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, igemm_max_blocks()), p.total_steps);
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
     dim3 grid(nblk);
-    if (p.stem_kw)
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, true>), grid, dim3(256), LDS_S, s, p);
+    if (p.stem_kw && p.stem3)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 2>), grid, dim3(256), LDS_S, s, p);
+    else if (p.stem_kw)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 1>), grid, dim3(256), LDS_S, s, p);
     else if (p.M >= 128) {
-        if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false, 2, 32>), grid, dim3(256), LDS_L, s, p);
-        else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, false>), grid, dim3(256), LDS_L, s, p);
+        if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32>), grid, dim3(256), LDS_L, s, p);
+        else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0>), grid, dim3(256), LDS_L, s, p);
     }
     else if (ks32)
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, false, 2, 32>), grid, dim3(256), LDS_S, s, p);
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32>), grid, dim3(256), LDS_S, s, p);
     else
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, false>), grid, dim3(256), LDS_S, s, p);
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0>), grid, dim3(256), LDS_S, s, p);
 }

@@ -112,6 +112,23 @@ def test_step_bce(eng):
 
 
 def test_step_stage1(eng):
+    _stage1_step_check(eng, 'stage1')
+
+
+def test_step_stage1_packed_stem(monkeypatch):
+    """FM_STEM_PACKED=1 (opt-in): the 7x7 stem reads a zero-framed NHWC3 image with K = 7 rows x 24 floats (11 K-steps
+    instead of 14).  Same step, same bounds as the default form."""
+    from fedmlp_amd.engine import Engine
+    monkeypatch.setenv("FM_STEM_PACKED", "1")
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    try:
+        assert e.debug_conv_info(0)["Kw"] == 176
+        _stage1_step_check(e, 'stage1_packed_stem')
+    finally:
+        e.close()
+
+
+def _stage1_step_check(eng, what):
     net = _load(eng)
     (x1, x2), y = _data(6, 3, views=2)
     act, neg = [1], [0, 2, 3, 4]
@@ -131,7 +148,7 @@ def test_step_stage1(eng):
     opt.step()
     assert rm.flips <= 32, rm.flips
     assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
-    _cmp_grads(eng, net, what='stage1')
+    _cmp_grads(eng, net, what=what)
     _cmp_state(eng, net, atol_w=2.5 * LR)
 
 

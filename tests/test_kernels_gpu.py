@@ -85,6 +85,7 @@ def _check_conv(e, sd, ci, imgs, groups, seed):
     want = wr.grad.permute(0, 2, 3, 1)                               # O,H,W,I
     want = F.pad(want, (0, info["cin_p"] - info["cin"], 0, info["kw_p"] - info["k"]))
     want = want.reshape(info["cout"], -1)
+    want = F.pad(want, (0, info["Kw"] - want.shape[1]))              # packed stem: rows of 7*8*3 = 168 padded to 176
     scale = want.abs().max().item()
     np.testing.assert_allclose(dw.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5 * scale,
                                err_msg=f"wgrad {name}")
@@ -113,6 +114,23 @@ def test_conv_all_layers_64(eng64, ci):
 def test_conv_layers_224(eng224, ci):
     e, sd = eng224
     _check_conv(e, sd, ci, imgs=3, groups=1, seed=200 + ci)
+
+
+@pytest.mark.parametrize("hw,imgs,groups", [(64, 6, 2), (224, 3, 1), (96, 2, 1)])
+def test_packed_stem_conv(monkeypatch, hw, imgs, groups):
+    """FM_STEM_PACKED=1: forward (+ BN partials) and weight gradient of the packed 7x7 stem against F.conv2d; the
+    gradient slot of the zero tap (columns 21..23 of every 24-float kernel row, and the 8 pad columns) must be 0."""
+    from fedmlp_amd.engine import Engine
+    monkeypatch.setenv("FM_STEM_PACKED", "1")
+    e = Engine("Resnet18", 5, hw, hw, 2 * imgs)
+    try:
+        flat, cnt = spec.init_state("Resnet18", 5, 11)
+        e.set_state(flat, cnt)
+        info = e.debug_conv_info(0)
+        assert info["Kw"] == 176 and info["cin_p"] == 3 and info["kw_p"] == 8
+        _check_conv(e, spec.flat_to_state_dict("Resnet18", 5, flat, cnt), 0, imgs=imgs, groups=groups, seed=300 + hw)
+    finally:
+        e.close()
 
 
 def test_conv_streamk_forced_splits():
