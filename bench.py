@@ -141,6 +141,13 @@ def family_traffic(prefix, args):
         return None
 
 
+def under_profiler():
+    """true inside `rocprofv3 ... -- python3 bench.py` (the tool preloads its library and exports ROCPROF* variables)"""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
 def two_stream_extra(args, eng, step_fn, B, max_images, dev):
     """ResNet-18's optional two-stream mode (FM_SIDE_TEACHER=2: frozen teacher + weight gradients on a side stream,
     bit-identical results), timed on a second engine after the main region.  It is NOT the default -- and not `value` --
@@ -361,7 +368,12 @@ def main():
                "last_loss": float(lv[-1])}
         if world == 1 and args.model == "Resnet18" and args.workload != "conv_fwd" and not args.no_profile \
                 and os.environ.get("FM_SIDE_TEACHER") is None:
-            out["config"]["two_stream_mode"] = two_stream_extra(args, eng, step, B, views * B, str(dev))
+            if under_profiler():
+                # the extra leg co-runs kernels on two streams: inside a rocprofv3 --stats run its stretched launch
+                # windows would be averaged into the per-kernel durations the roofline line is checked against
+                out["config"]["two_stream_mode"] = {"skipped": "running under rocprofv3"}
+            else:
+                out["config"]["two_stream_mode"] = two_stream_extra(args, eng, step, B, views * B, str(dev))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         else:

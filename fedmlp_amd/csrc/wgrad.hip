@@ -56,54 +56,94 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
     int4 e = {0, 0, 0, 0};
     if (bstage && gc < (p.Nw >> 2)) e = p.tab[gc];
 
-    f32x4 ra[NA], rb[NB];
-    // Pixel -> (image, oh, ow) of every B row this thread stages: decoded once by division,
+    // Global loads go through two buffer descriptors with 32-bit offsets, and every bounds case (pixels past the
+    // split's end, padded taps, halo rows / columns) is an offset the hardware range check answers with zeros: gload
+    // has no branch and no 64-bit address arithmetic, so it shares ONE basic block with the MFMAs of the current step
+    // and the scheduler interleaves the two (the pointer-select form cost ~250 VALU instructions in 18 basic blocks
+    // ahead of every step's first MFMA).
+    //   A: base = first pixel of the split, records = the split's rows -> rows past pend are out of range by themselves
+    //   B: base = first image the split touches, offsets relative to it (launch_wgrad keeps a split's span < 4 GB)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dY + (size_t)pbeg * p.M), 0, (pend - pbeg) * p.M * 4, 0x00020000);
+    const int img0 = pbeg / HWo;
+    const int nimg = p.npix / HWo;
+    const size_t img_bytes = (size_t)p.Hi * p.Wi * p.Ci * 4;
+    const size_t restB = (size_t)(nimg - img0) * img_bytes;
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.X + (size_t)img0 * (img_bytes >> 2)), 0, restB > 0xffffffffull ? 0xffffffffu : (unsigned)restB, 0x00020000);
+    const bool a_ok = m0 + 4 * ca < p.M;
+    const int a_off0 = (ra0 * p.M + m0 + 4 * ca) * 4;
+    const bool b_ok = bstage && e.w;
+    const int ci4 = p.Ci * 4, ez4 = e.z * 4;
+
+    u32x4 ra[NA], rb[NB];
+    // Pixel -> (image relative to img0, oh, ow) of every B row this thread stages: decoded once by division,
     // then advanced by 32 pixels per step with carries only (32 = d_img*HWo + dq*Wo + dr).
     int r_img[NB], r_oh[NB], r_ow[NB];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int pix = pbeg + rb0 + RPB * q;
-        r_img[q] = pix / HWo;
-        const int rem = pix - r_img[q] * HWo;
+        const int im = pix / HWo;
+        const int rem = pix - im * HWo;
+        r_img[q] = im - img0;
         r_oh[q] = rem / p.Wo;
         r_ow[q] = rem - r_oh[q] * p.Wo;
     }
     const int d_img = 32 / HWo, rem32 = 32 - d_img * HWo;
     const int dq = rem32 / p.Wo, dr = rem32 - dq * p.Wo;
-    // Out-of-range pixels / padded taps read a 16-B block of zeros: no select on loaded data.
-    // gload(s) must be called for s = 0, 1, 2, ... in order (it advances the row state).
-    auto gload = [&](int s) {
-        const int pb = pbeg + s * 32;
+    // gaddr(s) computes the offsets of step s (call it for s = 0, 1, 2, ... in order: it advances the row state; steps
+    // past the split's end get out-of-range offsets = zeros), gissue() issues the loads of the offsets computed last.
+    // In the main loop the loads of step s+1 are issued FIRST (their latency hides behind the step's MFMAs), the offsets
+    // of step s+2 are computed among the MFMAs, and sched_barriers keep the compiler from sinking the loads down to
+    // the LDS stores (which it does to save registers: the whole global latency was exposed before every barrier).
+    int offA[NA], offB[NB];
+    auto gaddr = [&](int s) {
 #pragma unroll
-        for (int q = 0; q < NA; ++q) {
-            const int pix = pb + ra0 + RPA * q;
-            const float* src = (pix < pend && m0 + 4 * ca < p.M) ? p.dY + (size_t)pix * p.M + m0 + 4 * ca : p.zeros;
-            ra[q] = *reinterpret_cast<const f32x4*>(src);
-        }
+#ifdef FM_WGRAD_FAKE_L2
+        for (int q = 0; q < NA; ++q) offA[q] = a_ok ? (a_off0 + ((s & 3) * 32 + RPA * q) * p.M * 4) : -1;
+#else
+        for (int q = 0; q < NA; ++q) offA[q] = a_ok ? a_off0 + (s * 32 + RPA * q) * p.M * 4 : -1;
+#endif
+        const int pb = pbeg + s * 32;
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int pix = pb + rb0 + RPB * q;
-            const int ih = r_oh[q] * p.stride + e.x, iw = r_ow[q] * p.stride + e.y;
-            const bool ok = bstage && pix < pend && e.w && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-            const float* src = ok ? p.X + ((size_t)(r_img[q] * p.Hi + ih) * p.Wi + iw) * p.Ci + e.z : p.zeros;
-            rb[q] = *reinterpret_cast<const f32x4*>(src);
+            // 24-bit multiplies (full rate; every factor is far below 2^23, launch_wgrad checks the span) and bitwise
+            // predicate logic: no 64-bit mad, no short-circuit branch
+            const int ih = __mul24(r_oh[q], p.stride) + e.x, iw = __mul24(r_ow[q], p.stride) + e.y;
+            const bool ok = b_ok & (pix < pend) & ((unsigned)ih < (unsigned)p.Hi) & ((unsigned)iw < (unsigned)p.Wi);
+            const int off = __mul24(__mul24(__mul24(r_img[q], p.Hi) + ih, p.Wi) + iw, ci4) + ez4;
+#ifdef FM_WGRAD_FAKE_L2
+            offB[q] = ok ? (off & 0x3fff0) : -1;      // timing experiment only: every B load inside one 256-KB window
+#else
+            offB[q] = ok ? off : -1;
+#endif
             int ow = r_ow[q] + dr, oh = r_oh[q] + dq, im = r_img[q] + d_img;
             if (ow >= p.Wo) { ow -= p.Wo; ++oh; }
             if (oh >= p.Ho) { oh -= p.Ho; ++im; }
             r_ow[q] = ow; r_oh[q] = oh; r_img[q] = im;
         }
     };
+    auto gissue = [&]() {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[q], 0, 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[q], 0, 0);
+    };
     auto lstore = [&](int buf) {
         float* a = As + buf * 32 * BM + ra0 * BM + 4 * ca;
-        float* b = Bs + buf * 32 * BNP + rb0 * BNP + 4 * cb;
+        // threads that stage no B row (64 of 256 when CB = 48) store their zeros to a private 16-B slot behind the tiles:
+        // a branch here would let the compiler sink the B loads below the MFMAs, right in front of these stores
+        float* b = bstage ? Bs + buf * 32 * BNP + rb0 * BNP + 4 * cb : Bs + 2 * 32 * BNP + 4 * (tid & 63);
+        const int bstep = bstage ? RPB * BNP : 0;
 #pragma unroll
-        for (int q = 0; q < NA; ++q) *reinterpret_cast<f32x4*>(a + q * RPA * BM) = ra[q];
-        if (bstage) {
+        for (int q = 0; q < NA; ++q) *reinterpret_cast<u32x4*>(a + q * RPA * BM) = ra[q];
 #pragma unroll
-            for (int q = 0; q < NB; ++q) *reinterpret_cast<f32x4*>(b + q * RPB * BNP) = rb[q];
-        }
+        for (int q = 0; q < NB; ++q) *reinterpret_cast<u32x4*>(b + q * bstep) = rb[q];
     };
 
+    const bool wave_cols = __builtin_amdgcn_readfirstlane(n0 + wn * (16 * FC)) < p.Nw;
     f32x4 acc[4][FC];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -111,15 +151,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
         for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nsteps > 0) {
-        gload(0);
+        gaddr(0);
+        gissue();
         lstore(0);
+        gaddr(1);
     }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) gload(s + 1);
+        gissue();                        // step s+1, unconditional (the step after the last loads zeros): one basic block
+        __builtin_amdgcn_sched_barrier(0);
+        gaddr(s + 2);
         const float* A = As + buf * 32 * BM + lg * BM + wm * 64 + 4 * li;
         const float* B = Bs + buf * 32 * BNP + lg * BNP + wn * (16 * FC) + FC * li;
+        // a wave whose 16*FC columns all lie past Nw (the last N-tile of N = 576 = 2.25 x 256) only stages: its
+        // fragment reads and MFMAs are skipped, wave-uniformly
+        if (wave_cols)
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(A + kk * 4 * BM);
@@ -138,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
                 for (int c = 0; c < FC; ++c)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[c], acc[r][c], 0, 0, 0);
         }
-        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -353,14 +401,23 @@ int wgrad_tile_n(int M, int Nw)
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
 {
     static bool attr_done = false;
-    constexpr int LDS_L = 2 * 32 * (128 + 128) * 4;
-    constexpr int LDS_S = 2 * 32 * (64 + 256) * 4;
-    constexpr int LDS_T = 2 * 32 * (64 + 192 + 16) * 4;
+    constexpr int LDS_L = 2 * 32 * (128 + 128) * 4 + 1024;   // + 64 x 16 B dummy slots
+    constexpr int LDS_S = 2 * 32 * (64 + 256) * 4 + 1024;
+    constexpr int LDS_T = 2 * 32 * (64 + 192 + 16) * 4 + 1024;
     if (!attr_done) {
         set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>), LDS_L, "wgrad_kernel<128, 128, 2>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4>), LDS_S, "wgrad_kernel<64, 256, 4>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3>), LDS_T, "wgrad_kernel<64, 192, 4, 3>");
         attr_done = true;
+    }
+    {   // 32-bit buffer offsets: one split's dY rows and the images it spans must stay below 2 GB (never close: a split
+        // of the largest layer at 1024 images is ~5 MB)
+        const size_t spanA = ((size_t)p.pix_per_split + 64) * p.M * 4;
+        const size_t spanB = ((size_t)p.pix_per_split / ((size_t)p.Ho * p.Wo) + 3) * p.Hi * p.Wi * p.Ci * 4;
+        if (spanA >= (1ull << 31) || spanB >= (1ull << 31) || spanB / ((size_t)p.Ci * 4) >= (1ull << 23)) {
+            fprintf(stderr, "fedmlp_hip: wgrad split too large for 32-bit buffer offsets (%zu / %zu bytes)\n", spanA, spanB);
+            abort();
+        }
     }
     dim3 grid(p.tilesM * p.tilesN, splits);
     if (p.M >= 128)
