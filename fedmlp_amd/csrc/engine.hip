@@ -174,8 +174,8 @@ struct fm_engine {
     std::vector<OpEv> opevs;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ev_free;
-    double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
-    int64_t prof_n[5] = {0, 0, 0, 0, 0};
+    double prof_ms[6] = {0, 0, 0, 0, 0, 0}, prof_flops[6] = {0, 0, 0, 0, 0, 0};
+    int64_t prof_n[6] = {0, 0, 0, 0, 0, 0};
     std::vector<void*> allocs;
     // dgrad weight packs: rebuilt by ONE launch after every optimizer step (and lazily after any
     // external change of the state), not per convolution call
@@ -905,7 +905,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
     p.pix_per_split = (((p.npix + splits - 1) / splits) + 31) & ~31;
     splits = (p.npix + p.pix_per_split - 1) / p.pix_per_split;
     {
-        ProfScope ps(e, c.cout_p >= 128 ? 3 : 4, 2.0 * c.macs_per_img * imgs);
+        ProfScope ps(e, c.cout_p >= 128 ? 3 : (c.cin == 3 ? 5 : 4), 2.0 * c.macs_per_img * imgs);
         launch_wgrad(p, splits, e->st);
     }
     k_reduce_slabs(e->ws_slab, e->grad + c.w_off, splits, (int64_t)c.w_numel, e->st);
@@ -1977,7 +1977,7 @@ int fm_profile_enable(fm_engine* e, int32_t on)
 
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops)
 {
-    ARGCHK(e && family >= 0 && family < 5, "family");
+    ARGCHK(e && family >= 0 && family < 6, "family");
     HIPCHK(hipStreamSynchronize(e->st));
     if (e->prof_fail) { e->prof_fail = false; g_err = "a profiling event could not be created/recorded"; return FM_ERR_HIP; }
     for (auto& p : e->evs) {
