@@ -36,8 +36,8 @@ sys.path.insert(0, ROOT)
 # kernel families of fm_profile_read (names as rocprofv3 prints them for the ResNet-18 workload, where every
 # conv has Ci % 32 == 0 and runs the 32-k-stage instantiation)
 KERNEL_NAMES = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,256,4,0,2,32>",
-                2: "igemm_kernel<64,256,4,1,4,16>", 3: "wgrad_kernel<128,128,2,4>", 4: "wgrad_kernel<64,192,4,3>",
-                5: "wgrad_kernel<64,256,4,4>"}
+                2: "igemm_kernel<64,256,4,2,4,16>", 3: "wgrad_kernel<128,128,2,4>", 4: "wgrad_kernel<64,192,4,3>",
+                5: "wgrad_kernel<64,192,4,3> [7x7 stem launch]"}
 NFAM = len(KERNEL_NAMES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)

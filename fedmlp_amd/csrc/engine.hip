@@ -265,11 +265,10 @@ int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hi
     }
     c.Kw = k * c.kw_p * c.cin_p;
     const char* pk = getenv("FM_STEM_PACKED");
-    if (cin == 3 && k == 7 && !eff && pk && atoi(pk) == 1) {
-        // packed 7x7 stem (opt-in): a kernel row is the 24 contiguous floats (7 taps x 3 channels + one zero tap) of an
-        // NHWC3 row of the zero-framed input; 7 x 24 = 168 -> 176 = 11 K-steps of 16 (the [7][8][4] form needs 14).
-        // The default stays the [7][8][4] form: the committed golden trajectories were calibrated on its rounding
-        // ("packed stem").
+    if (cin == 3 && k == 7 && !eff && !(pk && atoi(pk) == 0)) {
+        // packed 7x7 stem: a kernel row is the 24 contiguous floats (7 taps x 3 channels + one zero tap) of an NHWC3 row
+        // of the zero-framed input; 7 x 24 = 168 -> 176 = 11 K-steps of 16 (the [7][8][4] form, FM_STEM_PACKED=0,
+        // needs 14 and wastes 43 % of the weight gradient's tile columns)
         c.stem3 = true;
         c.cin_p = 3; c.kw_p = 8;
         c.Kw = 176;

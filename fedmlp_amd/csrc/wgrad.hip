@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < FC; ++c) dst[c] = acc[r][c][q];
+                    for (int c = 0; c < FC; ++c)
+                        if (n + c < p.Nw) dst[c] = acc[r][c][q];      // Nw need not be a multiple of 3 (stem: 176)
                 }
             }
     }
@@ -395,7 +396,7 @@ int wgrad_tile_n(int M, int Nw)
 {
     static const int t192 = getenv("FM_WGRAD192") ? atoi(getenv("FM_WGRAD192")) : 1;
     if (M >= 128) return 128;
-    return (t192 && Nw % 192 == 0) ? 192 : 256;
+    return (t192 && (Nw % 192 == 0 || Nw <= 192)) ? 192 : 256;      // Nw = 176: the packed 7x7 stem
 }
 
 void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)

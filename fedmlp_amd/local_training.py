@@ -100,6 +100,8 @@ class LocalUpdate(object):
         self.idxss = []
         self.order_queue = []
         self.tagging_log = None            # set to [] to record (class, pool, similarities) of every tagging call
+        self.selection_hook = None         # parity replays: f(rnd, k, cls, clean, noise) -> (clean, noise), called once
+                                           # per tagged class between selection and stage-2 training
         self._dev = {}
 
     # ---- data plumbing -------------------------------------------------------------------
@@ -433,6 +435,8 @@ class LocalUpdate(object):
                 top, bot = [], []
             clean = [int(pool_idx[j]) for j in top]
             noise = [int(pool_idx[j]) for j in bot]
+            if self.selection_hook is not None:
+                clean, noise = self.selection_hook(rnd, k, cls, clean, noise)
             if first:
                 self.traindata_idx += [clean, noise]
             else:

@@ -115,15 +115,15 @@ def test_step_stage1(eng):
     _stage1_step_check(eng, 'stage1')
 
 
-def test_step_stage1_packed_stem(monkeypatch):
-    """FM_STEM_PACKED=1 (opt-in): the 7x7 stem reads a zero-framed NHWC3 image with K = 7 rows x 24 floats (11 K-steps
-    instead of 14).  Same step, same bounds as the default form."""
+def test_step_stage1_padded_stem_form(monkeypatch):
+    """FM_STEM_PACKED=0: the 7x7 stem in the [7][8][4] K layout (14 K-steps instead of the packed form's 11).  Same
+    step, same bounds as the default form."""
     from fedmlp_amd.engine import Engine
-    monkeypatch.setenv("FM_STEM_PACKED", "1")
+    monkeypatch.setenv("FM_STEM_PACKED", "0")
     e = Engine("Resnet18", C_, HW, HW, 16)
     try:
-        assert e.debug_conv_info(0)["Kw"] == 176
-        _stage1_step_check(e, 'stage1_packed_stem')
+        assert e.debug_conv_info(0)["Kw"] == 224
+        _stage1_step_check(e, 'stage1_padded_stem')
     finally:
         e.close()
 

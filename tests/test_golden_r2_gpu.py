@@ -110,11 +110,46 @@ def _replay_two_stage(name, tol):
     locs = [LocalUpdate(args, i, ds, g["users"][i], pos, neg, active_class_list=[i]) for i in range(n_cl)]
     for l in locs:
         l.tagging_log = []
+    cur = {}                                   # round record of the golden being replayed
+
+    def make_hook(i):
+        """Discrete picks against the reference's.  The index work itself is pinned bit-exactly on identical inputs by
+        tests/test_kat_gpu.py; here the inputs are features of a net trained on another machine, so a pick may differ
+        ONLY where the engine's own similarities of the two candidates are a near-tie: <= 5e-3 of the row's range in
+        the first stage-2 round, <= 2e-2 in later ones (their features come from a net that has meanwhile trained a
+        round on pseudo-labels; its probe logits are 2-3e-2 of their range from the reference's by then) -- checked
+        for every differing element of every stage-2 round.  A near-tie pick that differs is then REPLACED by
+        the reference's: otherwise the two runs train on different pseudo-labelled sets from that round on and the
+        continuous comparisons below (loss, norms, prototypes, t) would compare different experiments."""
+        def hook(rnd, k, cls, clean, noise):
+            r, prev = cur["r"], cur["prev"]
+            out = []
+            for side, got in ((0, clean), (1, noise)):
+                full = r["traindata_idx"][i][2 * k + side]
+                want = full[len(prev["traindata_idx"][i][2 * k + side]):] if prev is not None and rnd > S1 else full
+                assert len(got) == len(want), (rnd, i, cls, side, len(got), len(want))
+                got_s, want_s = set(got), set(want)
+                if got_s != want_s:
+                    t = [t for t in locs[i].tagging_log if t["rnd"] == rnd and t["cls"] == cls][-1]
+                    where = {v: j for j, v in enumerate(t["pool_idx"])}
+                    rng = float(np.nanmax(t["sim"]) - np.nanmin(t["sim"]))
+                    for gi, wi in zip(sorted(got_s - want_s), sorted(want_s - got_s)):
+                        gap = abs(float(t["sim"][where[gi]]) - float(t["sim"][where[wi]]))
+                        mx["pick_gap"] = max(mx["pick_gap"], gap / rng)
+                        assert gap <= (5e-3 if rnd == S1 else 2e-2) * rng, (rnd, i, cls, gi, wi, gap, rng)
+                    rep["picks_replaced"] += len(got_s - want_s)
+                rep["picks_total"] += len(want)
+                out.append(list(want))
+            return out[0], out[1]
+        return hook
+
+    for i, l in enumerate(locs):
+        l.selection_hook = make_hook(i)
     tao, Prototype = [0] * C, []
     neg_lists, act_lists = g["neg_lists"], g["act_lists"]
     rep = {"max": {"loss": 0.0, "norm": 0.0, "bn_bias_norm": 0.0, "proto": 0.0, "logits": 0.0, "t_count": 0.0,
                    "pick_gap": 0.0},
-           "selection_identical": []}
+           "picks_replaced": 0, "picks_total": 0}
     mx = rep["max"]
 
     def cmp_norms(got, want):
@@ -126,6 +161,7 @@ def _replay_two_stage(name, tol):
             mx[kind] = max(mx[kind], abs(got[k] - w) / (abs(w) + 1e-12))
 
     for rnd, r in enumerate(g["rounds"]):
+        cur["r"], cur["prev"] = r, (g["rounds"][rnd - 1] if rnd > 0 else None)
         w, taos, protos = [], [], []
         for i in range(n_cl):
             if rnd < S1:
@@ -140,30 +176,9 @@ def _replay_two_stage(name, tol):
             if rnd == 0:
                 assert ret[4] == neg_lists[i] and ret[5] == act_lists[i]
             if rnd >= S1:
-                # The selected lists are used through membership only (DatasetSplit_pseudo, :1462-1469), so they are
-                # compared as sets.  The index work itself is pinned bit-exactly on identical inputs by
-                # tests/test_kat_gpu.py; here the inputs are features of a net trained for two rounds on another
-                # machine, so a pick may differ ONLY where the engine's own similarities of the two candidates are a
-                # near-tie (<= 5e-3 of the row's range): checked for every differing element, first stage-2 round.
-                same = [sorted(a) for a in locs[i].traindata_idx] == [sorted(b) for b in r["traindata_idx"][i]]
-                rep["selection_identical"].append(bool(same))
-                for got_l, want_l in zip(locs[i].traindata_idx, r["traindata_idx"][i]):
-                    assert abs(len(got_l) - len(want_l)) <= 1
-                if rnd == S1 and not same:
-                    logs = {t["cls"]: t for t in locs[i].tagging_log if t["rnd"] == rnd}
-                    for k, cls in enumerate(neg_lists[i]):
-                        for side in (0, 1):
-                            got_s, want_s = set(locs[i].traindata_idx[2 * k + side]), set(r["traindata_idx"][i][2 * k + side])
-                            assert len(got_s) == len(want_s), (rnd, i, cls)
-                            if got_s == want_s:
-                                continue
-                            t = logs[cls]
-                            where = {v: j for j, v in enumerate(t["pool_idx"])}
-                            rng = float(np.nanmax(t["sim"]) - np.nanmin(t["sim"]))
-                            for gi, wi in zip(sorted(got_s - want_s), sorted(want_s - got_s)):
-                                gap = abs(float(t["sim"][where[gi]]) - float(t["sim"][where[wi]]))
-                                mx["pick_gap"] = max(mx["pick_gap"], gap / rng)
-                                assert gap <= 5e-3 * rng, (rnd, i, cls, gi, wi, gap, rng)
+                # after the hook the lists equal the reference's as sets (membership is all DatasetSplit_pseudo uses,
+                # :1462-1469); how many picks the hook had to replace is in the report
+                assert [sorted(a) for a in locs[i].traindata_idx] == [sorted(b) for b in r["traindata_idx"][i]]
             w.append(copy.deepcopy(ret[0]))
             if len(ret) == 8:
                 taos.append(ret[6]); protos.append(ret[7])
@@ -184,6 +199,7 @@ def _replay_two_stage(name, tol):
         _, z = netglob(ds.x1[:4])
         want = np.array(r["probe_logits"])
         mx["logits"] = max(mx["logits"], float(np.abs(z.cpu().numpy() - want).max() / np.abs(want).max()))
+        rep.setdefault("running_max_after_round", []).append(dict(mx))
     _dump(rep, f"parity_{name}.json")
     for k, bound in tol.items():
         assert mx[k] <= bound, (name, k, mx[k], bound, mx)
@@ -192,16 +208,19 @@ def _replay_two_stage(name, tol):
 
 def test_two_stage_flow_conditioned_golden_64():
     """Bounds are fixed numbers over all four rounds (no per-round growth factor, no oracle-sensitivity excuse).
-    Measured on MI355X (gpurun_out/parity_traj_fedmlp64.json): loss 1.4e-3, weight norms 2.4e-3, BN-bias norms 2.5e-4
-    (the 32x32 / beta = 0 golden needed 5e-2 per round there), prototypes 1.5e-2 and probe logits 2.1e-2 of their
-    range after 128 Adam steps from a random init, t off by at most 11 of 1024 samples."""
+    Measured on MI355X (gpurun_out/parity_traj_fedmlp64.json) over both stem K layouts and three stream-K / tile-order
+    variants of the kernels: loss 0.9-1.4e-3, weight norms 1.9-2.4e-3, BN-bias norms 1.8-2.5e-4 (the 32x32 / beta = 0
+    golden needed 5e-2 per round there), prototypes 1.5-1.7e-2 and probe logits 2.2-2.7e-2 of their range after 128
+    Adam steps from a random init, t off by at most 9-12 of 1024 samples; 1-3 of the 20 picks are near-ties
+    (gap <= 3.8e-3 of the row's range) that fall the other way and are replaced by the reference's."""
     _replay_two_stage("traj_fedmlp64", {"loss": 3e-3, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 3e-2,
                                         "logits": 4e-2, "t_count": 16})
 
 
 def test_two_stage_flow_c14_golden():
-    """14 labels, 3 clients (configs[2] shape).  Measured: loss 3.2e-3, norms 1.7e-3, BN-bias norms 1.8e-4,
-    prototypes 3.1e-2, probe logits 2.8e-2, t off by <= 8 of 448; differing picks are near-ties (gap 4.4e-4 of range)."""
-    rep = _replay_two_stage("traj_fedmlp_c14", {"loss": 6e-3, "norm": 4e-3, "bn_bias_norm": 1e-3, "proto": 6e-2,
+    """14 labels, 3 clients (configs[2] shape).  Measured (both stem layouts): loss 1.6-2.5e-3, norms 1.3-1.5e-3,
+    BN-bias norms 1.3-1.5e-4, prototypes 2.3-3.1e-2, probe logits 3.2-3.7e-2, t off by <= 8 of 448; 4 of 18 picks are
+    near-ties replaced by the reference's (gap <= 8.9e-3 of range, second stage-2 round)."""
+    rep = _replay_two_stage("traj_fedmlp_c14", {"loss": 4e-3, "norm": 4e-3, "bn_bias_norm": 1e-3, "proto": 6e-2,
                                                 "logits": 6e-2, "t_count": 14})
-    assert len(rep["selection_identical"]) >= 3
+    assert rep["picks_total"] > 0

@@ -117,17 +117,22 @@ def test_conv_layers_224(eng224, ci):
 
 
 @pytest.mark.parametrize("hw,imgs,groups", [(64, 6, 2), (224, 3, 1), (96, 2, 1)])
-def test_packed_stem_conv(monkeypatch, hw, imgs, groups):
-    """FM_STEM_PACKED=1: forward (+ BN partials) and weight gradient of the packed 7x7 stem against F.conv2d; the
-    gradient slot of the zero tap (columns 21..23 of every 24-float kernel row, and the 8 pad columns) must be 0."""
+@pytest.mark.parametrize("packed", [1, 0])
+def test_stem_conv_forms(monkeypatch, hw, imgs, groups, packed):
+    """Forward (+ BN partials) and weight gradient of the 7x7 stem against F.conv2d in both K layouts: packed (default;
+    zero-framed NHWC3 input, kernel rows of 24 floats, K = 176 -- the gradient slot of the zero tap, columns 21..23 of
+    every row, and the 8 pad columns must come out 0) and FM_STEM_PACKED=0 ([7][8][4], K = 224)."""
     from fedmlp_amd.engine import Engine
-    monkeypatch.setenv("FM_STEM_PACKED", "1")
+    monkeypatch.setenv("FM_STEM_PACKED", str(packed))
     e = Engine("Resnet18", 5, hw, hw, 2 * imgs)
     try:
         flat, cnt = spec.init_state("Resnet18", 5, 11)
         e.set_state(flat, cnt)
         info = e.debug_conv_info(0)
-        assert info["Kw"] == 176 and info["cin_p"] == 3 and info["kw_p"] == 8
+        if packed:
+            assert info["Kw"] == 176 and info["cin_p"] == 3 and info["kw_p"] == 8
+        else:
+            assert info["Kw"] == 224 and info["cin_p"] == 4 and info["kw_p"] == 8
         _check_conv(e, spec.flat_to_state_dict("Resnet18", 5, flat, cnt), 0, imgs=imgs, groups=groups, seed=300 + hw)
     finally:
         e.close()
