@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
     // and the scheduler interleaves the two (the pointer-select form cost ~250 VALU instructions in 18 basic blocks
     // ahead of every step's first MFMA).
     //   A: base = first pixel of the split, records = the split's rows -> rows past pend are out of range by themselves
-    //   B: base = first image the split touches, offsets relative to it (launch_wgrad keeps a split's span < 4 GB)
+    //   B: base = first image the split touches, offsets relative to it (launch_wgrad keeps a split's span < 2 GB)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.dY + (size_t)pbeg * p.M), 0, (pend - pbeg) * p.M * 4, 0x00020000);
@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
     const size_t img_bytes = (size_t)p.Hi * p.Wi * p.Ci * 4;
     const size_t restB = (size_t)(nimg - img0) * img_bytes;
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.X + (size_t)img0 * (img_bytes >> 2)), 0, restB > 0xffffffffull ? 0xffffffffu : (unsigned)restB, 0x00020000);
+        const_cast<float*>(p.X + (size_t)img0 * (img_bytes >> 2)), 0, restB > 0x80000000ull ? 0x80000000u : (unsigned)restB, 0x00020000);
+    // the offset of every load that must return zeros: both descriptors hold at most 2^31 bytes (launch_wgrad checks the
+    // spans), so 2^31 is out of range for either without relying on how the range check treats a 32-bit wrap
+    constexpr int OOR = (int)0x80000000u;
     const bool a_ok = m0 + 4 * ca < p.M;
     const int a_off0 = (ra0 * p.M + m0 + 4 * ca) * 4;
     const bool b_ok = bstage && e.w;
@@ -101,9 +104,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
     auto gaddr = [&](int s) {
 #pragma unroll
 #ifdef FM_WGRAD_FAKE_L2
-        for (int q = 0; q < NA; ++q) offA[q] = a_ok ? (a_off0 + ((s & 3) * 32 + RPA * q) * p.M * 4) : -1;
+        for (int q = 0; q < NA; ++q) offA[q] = a_ok ? (a_off0 + ((s & 3) * 32 + RPA * q) * p.M * 4) : OOR;
 #else
-        for (int q = 0; q < NA; ++q) offA[q] = a_ok ? a_off0 + (s * 32 + RPA * q) * p.M * 4 : -1;
+        for (int q = 0; q < NA; ++q) offA[q] = a_ok ? a_off0 + (s * 32 + RPA * q) * p.M * 4 : OOR;
 #endif
         const int pb = pbeg + s * 32;
 #pragma unroll
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
             const bool ok = b_ok & (pix < pend) & ((unsigned)ih < (unsigned)p.Hi) & ((unsigned)iw < (unsigned)p.Wi);
             const int off = __mul24(__mul24(__mul24(r_img[q], p.Hi) + ih, p.Wi) + iw, ci4) + ez4;
 #ifdef FM_WGRAD_FAKE_L2
-            offB[q] = ok ? (off & 0x3fff0) : -1;      // timing experiment only: every B load inside one 256-KB window
+            offB[q] = ok ? (off & 0x3fff0) : OOR;      // timing experiment only: every B load inside one 256-KB window
 #else
-            offB[q] = ok ? off : -1;
+            offB[q] = ok ? off : OOR;
 #endif
             int ow = r_ow[q] + dr, oh = r_oh[q] + dq, im = r_img[q] + d_img;
             if (ow >= p.Wo) { ow -= p.Wo; ++oh; }
