@@ -359,3 +359,16 @@ def get_engine(model, n_classes, in_h, in_w, max_images, device=None, precision=
         e = Engine(model, n_classes, in_h, in_w, max_images, device, precision)
         _ENGINES[key] = e
     return e
+
+
+def release_engines():
+    """Close every cached engine (pulling a resident net's trained state to its host copy first).  The next
+    get_engine() builds a fresh one -- which is also when the library's per-engine environment switches are read."""
+    for key, e in list(_ENGINES.items()):
+        owner = getattr(e, "_owner", None)
+        if owner is not None:
+            owner._pull()
+            owner._engine = None
+        e._owner = None
+        e.close()
+        del _ENGINES[key]

@@ -95,9 +95,11 @@ def test_stage1_step_at_the_benchmarked_size_matches_the_reference():
         eng.close()
 
 
-def _replay_two_stage(name, tol):
+def _replay_two_stage(name, tol, replace_near_ties=True):
     """The FedMLP two-stage flow (stage 1, prototype pass, tagging + selection, stage 2, FedAvg*) against a golden
-    trajectory of the reference.  tol: fixed bounds {loss, norm, bn_bias_norm, proto, logits, t_count}."""
+    trajectory of the reference.  tol: fixed bounds {loss, norm, bn_bias_norm, proto, logits, t_count}.
+    replace_near_ties=False leaves the engine's own picks in place (free-running): near-ties are then checked in the
+    first stage-2 round only, because afterwards the two runs' pools differ."""
     from fedmlp_amd.local_training import LocalUpdate
     from fedmlp_amd.fedavg import FedAvg, FedAvg_tao, FedAvg_proto
     g = load_golden(name + ".json")
@@ -129,6 +131,9 @@ def _replay_two_stage(name, tol):
                 want = full[len(prev["traindata_idx"][i][2 * k + side]):] if prev is not None and rnd > S1 else full
                 assert len(got) == len(want), (rnd, i, cls, side, len(got), len(want))
                 got_s, want_s = set(got), set(want)
+                if not replace_near_ties and rnd > S1:
+                    out.append(list(got))
+                    continue
                 if got_s != want_s:
                     t = [t for t in locs[i].tagging_log if t["rnd"] == rnd and t["cls"] == cls][-1]
                     where = {v: j for j, v in enumerate(t["pool_idx"])}
@@ -139,7 +144,7 @@ def _replay_two_stage(name, tol):
                         assert gap <= (5e-3 if rnd == S1 else 2e-2) * rng, (rnd, i, cls, gi, wi, gap, rng)
                     rep["picks_replaced"] += len(got_s - want_s)
                 rep["picks_total"] += len(want)
-                out.append(list(want))
+                out.append(list(want) if replace_near_ties else list(got))
             return out[0], out[1]
         return hook
 
@@ -178,7 +183,8 @@ def _replay_two_stage(name, tol):
             if rnd >= S1:
                 # after the hook the lists equal the reference's as sets (membership is all DatasetSplit_pseudo uses,
                 # :1462-1469); how many picks the hook had to replace is in the report
-                assert [sorted(a) for a in locs[i].traindata_idx] == [sorted(b) for b in r["traindata_idx"][i]]
+                if replace_near_ties:
+                    assert [sorted(a) for a in locs[i].traindata_idx] == [sorted(b) for b in r["traindata_idx"][i]]
             w.append(copy.deepcopy(ret[0]))
             if len(ret) == 8:
                 taos.append(ret[6]); protos.append(ret[7])
@@ -200,7 +206,7 @@ def _replay_two_stage(name, tol):
         want = np.array(r["probe_logits"])
         mx["logits"] = max(mx["logits"], float(np.abs(z.cpu().numpy() - want).max() / np.abs(want).max()))
         rep.setdefault("running_max_after_round", []).append(dict(mx))
-    _dump(rep, f"parity_{name}.json")
+    _dump(rep, f"parity_{name}.json" if replace_near_ties else f"parity_{name}_free_running.json")
     for k, bound in tol.items():
         assert mx[k] <= bound, (name, k, mx[k], bound, mx)
     return rep
@@ -215,6 +221,21 @@ def test_two_stage_flow_conditioned_golden_64():
     (gap <= 3.8e-3 of the row's range) that fall the other way and are replaced by the reference's."""
     _replay_two_stage("traj_fedmlp64", {"loss": 3e-3, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 3e-2,
                                         "logits": 4e-2, "t_count": 16})
+
+
+def test_two_stage_flow_conditioned_golden_64_free_running(monkeypatch):
+    """The same replay with NO pick replaced, on the stem layout whose rounding happens to keep every first-round pick
+    on the reference's side (FM_STEM_PACKED=0): the whole flow then stays inside the same bounds by itself (measured
+    loss 1.4e-3, t off by 11 of 1024) -- the replacement above is not what holds the other runs in."""
+    from fedmlp_amd.engine import release_engines
+    monkeypatch.setenv("FM_STEM_PACKED", "0")
+    release_engines()                      # the stem layout is fixed when an engine is built
+    try:
+        rep = _replay_two_stage("traj_fedmlp64", {"loss": 3e-3, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 3e-2,
+                                                  "logits": 4e-2, "t_count": 16}, replace_near_ties=False)
+    finally:
+        release_engines()
+    assert rep["picks_replaced"] == 0
 
 
 def test_two_stage_flow_c14_golden():
