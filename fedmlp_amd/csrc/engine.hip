@@ -165,6 +165,7 @@ struct fm_engine {
     int sel_cap = 0;
     // profiling
     bool prof = false, prof_fail = false;
+    hipError_t soft_err = hipSuccess;      // first failed event record / stream wait of the current step (soft())
     // per-op timing (FM profile leg of tools/op_profile.py): label = "<op>@<block>"
     bool oprof = false;
     int ctx = -1;
@@ -213,6 +214,19 @@ struct fm_engine {
     int* sk_counters2 = nullptr;
     float* stem_col = nullptr;        // bf16 mode: [images][hout][wout][k][4][4] bf16 im2col of the input (the stem's X operand)
 };
+static inline void soft(fm_engine* e, hipError_t rc)
+{
+    if (rc != hipSuccess && e->soft_err == hipSuccess) e->soft_err = rc;
+}
+// end of a step's launch sequence: a failed launch (hipGetLastError) or a failed cross-stream event operation surfaces here
+#define STEP_DONE(e)                                                 \
+    do {                                                             \
+        const hipError_t se_ = (e)->soft_err;                        \
+        (e)->soft_err = hipSuccess;                                  \
+        HIPCHK(se_);                                                 \
+        HIPCHK(hipGetLastError());                                   \
+    } while (0)
+
 
 namespace {
 
@@ -1069,18 +1083,18 @@ void backward_and_step(fm_engine* e, int groups, int B)
     hipStream_t main_st = e->st;
     auto side_begin = [&](int k, int par) {
         if (!sw) return;
-        (void)hipEventRecord(e->ev_p[k][par], main_st);
-        (void)hipStreamWaitEvent(e->st2, e->ev_p[k][par], 0);
+        soft(e, hipEventRecord(e->ev_p[k][par], main_st));
+        soft(e, hipStreamWaitEvent(e->st2, e->ev_p[k][par], 0));
         e->st = e->st2;
         std::swap(e->ws_slab, e->ws_slab2);
     };
     auto side_end = [&](int k, int par) {
         if (!sw) return;
         std::swap(e->ws_slab, e->ws_slab2);
-        (void)hipEventRecord(e->ev_c[k][par], e->st2);
+        soft(e, hipEventRecord(e->ev_c[k][par], e->st2));
         e->st = main_st;
     };
-    auto guard = [&](int k, int par) { if (sw) (void)hipStreamWaitEvent(main_st, e->ev_c[k][par], 0); };
+    auto guard = [&](int k, int par) { if (sw) soft(e, hipStreamWaitEvent(main_st, e->ev_c[k][par], 0)); };
     k_fc_bwd(e->dlogits, e->feat, S + e->off_fcw, nullptr, e->grad + e->off_fcw, e->grad + e->off_fcb, e->GA, DT_F32, imgs,
              512, e->C, cl.hout * cl.wout, e->st);
     float *ga = e->GA, *ge = e->GE;
@@ -1118,8 +1132,8 @@ void backward_and_step(fm_engine* e, int groups, int B)
     bn_bwd(e, 0, e->dyh0, nullptr, e->dyh0, nullptr, groups, B);
     conv_wgrad(e, 0, e->x4, e->dyh0, imgs);
     if (sw) {
-        (void)hipEventRecord(e->ev_wdone, e->st2);
-        (void)hipStreamWaitEvent(main_st, e->ev_wdone, 0);
+        soft(e, hipEventRecord(e->ev_wdone, e->st2));
+        soft(e, hipStreamWaitEvent(main_st, e->ev_wdone, 0));
     }
     adam_step(e);      // optimizer.step()
 }
@@ -1298,18 +1312,18 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     hipStream_t main_st = e->st;
     auto side_begin = [&](int k, int par) {          // main has produced tensor k of parity par
         if (!sw) return;
-        (void)hipEventRecord(e->ev_p[k][par], main_st);
-        (void)hipStreamWaitEvent(e->st2, e->ev_p[k][par], 0);
+        soft(e, hipEventRecord(e->ev_p[k][par], main_st));
+        soft(e, hipStreamWaitEvent(e->st2, e->ev_p[k][par], 0));
         e->st = e->st2;
         std::swap(e->ws_slab, e->ws_slab2);
     };
     auto side_end = [&](int k, int par) {
         if (!sw) return;
         std::swap(e->ws_slab, e->ws_slab2);
-        (void)hipEventRecord(e->ev_c[k][par], e->st2);
+        soft(e, hipEventRecord(e->ev_c[k][par], e->st2));
         e->st = main_st;
     };
-    auto guard = [&](int k, int par) { if (sw) (void)hipStreamWaitEvent(main_st, e->ev_c[k][par], 0); };
+    auto guard = [&](int k, int par) { if (sw) soft(e, hipStreamWaitEvent(main_st, e->ev_c[k][par], 0)); };
     e->ctx = 500;
     { OP("k_fc_bwd"); k_fc_bwd(e->dlogits, h, S + e->off_fcw, e->drop_dev, G + e->off_fcw, G + e->off_fcb, e->T_mid, e->dt, imgs, e->D, e->C,
              HWh, e->st); }
@@ -1382,8 +1396,8 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
     { OP("bnact_bwd"); bnact_bwd(e, e->bn_stem, go, cs.y, go, nullptr, groups, B * cs.hout * cs.wout, cs.hout * cs.wout, 2); }
     { OP("conv_wgrad"); conv_wgrad(e, e->c_stem, e->x4, go, imgs); }
     if (sw) {                                    // every weight gradient is in G before the optimizer reads it
-        (void)hipEventRecord(e->ev_wdone, e->st2);
-        (void)hipStreamWaitEvent(main_st, e->ev_wdone, 0);
+        soft(e, hipEventRecord(e->ev_wdone, e->st2));
+        soft(e, hipStreamWaitEvent(main_st, e->ev_wdone, 0));
     }
     { OP("adam_step"); adam_step(e); }
 }
@@ -1511,7 +1525,7 @@ int fm_sync(fm_engine* e)
 {
     ARGCHK(e, "null engine");
     HIPCHK(hipStreamSynchronize(e->st));
-    HIPCHK(hipGetLastError());
+    STEP_DONE(e);
     return FM_OK;
 }
 
@@ -1747,7 +1761,7 @@ int fm_step_bce(fm_engine* e, const float* x_dev, const float* y_dev, int32_t B,
     k_loss_bce(e->logits, y_dev, to_cv(pos_weight_host, e->C), B, e->C, 1.f / ((float)bs_norm * (float)e->C),
                e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 1, B);
-    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
+    STEP_DONE(e);
     return FM_OK;
 }
 
@@ -1775,7 +1789,7 @@ int fm_step_stage1(fm_engine* e, const float* x1_dev, const float* x2_dev, const
                   1.f / ((float)bs_norm * (float)annotation_num),
                   n_neg ? 1.f / ((float)bs_norm * (float)n_neg) : 0.f, e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 2, B);
-    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
+    STEP_DONE(e);
     return FM_OK;
 }
 
@@ -1789,7 +1803,7 @@ int fm_step_stage2(fm_engine* e, const float* x_dev, const float* y_dev, const f
     net_forward_train(e, 1, B);
     k_loss_stage2(e->logits, y_dev, distill_dev, B, e->C, e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 1, B);
-    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
+    STEP_DONE(e);
     return FM_OK;
 }
 
@@ -1809,7 +1823,7 @@ int fm_step_fixmatch(fm_engine* e, const float* xw_dev, const float* xs_dev, con
                     to_cv(active_mask_host, e->C), B, e->C, n_neg, 1.f / ((float)bs_norm * (float)annotation_num),
                     e->C - annotation_num, e->dlogits, loss_dev, e->st);
     net_backward_and_step(e, 2, B);
-    HIPCHK(hipGetLastError());      // a failed launch surfaces here, not at the next fm_sync
+    STEP_DONE(e);
     return FM_OK;
 }
 
@@ -1916,7 +1930,7 @@ int fm_forward_train(fm_engine* e, const float* x1_dev, const float* x2_dev, int
     if (logits_dev)
         HIPCHK(hipMemcpyAsync(logits_dev, e->logits, (size_t)views * B * e->C * 4, hipMemcpyDeviceToDevice, e->st));
     e->pending_views = views; e->pending_B = B;
-    HIPCHK(hipGetLastError());
+    STEP_DONE(e);
     return FM_OK;
 }
 
@@ -1928,7 +1942,7 @@ int fm_backward_step(fm_engine* e, const float* dlogits_dev)
     HIPCHK(hipMemcpyAsync(e->dlogits, dlogits_dev, (size_t)views * B * e->C * 4, hipMemcpyDeviceToDevice, e->st));
     net_backward_and_step(e, views, B);
     e->pending_views = 0;
-    HIPCHK(hipGetLastError());
+    STEP_DONE(e);
     return FM_OK;
 }
 
