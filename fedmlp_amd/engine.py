@@ -149,6 +149,9 @@ class Engine:
         buf = (C.c_uint8 * _lib.FM_COMM_ID_BYTES)(*unique_id)
         _lib.check(self.lib.fm_comm_init(self.h, buf, int(rank), int(world)))
 
+    def comm_destroy(self):
+        _lib.check(self.lib.fm_comm_destroy(self.h))
+
     def comm_size(self):
         return int(self.lib.fm_comm_size(self.h))
 

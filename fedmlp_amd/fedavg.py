@@ -97,9 +97,29 @@ def comm_init(engine):
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return 1
-    box = [engine.comm_unique_id() if d.get_rank() == 0 else None]
+    # Every rank must end up on the SAME path (library communicator or torch.distributed fallback), so failures are
+    # agreed on: rank 0 ships None when it cannot draw an id, and after fm_comm_init the ranks take the minimum of
+    # their success flags; if any rank failed, those that succeeded drop their communicator and all of them raise.
+    box = [None]
+    if d.get_rank() == 0:
+        try:
+            box = [engine.comm_unique_id()]
+        except Exception:                                    # noqa: BLE001
+            box = [None]
     d.broadcast_object_list(box, src=0)
-    engine.comm_init(box[0], d.get_rank(), d.get_world_size())
+    if box[0] is None:
+        raise RuntimeError("fm_comm_unique_id failed on rank 0")
+    err = None
+    try:
+        engine.comm_init(box[0], d.get_rank(), d.get_world_size())
+    except Exception as ex:                                  # noqa: BLE001
+        err = ex
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=engine.device)
+    d.all_reduce(ok, op=d.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if err is None:
+            engine.comm_destroy()
+        raise RuntimeError(f"fm_comm_init failed on at least one rank ({err})")
     return engine.comm_size()
 
 

@@ -87,3 +87,61 @@ def test_allreduce_forms_match_reference_surface(tmp_path):
         np.testing.assert_allclose(got["tao"], want_tao, rtol=1e-12)
         np.testing.assert_allclose(got["proto"], want_proto, rtol=2e-6, atol=1e-7, equal_nan=True)
         assert np.isnan(got["proto"][4:]).all()          # classes without an active client
+
+
+# ---- comm_init: every rank must end up on the same path -------------------------------------------------
+class FakeCommEngine:
+    """stand-in with the four communicator methods fedavg.comm_init touches"""
+    device = "cpu"
+
+    def __init__(self, fail_init=False, fail_id=False):
+        self.fail_init, self.fail_id, self.size, self.destroyed = fail_init, fail_id, 0, False
+
+    def comm_unique_id(self):
+        if self.fail_id:
+            raise RuntimeError("no RCCL")
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        assert uid == bytes(range(128))
+        if self.fail_init:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.size = world
+
+    def comm_destroy(self):
+        self.destroyed, self.size = True, 0
+
+    def comm_size(self):
+        return self.size
+
+
+def _comm_worker(rank, port, out_dir, case):
+    from fedmlp_amd.fedavg import comm_init
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    eng = FakeCommEngine(fail_init=(case == "init_fails_on_rank1" and rank == 1), fail_id=(case == "id_fails" and rank == 0))
+    try:
+        res = ("ok", comm_init(eng))
+    except RuntimeError as ex:
+        res = ("raised", str(ex))
+    with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
+        f.write(f"{res[0]}|{res[1]}|{eng.comm_size()}|{int(eng.destroyed)}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["all_fine", "init_fails_on_rank1", "id_fails"])
+def test_comm_init_failure_is_agreed_on_by_all_ranks(tmp_path, case):
+    """A library communicator that forms on some ranks only would leave the ranks on different all-reduce paths
+    (deadlock): comm_init either returns the rank count everywhere or raises everywhere, and a rank whose own
+    fm_comm_init succeeded drops its communicator again."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_comm_worker, args=(port, str(tmp_path), case), nprocs=WORLD, join=True)
+    res = [open(os.path.join(str(tmp_path), f"c{r}.txt")).read().split("|") for r in range(WORLD)]
+    if case == "all_fine":
+        assert [r[0] for r in res] == ["ok", "ok"] and [r[2] for r in res] == ["2", "2"]
+    else:
+        assert [r[0] for r in res] == ["raised", "raised"], res
+        assert [r[2] for r in res] == ["0", "0"], res               # nobody keeps a communicator
+        if case == "init_fails_on_rank1":
+            assert res[0][3] == "1"                                  # rank 0 had one and destroyed it
