@@ -490,10 +490,19 @@ int bn_bwd_blocks(int pix_per_group)
     return max(1, min(cap, cdiv(pix_per_group, 64)));
 }
 
+// ReLU mask of dz: from z (the stored post-activation, z > 0) or -- msc/msh given, z null -- recomputed from the conv
+// output the kernel reads anyway: relu(bn(y)) > 0  <=>  y*scale + shift > 0 with the forward's own per-group scale /
+// shift and the same fused multiply-add bn_apply_kernel uses (bit-identical mask, one tensor read less).
+__device__ __forceinline__ f32x4 relu_mask_from_y(f32x4 d, f32x4 yy, f32x4 sc, f32x4 sh)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(yy[k], sc[k], sh[k]) > 0.f ? d[k] : 0.f;
+    return d;
+}
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                      const float* __restrict__ y, const float* __restrict__ mean,
                                      const float* __restrict__ istd, float* __restrict__ part, int pix_per_group,
-                                     int C)
+                                     int C, const float* __restrict__ msc, const float* __restrict__ msh)
 {
     __shared__ f32x4 red[2][256];
     const int g = blockIdx.y, nblk = gridDim.x;
@@ -505,6 +514,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* 
     const size_t base = (size_t)g * pix_per_group * C;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + cq * 4);
     const f32x4 is = *reinterpret_cast<const f32x4*>(istd + g * C + cq * 4);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+    if (msc) {
+        sc = *reinterpret_cast<const f32x4*>(msc + g * C + cq * 4);
+        sh = *reinterpret_cast<const f32x4*>(msh + g * C + cq * 4);
+    }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (int t0 = blockIdx.x * TP; t0 < pix_per_group; t0 += nblk * TP)
 #pragma unroll 4
@@ -516,7 +530,9 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = zz[k] > 0.f ? d[k] : 0.f;
         }
-        const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + o) - mu) * is;
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+        if (msc) d = relu_mask_from_y(d, yy, sc, sh);
+        const f32x4 xh = (yy - mu) * is;
         s1 += d;
         s2 += d * xh;
     }
@@ -534,10 +550,12 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* 
     }
 }
 void k_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* istd,
-                     float* part, int groups, int pix_per_group, int C, hipStream_t s)
+                     float* part, int groups, int pix_per_group, int C, hipStream_t s, const float* mask_scale,
+                     const float* mask_shift)
 {
     dim3 grid(bn_bwd_blocks(pix_per_group), groups);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, s, dz, z, y, mean, istd, part, pix_per_group, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, s, dz, z, y, mean, istd, part, pix_per_group, C,
+                       mask_scale, mask_shift);
 }
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int groups, int nblk, int C, int count,
@@ -598,7 +616,8 @@ void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                     const float* __restrict__ y, const float* __restrict__ ca,
                                     const float* __restrict__ cb, const float* __restrict__ cc, float* dy,
-                                    float* dyh_out, int pix_per_group, int C)
+                                    float* dyh_out, int pix_per_group, int C, const float* __restrict__ msc,
+                                    const float* __restrict__ msh)
 {
     const int g = blockIdx.y;
     const int Q = C >> 2;
@@ -618,6 +637,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
             for (int k = 0; k < 4; ++k) d[k] = zz[k] > 0.f ? d[k] : 0.f;
         }
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+        if (msc)
+            d = relu_mask_from_y(d, yy, *reinterpret_cast<const f32x4*>(msc + g * C + cq * 4),
+                                 *reinterpret_cast<const f32x4*>(msh + g * C + cq * 4));
         const f32x4 r = a4[cq] * d + b4[cq] * yy + c4[cq];
         if (dyh_out) *reinterpret_cast<f32x4*>(dyh_out + o) = d;
         *reinterpret_cast<f32x4*>(dy + o) = r;
@@ -625,12 +647,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* _
 }
 void k_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* ca, const float* cb,
                     const float* cc, float* dy, float* dyh_out, int groups, int pix_per_group, int C,
-                    hipStream_t s)
+                    hipStream_t s, const float* mask_scale, const float* mask_shift)
 {
     int64_t n4 = (int64_t)pix_per_group * (C / 4);
     dim3 grid(cdiv(n4, 256), groups);   // one 16-B element per thread: 6.3 TB/s vs 4.7 for a capped grid-stride loop (tools/ew_bw.hip)
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dz, z, y, ca, cb, cc, dy, dyh_out,
-                       pix_per_group, C);
+                       pix_per_group, C, mask_scale, mask_shift);
 }
 
 // ------------------------------------------------------------ optimiser --------

@@ -939,17 +939,23 @@ void bn_fwd_finalize(fm_engine* e, int ci, int groups, int imgs_per_group)
 }
 
 // backward through BN bi: dz (+ optional relu mask source z) -> dy ; optional masked grad out
+// z_is_relu_of_bn: z = relu(bn(y)) of THIS BatchNorm with nothing added (bn1 of a basic block): the ReLU mask is then
+// recomputed from y, which both passes read anyway, and z is not read (FM_BN_MASK_FROM_Y=0 reads z as before)
 void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, float* dyh_out, int groups,
-            int imgs_per_group)
+            int imgs_per_group, bool z_is_relu_of_bn = false)
 {
     const Conv& c = e->convs[bi];
     Bn& b = e->bns[bi];
     const int pix = imgs_per_group * c.hout * c.wout;
-    k_bn_bwd_reduce(dz, z, c.y, b.mean, b.istd, e->ws_part, groups, pix, b.C, e->st);
+    const char* fy = getenv("FM_BN_MASK_FROM_Y");          // read per call: tests compare both forms in one process
+    const int from_y = fy ? atoi(fy) : 1;
+    const float *msc = nullptr, *msh = nullptr;
+    if (z_is_relu_of_bn && z && from_y) { msc = b.scale; msh = b.shift; z = nullptr; }
+    k_bn_bwd_reduce(dz, z, c.y, b.mean, b.istd, e->ws_part, groups, pix, b.C, e->st, msc, msh);
     k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix), b.C, pix, e->state + e->off_gamma + b.ch_off, b.mean,
                       b.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b.ch_off,
                       e->grad + e->off_beta + b.ch_off, e->st);
-    k_bn_bwd_apply(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyh_out, groups, pix, b.C, e->st);
+    k_bn_bwd_apply(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyh_out, groups, pix, b.C, e->st, msc, msh);
 }
 
 void to_nhwc4(fm_engine* e, const float* const* xs, int groups, int B)
@@ -1112,7 +1118,7 @@ void backward_and_step(fm_engine* e, int groups, int B)
         side_end(0, par);
         guard(2, par);
         conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false);
-        bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B);
+        bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true);
         side_begin(2, par);
         conv_wgrad(e, blk.c1, in, GD, imgs);
         side_end(2, par);

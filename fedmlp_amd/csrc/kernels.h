@@ -59,8 +59,10 @@ void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* i
                      int imgs, int H, int W, int C, hipStream_t s);
 // backward: partial sums of dyh = dz*(z>0) and dyh*xhat -> part[groups][nblk][2][C]
 int bn_bwd_blocks(int pix_per_group);
+// ReLU mask of dz: z > 0 (z = stored post-activation), or, with z null and mask_scale / mask_shift given, y*scale+shift > 0
 void k_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* istd,
-                     float* part, int groups, int pix_per_group, int C, hipStream_t s);
+                     float* part, int groups, int pix_per_group, int C, hipStream_t s,
+                     const float* mask_scale = nullptr, const float* mask_shift = nullptr);
 // coefficients ca,cb,cc [groups][C]; dgamma/dbeta written (summed over groups)
 void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count, const float* gamma,
                        const float* mean, const float* istd, float* ca, float* cb, float* cc,
@@ -68,7 +70,7 @@ void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count
 // dy = ca*dyh + cb*y + cc ; optionally store dyh
 void k_bn_bwd_apply(const float* dz, const float* z, const float* y, const float* ca, const float* cb,
                     const float* cc, float* dy, float* dyh_out, int groups, int pix_per_group, int C,
-                    hipStream_t s);
+                    hipStream_t s, const float* mask_scale = nullptr, const float* mask_shift = nullptr);
 
 // ---- EfficientNet-B0 path (effnet.hip): any C % 4 == 0, act 0 none / 1 relu / 2 swish ---------
 // Activation tensors are fp32 or bf16 in HBM (DT_F32 / DT_BF16, common.h); arithmetic is fp32.  `ty` is the

@@ -340,3 +340,30 @@ def test_stage1_two_stream_teacher_equals_one_stream(monkeypatch):
     for k in (1, 2):
         np.testing.assert_array_equal(outs[0][1], outs[k][1])
         np.testing.assert_array_equal(outs[0][0], outs[k][0])
+
+
+def test_relu_mask_from_conv_output_is_bit_identical(monkeypatch):
+    """bn1's backward recomputes the ReLU mask from the conv output (y*scale + shift > 0, the forward's own fused
+    multiply-add) instead of reading the stored activation: the same bits after three stage-1 steps as with
+    FM_BN_MASK_FROM_Y=0, which reads the activation."""
+    (x1, x2), y = _data(6, 45, views=2)
+    mask = [0.0, 1.0, 0.0, 0.0, 0.0]
+    outs = []
+    e = None
+    from fedmlp_amd.engine import Engine
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("FM_BN_MASK_FROM_Y", mode)
+            _load(e)
+            e.teacher_snapshot()
+            lo = torch.zeros(3, device="cuda")
+            for s_ in range(3):
+                e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo[s_:s_ + 1])
+            flat, _ = e.get_state()
+            outs.append((flat.copy(), lo.cpu().numpy().copy(), e.debug_get_grads().copy()))
+    finally:
+        e.close()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
