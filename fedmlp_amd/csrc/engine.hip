@@ -351,7 +351,7 @@ int build_tables(fm_engine* e)
             j.ntaps = d.taps.n;
             for (int t = 0; t < d.taps.n; ++t) j.taps[t] = d.taps.t[t];
             j.blk0 = blk;
-            blk += (int)(((size_t)c.cin_p * d.taps.n * c.cout_p + 255) / 256);
+            blk += pack_job_blocks(c.cout_p, c.cin_p, d.taps.n);
             jobs.push_back(j);
         }
     if (e->precision) {        // bf16 shadows (W and W^T) of every 1x1 convolution

@@ -28,6 +28,7 @@ void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList tap
 // all data-gradient weight packs of a step in one launch: job j fills jobs[j].out from state + jobs[j].w_off
 struct PackJob { long long w_off; float* out; int Co, T, Ci, ntaps; int taps[9]; int blk0; };
 void k_pack_dgrad_all(const float* state, const PackJob* jobs, int njobs, int nblocks, hipStream_t s);
+int pack_job_blocks(int Co, int Ci, int ntaps);      // blocks of one job (32 x 32 tiles per tap); PackJob.blk0 = running sum
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
 void k_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);   // y = a*y + b*x
 
