@@ -725,13 +725,17 @@ int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
     if (odd32(2 * a.S) < 32 * CCi) a.strideS = odd32(32 * CCi);
     const int tilesL = (a.L + 63) / 64;
     const int tsteps = (w.npix + 31) / 32;
-    // blocks per launch / 32-pixel steps per block: every split writes an fp32 [64][S] partial tile that reduce_slabs reads
-    // back, so 2048 blocks of >= 8 steps (round 2's first setting) moved more slab bytes than activations for the
-    // late, channel-heavy layers.  Measured bf16 bs 512 step: 2048/8 60.68, 1024/16 60.54, 768/24 60.47, 512/32 60.20 ms.
+    // Splits of the pixel axis.  Every split leaves an fp32 [M][K] partial that reduce_slabs reads back.  The late,
+    // channel-heavy layers (1 152 x 192: 885 KB per split) run 512 blocks of >= 32 steps -- at 2 048 blocks they moved
+    // more slab bytes than activations (bf16 bs-512 step 59.1 -> 58.3 ms) -- while layers whose partial is small
+    // (<= FM_PW_WG_SMALL_KB, default 64: the early high-resolution ones, 24 x 96 = 12 KB) keep 2 048 blocks of >= 8 steps:
+    // their gate / BN prologue is issue-bound and needs every SIMD busy (at 512 blocks the two largest ran 0.78 -> 1.9 ms).
     static const int wg_blocks = getenv("FM_PW_WG_BLOCKS") ? atoi(getenv("FM_PW_WG_BLOCKS")) : 512;
     static const int wg_minsteps = getenv("FM_PW_WG_MINSTEPS") ? atoi(getenv("FM_PW_WG_MINSTEPS")) : 32;
-    int splits = std::max(1, wg_blocks / tilesL);
-    splits = std::min(splits, std::max(1, tsteps / wg_minsteps));
+    static const int wg_small_kb = getenv("FM_PW_WG_SMALL_KB") ? atoi(getenv("FM_PW_WG_SMALL_KB")) : 64;
+    const bool small_partial = (size_t)w.M * w.K * 4 <= ((size_t)wg_small_kb << 10);
+    int splits = std::max(1, (small_partial ? 2048 : wg_blocks) / tilesL);
+    splits = std::min(splits, std::max(1, tsteps / (small_partial ? 8 : wg_minsteps)));
     splits = (int)std::min<size_t>(splits, std::max<size_t>(1, slab_floats / ((size_t)w.M * w.K)));
     const size_t lds = (size_t)2 * (32 * WG_STRIDE_BIG + 32 * a.strideS);
     static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
