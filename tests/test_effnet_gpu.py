@@ -530,3 +530,33 @@ def test_build_model_call_surface():
     assert fe.shape == (3, 1280) and ze.shape == (3, C_)
     np.testing.assert_allclose(fe.cpu().numpy(), f.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(ze.cpu().numpy(), z.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("precision", ["bf16"])
+def test_row_blocked_bn_act_passes_are_bit_identical(monkeypatch, precision):
+    """FM_EW_ROWS (default on, bf16 storage): BN + activation apply / backward-apply with four pixels per thread and the
+    per-channel parameters loaded once.  Pure re-tiling of an elementwise pass: the same bits after two stage-1 steps
+    as the one-piece-per-thread kernels (FM_EW_ROWS=0)."""
+    from fedmlp_amd.engine import Engine
+    e = Engine(M, C_, 96, 96, 16, precision=precision)
+    e.stochastic = False
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn((6, 3, 96, 96), generator=g).cuda(); x2 = torch.randn((6, 3, 96, 96), generator=g).cuda()
+    y = (torch.rand((6, C_), generator=g) < 0.3).float().cuda()
+    outs = []
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("FM_EW_ROWS", mode)
+            _load(e)
+            e.set_stochastic(None, None)
+            e.teacher_snapshot()
+            lo = torch.zeros(2, device="cuda")
+            for s_ in range(2):
+                e.step_stage1(x1, x2, y, [0.0, 1.0, 0.0, 0.0, 0.0], 1, 8, lo[s_:s_ + 1])
+            flat, _ = e.get_state()
+            outs.append((flat.copy(), lo.cpu().numpy().copy(), e.debug_get_grads().copy()))
+    finally:
+        e.close()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
