@@ -91,10 +91,14 @@ __global__ void bnact_apply_kernel(const TY* __restrict__ y, const float* __rest
 // still one contiguous run of P*Q pieces, a block covers one contiguous chunk of EW_R*P pixels (DRAM locality), and
 // the per-element arithmetic is untouched (bit-identical results).
 constexpr int EW_R = 4;
-static inline bool ew_rows_on(int Q)
+// FM_EW_ROWS (bf16 storage, default 3) / FM_EW_ROWS_F32 (fp32 storage, default 1): bit 0 = apply pass, bit 1 =
+// backward-apply pass.  Measured per step: bf16 58.5 -> 57.1 ms, all of it from the backward-apply (14 parameter loads
+// per 2 data loads); fp32 apply 58.35 -> 58.04, fp32 backward-apply 58.35 -> 58.85 (slower: stays one piece per thread).
+static inline bool ew_rows_on(int Q, int nv, int pass_bit)
 {
-    const char* v = getenv("FM_EW_ROWS");            // read per call (tests compare both forms in one process)
-    return !(v && atoi(v) == 0) && Q >= 1 && Q <= 256;
+    const char* v = getenv(nv == 2 ? "FM_EW_ROWS" : "FM_EW_ROWS_F32");      // read per call (tests compare both forms in one process)
+    const int mode = v ? atoi(v) : (nv == 2 ? 3 : 1);
+    return (mode & pass_bit) && Q >= 1 && Q <= 256;
 }
 template <typename TY, typename TA>
 __global__ __launch_bounds__(256) void bnact_apply_rows_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
@@ -149,7 +153,7 @@ void k_bnact_apply(const void* y, int ty, const float* scale, const float* shift
 {
     const int nv = (ty == DT_BF16 && ta == DT_BF16) ? 2 : 1;
     const int Q = C / (4 * nv);
-    if (nv == 2 && ew_rows_on(Q)) {      // fp32 storage: 2 parameter loads per data load only, measured 0.2 ms slower per step
+    if (ew_rows_on(Q, nv, 1)) {
         const int T = (256 / Q) * Q;
         const dim3 rgrid(cdiv((int64_t)pix_per_group * Q, (int64_t)EW_R * T), groups);
         if (ty == DT_F32 && ta == DT_F32)
@@ -412,7 +416,7 @@ void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const floa
 {
     const int nv = (ty == DT_BF16 && ta == DT_BF16) ? 2 : 1;
     const int Q = C / (4 * nv);
-    if (nv == 2 && ew_rows_on(Q)) {      // fp32 storage: 2 parameter loads per data load only, measured 0.2 ms slower per step
+    if (ew_rows_on(Q, nv, 2)) {
         const int T = (256 / Q) * Q;
         const dim3 rgrid(cdiv((int64_t)pix_per_group * Q, (int64_t)EW_R * T), groups);
         if (ty == DT_F32 && ta == DT_F32)

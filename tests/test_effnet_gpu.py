@@ -532,11 +532,11 @@ def test_build_model_call_surface():
     np.testing.assert_allclose(ze.cpu().numpy(), z.numpy(), rtol=2e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("precision", ["bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_row_blocked_bn_act_passes_are_bit_identical(monkeypatch, precision):
-    """FM_EW_ROWS (default on, bf16 storage): BN + activation apply / backward-apply with four pixels per thread and the
-    per-channel parameters loaded once.  Pure re-tiling of an elementwise pass: the same bits after two stage-1 steps
-    as the one-piece-per-thread kernels (FM_EW_ROWS=0)."""
+    """FM_EW_ROWS / FM_EW_ROWS_F32: BN + activation apply (bit 0) and backward-apply (bit 1) with four pixels per thread
+    and the per-channel parameters loaded once.  Pure re-tiling of an elementwise pass: the same bits after two
+    stage-1 steps with both passes row-blocked (3) as with the one-piece-per-thread kernels (0)."""
     from fedmlp_amd.engine import Engine
     e = Engine(M, C_, 96, 96, 16, precision=precision)
     e.stochastic = False
@@ -545,8 +545,8 @@ def test_row_blocked_bn_act_passes_are_bit_identical(monkeypatch, precision):
     y = (torch.rand((6, C_), generator=g) < 0.3).float().cuda()
     outs = []
     try:
-        for mode in ("1", "0"):
-            monkeypatch.setenv("FM_EW_ROWS", mode)
+        for mode in ("3", "0"):
+            monkeypatch.setenv("FM_EW_ROWS" if precision == "bf16" else "FM_EW_ROWS_F32", mode)
             _load(e)
             e.set_stochastic(None, None)
             e.teacher_snapshot()
