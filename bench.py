@@ -15,6 +15,12 @@ usage: python bench.py --gpus N --steps K --warmup W
   (python -m torch.distributed.run ... bench.py, one rank per GPU) before touching
   the GPU and exits with their code.  Rank 0 prints ONE JSON line.
 
+Streams: the engine's default mode enqueues the frozen teacher's forward and the weight gradients on its own
+side stream (same bits as one stream, +3-4 %); that is what `value` times.  Co-running kernels stretch each
+other's launch windows, so the per-kernel durations behind `roofline` come from a ONE-stream engine: a short
+separate pass after the timed region (roofline.measured_in says so), or the timed region itself with
+--one-stream -- the form to run under rocprofv3, whose per-kernel averages then agree with the line.
+
 Other legs (same JSON contract, named in config.workload):
   --workload conv_fwd --batch 256     eval-mode forward only: the north-star "conv forward at
                                        bs=256" MFMA-roofline number (928.5 GFLOP per pass)
@@ -44,7 +50,7 @@ PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (
 # minimum activation bytes per image of one EfficientNet-B0 forward
 EFFNET_FWD_BYTES = {"fp32": 73.8e6, "bf16": 36.9e6}
 RESNET_FWD_FLOP = 3.627e9             # 2 x 1 813 561 344 conv MACs per 224x224 image
-PMC_FILE = os.path.join("profiles", "r02", "pmc_traffic.json")
+PMC_FILES = [os.path.join("profiles", r, "pmc_traffic.json") for r in ("r03", "r02")]
 
 
 def parse(argv=None):
@@ -63,6 +69,13 @@ def parse(argv=None):
     ap.add_argument("--round-steps", type=int, default=40, help="steps per FL round (5000/128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="engine stream mode 1: every kernel on one stream, roofline measured inside the timed region "
+                         "(use this under rocprofv3: per-kernel durations of co-running kernels describe no kernel alone)")
+    ap.add_argument("--roofline-steps", type=int, default=12,
+                    help="steps of the separate one-stream roofline pass (default mode only)")
+    ap.add_argument("--cpu-threads", default="16,32,64,all",
+                    help="thread counts tried by the cpu_baseline leg (the best one is reported)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="HIP events bracket the conv launches of every Nth timed step (each pair costs ~3 us of "
                          "stream time: on every step that is 0.7 ms of a 39-ms ResNet-18 step)")
@@ -82,9 +95,10 @@ def physical_cores():
 
 def cpu_baseline(args):
     """The oracle (torch CPU fp32 restatement of the same step arithmetic) timed on this host: a
-    bounded sample, ~10-30 s of CPU work.  The micro-batch is the reference's own CPU-runnable
-    batch (configs[0]: bs 32) unless --batch is smaller; the rate is per image, so it compares
-    directly with `value`."""
+    bounded sample, ~10 s of CPU work per thread count tried; the best thread count is reported
+    (all cores oversubscribe oneDNN on a 128-core host).  The micro-batch is the reference's own
+    CPU-runnable batch (configs[0]: bs 32) unless --batch is smaller; the rate is per image, so it
+    compares directly with `value`."""
     from oracle import steps_ref as R
     from tests.helpers import oracle_net
     import copy
@@ -118,25 +132,40 @@ def cpu_baseline(args):
             loss = R.loss_train(z, y, [1.0] * args.classes, args.batch, args.classes)
         opt.zero_grad(); loss.backward(); opt.step()
 
-    step()                                   # warm-up (allocator, oneDNN primitives)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step(); n += 1
-        dt = time.perf_counter() - t0
-        if dt > 12.0 or n >= 20:
-            break
-    return {"value": round(n * B / dt, 3), "unit": "images/sec", "cores": physical_cores(),
-            "threads": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} oracle {args.workload} steps at micro-batch {B} (config batch {args.batch}; the loss "
-                      f"normaliser is the config batch), 3x{args.hw}x{args.hw}, torch CPU fp32, same step "
-                      f"arithmetic, no DataLoader; {dt:.1f} s"}
+    cores, avail = physical_cores(), torch.get_num_threads()
+    cand = []
+    for t in args.cpu_threads.split(","):
+        n = max(avail, cores) if t.strip() == "all" else int(t)
+        n = max(1, min(n, max(avail, cores)))
+        if n not in cand:
+            cand.append(n)
+    tried, best = {}, None
+    for nt in cand:
+        torch.set_num_threads(nt)
+        step()                               # warm-up (allocator, oneDNN primitives for this thread count)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step(); n += 1
+            dt = time.perf_counter() - t0
+            if dt > 6.0 or n >= 10:
+                break
+        rate = n * B / dt
+        tried[str(nt)] = round(rate, 3)
+        if best is None or rate > best[0]:
+            best = (rate, nt, n, dt)
+    torch.set_num_threads(avail)
+    rate, nt, n, dt = best
+    return {"value": round(rate, 3), "unit": "images/sec", "cores": cores, "threads": nt, "micro_batch": B,
+            "images_per_sec_by_threads": tried, "kind": "port",
+            "sample": f"best of thread counts {cand}: {n} oracle {args.workload} steps at micro-batch {B} (config batch "
+                      f"{args.batch}; the loss normaliser is the config batch), 3x{args.hw}x{args.hw}, torch CPU fp32, same "
+                      f"step arithmetic, no DataLoader; {dt:.1f} s at {nt} threads"}
 
 
 def family_traffic(prefix, args):
     """launch-weighted mean HBM bytes per launch over every profiled kernel whose name contains `prefix`"""
     try:
-        with open(os.path.join(ROOT, PMC_FILE)) as f:
-            doc = json.load(f).get(workload_key(args))
+        doc = pmc_doc(args)[0]
         ks = [v for k, v in doc["kernels"].items()
               if prefix in k.replace(" ", "").replace("false", "0").replace("true", "1")]   # (older profiles: bool STEM)
         n = sum(v["launches"] for v in ks)
@@ -145,44 +174,49 @@ def family_traffic(prefix, args):
         return None
 
 
-def under_profiler():
-    """true inside `rocprofv3 ... -- python3 bench.py` (the tool preloads its library and exports ROCPROF* variables)"""
-    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
-        return True
-    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+def pmc_doc(args):
+    """(entry of this workload, file it came from) from the newest committed rocprofv3 PMC summary that has one"""
+    for rel in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                doc = json.load(f).get(workload_key(args))
+            if doc is not None:
+                return doc, rel
+        except Exception:
+            continue
+    return None, PMC_FILES[0]
 
 
-def two_stream_extra(args, eng, step_fn, B, max_images, dev):
-    """ResNet-18's optional two-stream mode (FM_SIDE_TEACHER=2: frozen teacher + weight gradients on a side stream,
-    bit-identical results), timed on a second engine after the main region.  It is NOT the default -- and not `value` --
-    because co-running MFMA kernels stretch each other's launch windows, so the per-kernel durations behind `roofline`
-    stop describing a kernel alone."""
-    import torch
+def read_families(eng):
+    return [eng.profile_read(f) for f in range(NFAM)]
+
+
+def one_stream_roofline_pass(args, eng, step_fn, max_images, dev):
+    """ResNet-18: per-kernel durations from a second engine in stream mode 1 (every kernel alone on the chip), same state,
+    same inputs, HIP events around every conv launch of `--roofline-steps` steps.  Returns (families, ms_per_step)."""
     from fedmlp_amd.engine import Engine
-    os.environ["FM_SIDE_TEACHER"] = "2"
-    try:
-        e2 = Engine(args.model, args.classes, args.hw, args.hw, max_images, device=dev)
-    finally:
-        del os.environ["FM_SIDE_TEACHER"]
+    e1 = Engine(args.model, args.classes, args.hw, args.hw, max_images, device=dev, streams=1)
     try:
         flat, cnt = eng.get_state()
-        e2.set_state(flat, cnt)
-        e2.teacher_snapshot()
-        e2.adam_reset(3e-5)
-        n, w = 20, 5
+        e1.set_state(flat, cnt)
+        e1.teacher_snapshot()
+        e1.adam_reset(3e-5)
+        n, w = max(1, args.roofline_steps), 3
         for i in range(w):
-            step_fn(i, i, e2)
+            step_fn(i, i, e1)
         torch.cuda.synchronize()
+        e1.profile_enable(True)
+        read_families(e1)
         t0 = time.perf_counter()
         for i in range(n):
-            step_fn(i, w + i, e2)
+            step_fn(i, w + i, e1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        fams = read_families(e1)
+        e1.profile_enable(False)
     finally:
-        e2.close()
-    return {"env": "FM_SIDE_TEACHER=2", "steps": n, "ms_per_step": round(dt / n * 1e3, 4),
-            "images_per_sec_per_client": round(B * n / dt, 3),
-            "note": "teacher forward and weight gradients on a side stream; same bits as the default one-stream order"}
+        e1.close()
+    return fams, dt / n * 1e3
 
 
 def measured_traffic(kernel_name, args):
@@ -190,17 +224,13 @@ def measured_traffic(kernel_name, args):
     committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate passes over this
     same command, FETCH_SIZE doubled per MI355X_MICROARCH.md); null when the workload differs from
     the profiled one."""
-    try:
-        with open(os.path.join(ROOT, PMC_FILE)) as f:
-            doc = json.load(f).get(workload_key(args))
-        if doc is None:
-            return None
-        key = kernel_name.replace(" ", "")
-        for k, v in doc["kernels"].items():
-            if key in k.replace(" ", "").replace("false", "0").replace("true", "1"):     # (older profiles: bool STEM)
-                return v["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        pass
+    doc, _ = pmc_doc(args)
+    if doc is None:
+        return None
+    key = kernel_name.replace(" ", "")
+    for k, v in doc["kernels"].items():
+        if key in k.replace(" ", "").replace("false", "0").replace("true", "1"):     # (older profiles: bool STEM)
+            return v["hbm_bytes_per_launch_corrected"]
     return None
 
 
@@ -232,21 +262,19 @@ def main():
 
     B, C = args.batch, args.classes
     views = 2 if args.workload == "stage1" else 1
-    eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev), precision=args.precision)
+    eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev), precision=args.precision,
+                 streams=1 if args.one_stream else 0)
     flat, cnt = spec.init_state(args.model, C, 1037)
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
     eng.adam_reset(3e-5)
     rccl_ranks = 1
     if world > 1:
-        # RCCL communicator inside the C-ABI library (fm_comm_init); if it cannot be formed on this node the same
-        # all-reduce runs through torch.distributed's RCCL communicator on the engine's arena (fedavg.py)
-        try:
-            rccl_ranks = comm_init(eng)
-        except Exception as ex:                              # noqa: BLE001
-            print(f"[bench] fm_comm_init failed ({ex}); FedAvg falls back to torch.distributed all_reduce",
-                  file=sys.stderr, flush=True)
-            rccl_ranks = 0
+        # RCCL communicator inside the C-ABI library (fm_comm_init, dlopen'ed librccl)
+        # a record of the wrong path is worse than no record: --gpus N measures the in-library RCCL all-reduce or fails
+        rccl_ranks = comm_init(eng)
+        if rccl_ranks != world:
+            raise SystemExit(f"[bench] library RCCL communicator has {rccl_ranks} ranks, --gpus {world}")
     # Efficient_b0: the engine draws drop-connect / dropout multipliers before every train step
 
     # synthetic client data resident in HBM (seed = reference default, utils/options.py:10)
@@ -281,9 +309,19 @@ def main():
         else:
             en.forward_eval_into(x1[j], feat_out, logit_out)
 
-    def fedavg():
+    # per-kernel HIP events inside the timed region only where the launches of one stream do not overlap others'
+    in_region = (not args.no_profile) and (args.one_stream or args.workload == "conv_fwd" or args.model == "Efficient_b0")
+    ar_ev = []                                   # (start, end) events around every FedAvg all-reduce of the timed region
+
+    def fedavg(timed=False):
         if world > 1 and args.workload != "conv_fwd":
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
             fedavg_allreduce(eng, 1.0 / world)
+            if timed:
+                b.record()
+                ar_ev.append((a, b))
 
     for i in range(args.warmup):
         step(i, i)
@@ -291,36 +329,56 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    if not args.no_profile:
+    if in_region:
         eng.profile_enable(True)
-        for f in range(NFAM):
-            eng.profile_read(f)
+        read_families(eng)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pe = max(1, args.profile_every)
     for i in range(args.steps):
-        if not args.no_profile and pe > 1:
+        if in_region and pe > 1:
             eng.profile_enable(i % pe == 0)
         step(i, args.warmup + i)
         if (i + 1) % args.round_steps == 0 and i + 1 < args.steps:
-            fedavg()
-    fedavg()
+            fedavg(True)
+    fedavg(True)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0           # this rank's own steps + all-reduces (before the closing barrier)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar_ev)
+        mine = torch.tensor([dt_rank * 1e3 / args.steps, ar_ms, float(len(ar_ev))], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step_incl_allreduce": round(v[0].item(), 4),
+                     "allreduce_ms_total": round(v[1].item(), 3), "allreduces": int(v[2].item())}
+                    for r, v in enumerate(allr)]
 
     roof = None
     if not args.no_profile:
-        fams = [eng.profile_read(f) for f in range(NFAM)]
-        eng.profile_enable(False)
+        sampled, one_stream_ms = None, None
+        if in_region:
+            fams = read_families(eng)
+            eng.profile_enable(False)
+            measured_in = "the timed region" + (" (engine stream mode 1: one stream)" if args.one_stream else "")
+            sampled = (f"HIP events around the conv launches of every {pe}th step of the timed region" if pe > 1
+                       else "HIP events around every conv launch of the timed region")
+        else:
+            fams, one_stream_ms = one_stream_roofline_pass(args, eng, step, views * B, str(dev))
+            measured_in = (f"a separate one-stream pass of {max(1, args.roofline_steps)} steps after the timed region (second "
+                           f"engine, stream mode 1, same state and inputs): in the default two-stream mode co-running kernels "
+                           f"stretch each other's launch windows; `python bench.py --one-stream` times that mode itself")
+            sampled = "HIP events around every conv launch of the one-stream pass"
         allk = {KERNEL_NAMES[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
                                   "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
                 for f in range(NFAM)}
+        pmc_file = pmc_doc(args)[1]
         if args.model == "Efficient_b0":
             # HBM-bound model: whole-step algorithmic activation bytes over the step time
             n_fwd = {"stage1": 4 * B, "train": B, "stage2": B, "conv_fwd": B}[args.workload]
@@ -329,7 +387,7 @@ def main():
             gbs = alg / (dt / args.steps) / 1e9
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": measured_traffic("whole_step", args),
-                    "traffic_source": PMC_FILE + " (separate rocprofv3 --pmc passes, not this run)",
+                    "traffic_source": pmc_file + " (separate rocprofv3 --pmc passes, not this run)",
                     "kernel": "whole step (all kernels of one step; no single kernel dominates)",
                     "algorithmic_bytes_per_step": alg, "mfma_kernels": allk}
         else:
@@ -345,11 +403,14 @@ def main():
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(name, args),
-                    "traffic_source": PMC_FILE + " (separate rocprofv3 --pmc passes, not this run)",
+                    "traffic_source": pmc_file + " (separate rocprofv3 --pmc passes, not this run)",
                     "kernel": name, "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
-                    "sampled": f"HIP events around the conv launches of every {pe}th step of the timed region"
-                               if pe > 1 else "HIP events around every conv launch of the timed region",
-                    "all_kernels": allk}
+                    "measured_in": measured_in, "sampled": sampled, "all_kernels": allk}
+            if one_stream_ms is not None:
+                roof["one_stream_ms_per_step"] = round(one_stream_ms, 4)
+                steps_alg = {"stage1": 28.55e9, "train": 10.65e9, "stage2": 10.65e9}[args.workload] * B
+                roof["whole_step_tflops"] = round(steps_alg / (dt / args.steps) / 1e12, 3)
+                roof["whole_step_frac"] = round(steps_alg / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             if args.workload == "conv_fwd":
                 roof["traffic"] = family_traffic("igemm_kernel<", args)     # mean over the 20 conv launches of a pass
                 roof["algorithmic_flop_per_pass"] = RESNET_FWD_FLOP * B
@@ -372,17 +433,13 @@ def main():
                                       f"FedAvg all-reduce every {args.round_steps} steps + once at end",
                           "images_per_sec_per_client": round(B * args.steps / dt, 3),
                           "views_per_sec": round(views * total / dt, 3), "parallelism": f"clients{world}",
+                          "stream_mode": "one stream (--one-stream)" if args.one_stream else
+                                         "default: frozen teacher + weight gradients on the engine's side stream",
                           "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3)},
                "roofline": roof,
                "last_loss": float(lv[-1])}
-        if world == 1 and args.model == "Resnet18" and args.workload != "conv_fwd" and not args.no_profile \
-                and os.environ.get("FM_SIDE_TEACHER") is None:
-            if under_profiler():
-                # the extra leg co-runs kernels on two streams: inside a rocprofv3 --stats run its stretched launch
-                # windows would be averaged into the per-kernel durations the roofline line is checked against
-                out["config"]["two_stream_mode"] = {"skipped": "running under rocprofv3"}
-            else:
-                out["config"]["two_stream_mode"] = two_stream_extra(args, eng, step, B, views * B, str(dev))
+        if per_rank is not None:
+            out["config"]["per_rank"] = per_rank
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         else:

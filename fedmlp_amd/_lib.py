@@ -66,6 +66,7 @@ SYMBOLS = {
     "fm_profile_enable": (C.c_int, [_P, _I32]),
     "fm_profile_read": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double)]),
+    "fm_comm_preflight": (C.c_int, []),
     "fm_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "fm_comm_init": (C.c_int, [_P, C.POINTER(C.c_uint8), _I32, _I32]),
     "fm_comm_destroy": (C.c_int, [_P]),

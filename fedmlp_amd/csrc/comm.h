@@ -4,6 +4,7 @@
 #include <stddef.h>
 
 const char* fmcomm_error();
+bool fmcomm_preflight();      // dlopen librccl and resolve its entry points: local, not a collective
 bool fmcomm_unique_id(unsigned char id[128]);
 bool fmcomm_init(void** comm, const unsigned char id[128], int rank, int world);
 bool fmcomm_destroy(void* comm);

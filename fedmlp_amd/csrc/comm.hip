@@ -77,6 +77,7 @@ bool chk(int rc, const char* what)
 }  // namespace
 
 const char* fmcomm_error() { return g_api.err.c_str(); }
+bool fmcomm_preflight() { return load_api(); }
 
 bool fmcomm_unique_id(unsigned char id[128])
 {

@@ -131,7 +131,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 // small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
 int igemm_max_blocks();
-void launch_wgrad(const WgradParams& p, int splits, hipStream_t s);
+bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s);    // false = split exceeds the 32-bit offset span
 int wgrad_tile_n(int M, int Nw);
 // 1x1 stride-1 convs with min(M, Nw) <= 128: returns the splits written to p.slab, 0 = not handled
 int launch_wgrad_skinny(const WgradParams& p, size_t slab_floats, hipStream_t s);

@@ -189,6 +189,7 @@ struct fm_engine {
     double* comm_buf = nullptr;       // device scratch of the small all-reduces
     size_t comm_buf_n = 0;
     int precision = 0;                // 0 fp32 activations, 1 bf16 activations (EfficientNet-B0 only)
+    int stream_mode = 0;              // fm_config.reserved[1]: 0 side stream for teacher + weight gradients, 1 one stream, 2 teacher only
     int dt = DT_F32;                  // storage type of activations / their gradients (DT_F32 or DT_BF16)
     bf16 *wb = nullptr, *twb = nullptr;   // bf16 weight shadows of the student / the teacher (1x1 convs, W and W^T)
     size_t wb_numel = 0;
@@ -252,6 +253,16 @@ int aalloc(fm_engine* e, float** p, size_t n) { return dalloc(e, p, e->precision
         int rc_ = aalloc(e, &(p), (n));                \
         if (rc_ != FM_OK) return rc_;                  \
     } while (0)
+
+// The engine's side stream runs at the LOWEST priority: the caller's stream carries the dependent chain (student forward,
+// BatchNorm / data-gradient chain) whose short bandwidth-bound kernels should be dispatched first; the side stream's
+// teacher forward / weight gradients fill what is left (ResNet-18 stage-1 step 37.7 -> 37.1 ms; highest priority: 38.3)
+hipError_t create_side_stream(hipStream_t* st)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
+}
 
 int upload_tab(fm_engine* e, const std::vector<int4>& h, int4** d)
 {
@@ -622,7 +633,7 @@ int alloc_workspaces(fm_engine* e)
         DALLOC(e->se_dgp, B * max_ce); DALLOC(e->se_drp, B * max_cs); DALLOC(e->se_ds, B * max_ce);
         DALLOC(e->se_pool, B * 16 * 5 * max_ce);       // [imgs][<=16 chunks][5 sums][C]
         {
-            int side = getenv("FM_SIDE_TEACHER") ? atoi(getenv("FM_SIDE_TEACHER")) : 1;     // read per engine
+            int side = e->stream_mode != 1;          // fm_config.reserved[1]: 0 two streams, 1 one stream, 2 teacher only
             if (side) {
                 // the second buffer sets roughly double the activation footprint: keep one stream when they would not fit
                 // next to what is still to be allocated (slabs, statistics: < 2 GB) with 4 GB to spare
@@ -647,11 +658,11 @@ int alloc_workspaces(fm_engine* e)
                 AALLOC(e->t_Tmid, t_mid);
                 DALLOC(e->t_se_pool, B * 16 * max_ce);
                 DALLOC(e->t_rec, (size_t)16 << 20);           // pooling records of the eval depthwise forward (<= 33 MB)
-                HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+                HIPCHK(create_side_stream(&e->st2));
                 HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&e->ev_t, hipEventDisableTiming));
                 e->side_ok = true;
-                const int sidew = getenv("FM_SIDE_WGRAD") ? atoi(getenv("FM_SIDE_WGRAD")) : 1;
+                const int sidew = e->stream_mode == 0;
                 if (sidew) {
                     AALLOC(e->T_small2, t_small); AALLOC(e->T_mid2, t_mid); AALLOC(e->T_big2, t_big);
                     DALLOC(e->se_dgp2, B * max_ce); DALLOC(e->se_drp2, B * max_cs);
@@ -682,16 +693,15 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->sk_counters, (size_t)1 << 20);
     HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
     {
-        const int side = getenv("FM_SIDE_TEACHER") ? atoi(getenv("FM_SIDE_TEACHER")) : 1;     // read per engine
+        const int side = e->stream_mode != 1;
         if (side) {
             DALLOC(e->sk_slab2, (size_t)igemm_max_blocks() * 2 * 16384);
             DALLOC(e->sk_counters2, (size_t)1 << 20);
             HIPCHK(hipMemset(e->sk_counters2, 0, ((size_t)1 << 20) * 4));
-            // ResNet-18 (MFMA-bound, persistent 512-block kernels): measured 40.70 -> 39.54 ms per stage-1 step with the teacher
-            // on the side stream, but co-running kernels stretch each other's launch windows, so the per-kernel HIP-event /
-            // rocprof durations behind bench.py's roofline line stop describing a kernel alone (0.716 -> 0.49 for the same
-            // code).  Default: EfficientNet only (its roofline is the whole step); FM_SIDE_TEACHER=2 turns it on here too.
-            if (e->model == 0 && side >= 2) {
+            // ResNet-18 (MFMA-bound, persistent 512-block kernels): 39.0 -> 37.7 ms per stage-1 step with the teacher and the
+            // weight gradients on the side stream, same bits.  Co-running kernels stretch each other's launch windows, so
+            // per-kernel durations (bench.py's roofline, rocprofv3) are taken from a one-stream engine (stream mode 1).
+            if (e->model == 0) {
                 const Conv& c0 = e->convs[0];
                 const size_t pooled = B * (c0.hout / 2) * (c0.wout / 2) * 64;
                 DALLOC(e->t_c0y, B * c0.hout * c0.wout * c0.cout_p);
@@ -702,11 +712,11 @@ int alloc_workspaces(fm_engine* e)
                     DALLOC(blk.t_z1, n); DALLOC(blk.t_out, n);
                     if (blk.ds >= 0) DALLOC(blk.t_dsy, n);
                 }
-                HIPCHK(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+                HIPCHK(create_side_stream(&e->st2));
                 HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&e->ev_t, hipEventDisableTiming));
                 e->side_ok = true;
-                const int sidew = getenv("FM_SIDE_WGRAD") ? atoi(getenv("FM_SIDE_WGRAD")) : 1;
+                const int sidew = e->stream_mode == 0;
                 if (sidew) {
                     DALLOC(e->GB2, pooled); DALLOC(e->GC2, pooled); DALLOC(e->GD2, pooled);
                     DALLOC(e->ws_slab2, e->slab_floats);
@@ -919,7 +929,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
     splits = (p.npix + p.pix_per_split - 1) / p.pix_per_split;
     {
         ProfScope ps(e, c.cout_p >= 128 ? 3 : (c.cin == 3 ? 5 : 4), 2.0 * c.macs_per_img * imgs);
-        launch_wgrad(p, splits, e->st);
+        if (!launch_wgrad(p, splits, e->st)) soft(e, hipErrorInvalidValue);     // surfaces through STEP_DONE as FM_ERR_HIP
     }
     k_reduce_slabs(e->ws_slab, e->grad + c.w_off, splits, (int64_t)c.w_numel, e->st);
     if (c.stem3) k_stem3_mask_grad(e->grad + c.w_off, c.cout_p, e->st);
@@ -1490,8 +1500,10 @@ int fm_create(const fm_config* cfg, fm_engine** out)
     ARGCHK(cfg->max_images >= 1, "max_images");
     ARGCHK(cfg->reserved[0] == 0 || (cfg->reserved[0] == 1 && cfg->model == 1),
            "precision (reserved[0]) must be 0 (fp32) or, for EfficientNet-B0, 1 (bf16 activations)");
+    ARGCHK(cfg->reserved[1] >= 0 && cfg->reserved[1] <= 2 && cfg->reserved[2] == 0, "reserved[1] (stream mode) must be 0, 1 or 2; reserved[2] must be 0");
     fm_engine* e = new fm_engine();
     e->precision = cfg->reserved[0];
+    e->stream_mode = cfg->reserved[1];
     e->dt = e->precision ? DT_BF16 : DT_F32;
     e->fuse_gate = e->precision && !(getenv("FM_FUSE_GATE") && atoi(getenv("FM_FUSE_GATE")) == 0);
     e->cfg = *cfg;
@@ -1626,6 +1638,12 @@ int fm_state_scale(fm_engine* e, float w)
     do {                                                 \
         if (!(x)) { g_err = fmcomm_error(); return FM_ERR_HIP; } \
     } while (0)
+
+int fm_comm_preflight(void)
+{
+    COMMCHK(fmcomm_preflight());
+    return FM_OK;
+}
 
 int fm_comm_unique_id(uint8_t* id128)
 {

@@ -402,7 +402,8 @@ int wgrad_tile_n(int M, int Nw)
     return (t192 && (Nw % 192 == 0 || Nw <= 192)) ? 192 : 256;      // Nw = 176: the packed 7x7 stem
 }
 
-void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
+// false: the split is too large for the kernel's 32-bit buffer offsets (nothing launched; the caller reports the error)
+bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
 {
     static bool attr_done = false;
     constexpr int LDS_L = 2 * 32 * (128 + 128) * 4 + 1024;   // + 64 x 16 B dummy slots
@@ -420,7 +421,7 @@ void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
         const size_t spanB = ((size_t)p.pix_per_split / ((size_t)p.Ho * p.Wo) + 3) * p.Hi * p.Wi * p.Ci * 4;
         if (spanA >= (1ull << 31) || spanB >= (1ull << 31) || spanB / ((size_t)p.Ci * 4) >= (1ull << 23)) {
             fprintf(stderr, "fedmlp_hip: wgrad split too large for 32-bit buffer offsets (%zu / %zu bytes)\n", spanA, spanB);
-            abort();
+            return false;
         }
     }
     dim3 grid(p.tilesM * p.tilesN, splits);
@@ -430,4 +431,5 @@ void launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
         hipLaunchKernelGGL((wgrad_kernel<64, 192, 4, 3>), grid, dim3(256), LDS_T, s, p);
     else
         hipLaunchKernelGGL((wgrad_kernel<64, 256, 4>), grid, dim3(256), LDS_S, s, p);
+    return true;
 }

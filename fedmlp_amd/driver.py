@@ -25,11 +25,11 @@ def args_parser():
     p.add_argument("--batch_size", type=int, default=32)
     p.add_argument("--base_lr", type=float, default=3e-5)
     p.add_argument("--annotation_num", type=int, default=1)
-    p.add_argument("--n_clients", type=int, default=5)
-    p.add_argument("--n_classes", type=int, default=5)
+    p.add_argument("--n_clients", type=int, default=8)            # utils/options.py:34
+    p.add_argument("--n_classes", type=int, default=8)            # utils/options.py:36
     p.add_argument("--local_ep", type=int, default=1)
-    p.add_argument("--rounds_warmup", type=int, default=4)
-    p.add_argument("--rounds_FedMLP_stage1", type=int, default=2)
+    p.add_argument("--rounds_warmup", type=int, default=500)      # utils/options.py:42
+    p.add_argument("--rounds_FedMLP_stage1", type=int, default=50)    # utils/options.py:46
     p.add_argument("--U", type=float, default=0.7)
     p.add_argument("--L", type=float, default=0.3)
     p.add_argument("--clean_threshold", type=float, default=0.005)
@@ -39,7 +39,10 @@ def args_parser():
     p.add_argument("--hw", type=int, default=224)
     p.add_argument("--gpus", type=int, default=1, help="ranks = GPUs; clients are dealt round-robin over them")
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"], help="bf16: Efficient_b0 only")
-    p.add_argument("--pretrained", type=int, default=0, help="1: ImageNet checkpoint through build_model (utils/options.py:26)")
+    p.add_argument("--streams", type=int, default=0, help="engine stream mode (fm_config.reserved[1]): 0 default, 1 one stream")
+    p.add_argument("--pretrained", type=int, default=1,
+                   help="utils/options.py:26: ImageNet checkpoint through build_model (a warning and the from-scratch init "
+                        "when no checkpoint file is on this machine)")
     p.add_argument("--pretrained_path", default=None)
     p.add_argument("--init_ckpt", default=None, help="torch.save(state_dict) file to start from (main.py:361-367)")
     p.add_argument("--save_every", type=int, default=0, help="save netglob.state_dict() every N rounds (main.py:237)")
@@ -78,6 +81,52 @@ class DeviceDataset:
         return self._v
 
 
+class RoundAccumulator:
+    """One round's aggregation (main.py:216-234: FedAvg, FedAvg_tao, FedAvg_proto) split over ranks.  A rank that trains
+    several clients folds them first -- state and counters with the weights n_c / sum(n), tao / prototype numerators
+    with n_c per class the client misses / annotates -- then every sum over ranks is ONE all-reduce
+    (fedmlp_amd/fedavg.py: the library's RCCL communicator, or torch.distributed).  With one rank it reproduces the
+    reference's single-process loop; the world-2 gloo test pins both against utils/FedAvg.py's surface."""
+
+    def __init__(self, state_like, n_counters, C, D, n_total):
+        self.acc = torch.zeros_like(state_like)
+        self.acc_cnt = np.zeros(n_counters, np.float64)
+        self.C, self.n_total = C, float(n_total)
+        self.t = np.zeros(C); self.tn = np.zeros(C)              # FedAvg_tao numerators / weights of this rank
+        self.p = torch.zeros((2 * C, D)); self.pn = np.zeros(C)  # FedAvg_proto numerators / weights
+
+    def add(self, n_c, state, counters, active_class_list, ret):
+        w = n_c / self.n_total
+        self.acc.add_(state, alpha=w)                            # FedAvg numerator (utils/FedAvg.py:9-13)
+        self.acc_cnt += w * np.asarray(counters, np.float64)
+        if len(ret) == 8:                                        # (..., t, proto) of a prototype pass
+            neg = np.array([0.0 if k in active_class_list else 1.0 for k in range(self.C)])
+            act = 1.0 - neg
+            self.t += np.asarray(ret[6]) * n_c * neg; self.tn += n_c * neg
+            pa = np.repeat(act, 2)
+            self.p += torch.where(torch.from_numpy(pa > 0)[:, None], torch.as_tensor(ret[7]) * n_c, torch.zeros(()))
+            self.pn += n_c * act
+
+    def reduce(self, eng, dev, with_tao_proto):
+        """-> (global num_batches_tracked counters, tao or None, Prototype or None); the averaged state is in the engine"""
+        from fedmlp_amd.fedavg import fedavg_allreduce, tao_allreduce, proto_allreduce
+        eng.state_tensor().copy_(self.acc)
+        eng.counters(np.zeros(len(self.acc_cnt), np.int64))      # the counters are reduced as float64 below
+        fedavg_allreduce(eng, 1.0)                               # fm_fedavg_allreduce: ncclAllReduce of the state arena
+        cnt = np.trunc(rank_sum(self.acc_cnt, dev) + 1e-9).astype(np.int64)   # utils/FedAvg.py:13 + load_state_dict
+        eng.counters(cnt)
+        if not with_tao_proto:
+            return cnt, None, None
+        # FedAvg_tao / FedAvg_proto (utils/FedAvg.py:51-93): this rank enters with its folded clients' means and, per
+        # class, the weight sum(n_c) of its clients that miss / annotate the class
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t_rank = np.where(self.tn > 0, self.t / np.where(self.tn > 0, self.tn, 1.0), 0.0)
+            p_rank = self.p.numpy() / np.repeat(np.where(self.pn > 0, self.pn, 1.0), 2)[:, None].astype(np.float32)
+        tao = tao_allreduce(t_rank, 1.0, self.tn, device=dev, engine=eng)
+        proto = proto_allreduce(p_rank, 1.0, self.pn, device=dev, engine=eng)
+        return cnt, tao, proto
+
+
 def main():
     args = args_parser()
     from fedmlp_amd.launch import launched_by_torchrun, spawn_ranks
@@ -105,7 +154,8 @@ def main():
 
     C, S1 = args.n_classes, args.rounds_FedMLP_stage1
     args.feature_dim = args.feature_dim or spec.FEATURE_DIM[args.model]
-    eng = Engine(args.model, C, args.hw, args.hw, 4 * args.batch_size, device=str(dev), precision=args.precision)
+    eng = Engine(args.model, C, args.hw, args.hw, 4 * args.batch_size, device=str(dev), precision=args.precision,
+                 streams=args.streams)
     try:
         comm_init(eng)                                    # the library's own RCCL communicator (C ABI)
     except Exception as ex:                               # noqa: BLE001  (then torch.distributed carries the sums)
@@ -132,16 +182,12 @@ def main():
     log = []
     for rnd in range(args.rounds_warmup):
         t0 = time.perf_counter()
-        acc = torch.zeros_like(glob)
-        acc_cnt = np.zeros(len(glob_cnt), np.float64)
-        t_loc = np.zeros(C); tn_loc = np.zeros(C)         # this rank's FedAvg_tao / FedAvg_proto numerators
-        p_loc = torch.zeros((2 * C, args.feature_dim)); pn_loc = np.zeros(C)
+        acc = RoundAccumulator(glob, len(glob_cnt), C, args.feature_dim, float(sum(n_all)))
         losses = []
         for c in mine:
             loc = clients[c]
             eng.state_tensor().copy_(glob)                # net = deepcopy(netglob)  (main.py:181-184)
             eng.counters(glob_cnt)
-            w = n_all[c] / float(sum(n_all))
             if args.exp == "FedAVG":
                 ret = loc.train(rnd, net, None)
             elif args.exp == "FedAVG+FixMatch":
@@ -152,32 +198,12 @@ def main():
                 ret = loc.train_FedMLP(rnd, tao, Prototype, None, loc.negative_class_list,
                                        loc.active_class_list, net=net)
             losses.append(float(ret[1]))
-            acc.add_(eng.state_tensor(), alpha=w)         # FedAvg numerator (utils/FedAvg.py:9-13)
-            acc_cnt += w * eng.counters().astype(np.float64)
-            if len(ret) == 8:                             # several clients on one rank: fold them first
-                neg = np.array([0.0 if k in loc.active_class_list else 1.0 for k in range(C)])
-                act = 1.0 - neg
-                t_loc += ret[6] * n_all[c] * neg; tn_loc += n_all[c] * neg
-                pa = np.repeat(act, 2)
-                p_loc += torch.where(torch.from_numpy(pa > 0)[:, None], ret[7] * n_all[c], torch.zeros(()))
-                pn_loc += n_all[c] * act
-        # ---- aggregation (main.py:216-234): every sum over clients is an RCCL all-reduce in the library.
-        # A rank that trained several clients has already folded them (weights n_c / sum(n)) into `acc`.
-        eng.state_tensor().copy_(acc)
-        eng.counters(np.zeros(len(glob_cnt), np.int64))   # the counters are reduced as float64 below
-        from fedmlp_amd.fedavg import fedavg_allreduce
-        fedavg_allreduce(eng, 1.0)                        # fm_fedavg_allreduce: ncclAllReduce of the state arena
+            acc.add(n_all[c], eng.state_tensor(), eng.counters(), loc.active_class_list, ret)
+        # ---- aggregation (main.py:216-234): every sum over clients is an RCCL all-reduce in the library
+        glob_cnt, tao_new, proto_new = acc.reduce(eng, dev, with_tao_proto=(args.exp == "FedMLP" and rnd >= S1 - 1))
         glob.copy_(eng.state_tensor())
-        glob_cnt = np.trunc(rank_sum(acc_cnt, dev) + 1e-9).astype(np.int64)   # utils/FedAvg.py:13 + load_state_dict
-        eng.counters(glob_cnt)
-        if args.exp == "FedMLP" and rnd >= S1 - 1:
-            # FedAvg_tao / FedAvg_proto (utils/FedAvg.py:51-93): this rank enters with its folded clients'
-            # means and, per class, the weight sum(n_c) of its clients that miss / annotate the class
-            with np.errstate(invalid="ignore", divide="ignore"):
-                t_rank = np.where(tn_loc > 0, t_loc / np.where(tn_loc > 0, tn_loc, 1.0), 0.0)
-                p_rank = p_loc.numpy() / np.repeat(np.where(pn_loc > 0, pn_loc, 1.0), 2)[:, None].astype(np.float32)
-            tao = tao_allreduce(t_rank, 1.0, tn_loc, device=dev, engine=eng)
-            Prototype = proto_allreduce(p_rank, 1.0, pn_loc, device=dev, engine=eng)
+        if tao_new is not None:
+            tao, Prototype = tao_new, proto_new
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         rec = {"round": rnd, "sec": round(dt, 3), "mean_loss": float(np.mean(losses)) if losses else None,

@@ -26,7 +26,9 @@ class Engine:
     """One per process/GPU. Owns the device-resident model state, optimiser
     moments, teacher snapshot and activation workspaces for `max_images`."""
 
-    def __init__(self, model, n_classes, in_h, in_w, max_images, device=None, precision="fp32"):
+    def __init__(self, model, n_classes, in_h, in_w, max_images, device=None, precision="fp32", streams=0):
+        """streams: fm_config.reserved[1] -- 0 the engine forks its side stream for the frozen teacher and the weight
+        gradients (default, bit-identical to one stream), 1 one stream (per-kernel profiling), 2 teacher only."""
         if not torch.cuda.is_available():
             raise RuntimeError("fedmlp_amd.Engine needs a GPU (no CPU fallback)")
         self.lib = _lib.load()
@@ -40,8 +42,13 @@ class Engine:
         self.precision = precision
         if precision != "fp32" and model != "Efficient_b0":
             raise ValueError("precision 'bf16' is built for Efficient_b0 only (BASELINE configs[4])")
+        # the engine enqueues on torch's CURRENT stream of this device (0 = the null stream when it is the default one),
+        # so its kernels are ordered with the torch ops around the calls
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.streams = int(streams)
         cfg = _lib.FmConfig(MODEL_IDS[model], self.n_classes, self.in_h, self.in_w,
-                            self.max_images, (C.c_int32 * 3)(PRECISION_IDS[precision], 0, 0), None)
+                            self.max_images, (C.c_int32 * 3)(PRECISION_IDS[precision], self.streams, 0),
+                            C.c_void_p(self.stream) if self.stream else None)
         h = C.c_void_p()
         _lib.check(self.lib.fm_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -140,6 +147,10 @@ class Engine:
         return feat, logits
 
     # ---- RCCL inside the C-ABI library (utils/FedAvg.py:7-14, 51-93 across ranks) ---------
+    def comm_preflight(self):
+        """librccl loadable and complete on THIS rank (local; fm_comm_init is the collective step)."""
+        _lib.check(self.lib.fm_comm_preflight())
+
     def comm_unique_id(self):
         buf = (C.c_uint8 * _lib.FM_COMM_ID_BYTES)()
         _lib.check(self.lib.fm_comm_unique_id(buf))

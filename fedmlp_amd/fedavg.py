@@ -100,6 +100,17 @@ def comm_init(engine):
     # Every rank must end up on the SAME path (library communicator or torch.distributed fallback), so failures are
     # agreed on: rank 0 ships None when it cannot draw an id, and after fm_comm_init the ranks take the minimum of
     # their success flags; if any rank failed, those that succeeded drop their communicator and all of them raise.
+    # (0) non-collective preflight, agreed on before any rank enters ncclCommInitRank: a rank that cannot load librccl
+    # would otherwise leave its peers blocked inside the collective init, never reaching the agreement below
+    pre = None
+    try:
+        engine.comm_preflight()
+    except Exception as ex:                                  # noqa: BLE001
+        pre = ex
+    ok0 = torch.tensor([0 if pre is not None else 1], dtype=torch.int32, device=engine.device)
+    d.all_reduce(ok0, op=d.ReduceOp.MIN)
+    if int(ok0.item()) == 0:
+        raise RuntimeError(f"fm_comm_preflight failed on at least one rank ({pre})")
     box = [None]
     if d.get_rank() == 0:
         try:

@@ -244,7 +244,10 @@ def build_model(args):
             import torch as _t
             sd = _t.load(path, map_location="cpu")
             res = net.load_state_dict(sd, strict=False)
-            bad = [k for k in res.missing_keys + res.mismatched_keys if k not in spec.classifier_keys(net.model)]
+            # torchvision's / efficientnet-pytorch's published ImageNet files carry no `num_batches_tracked` entries: torch's
+            # BatchNorm leaves a missing counter at 0 (the reference loads such files), and so does merge_state_dict
+            bad = [k for k in res.missing_keys + res.mismatched_keys
+                   if k not in spec.classifier_keys(net.model) and not k.endswith(".num_batches_tracked")]
             if bad:
                 raise RuntimeError(f"build_model: {path} does not match {net.model}: {bad[:6]}")
     return net

@@ -52,7 +52,12 @@ typedef struct fm_config {
                              utils/local_training.py:14 imports autocast and never uses it);
                              1 bf16 activation storage + bf16 MFMA for the 1x1 convolutions, fp32
                              accumulation / BN statistics / master weights / Adam -- EfficientNet-B0
-                             only (BASELINE configs[4]).  reserved[1..2] must be 0. */
+                             only (BASELINE configs[4]).
+                             reserved[1] = stream mode: 0 (default) the frozen teacher's forward and the
+                             backward's weight gradients are enqueued on an engine-owned side stream that is
+                             forked from and joined to `stream` inside every call (same bits as one stream);
+                             1 = everything on `stream` (use for per-kernel profiling); 2 = teacher forward on
+                             the side stream only.  reserved[2] must be 0. */
     void*   stream;       /* hipStream_t; NULL = null stream                         */
 } fm_config;
 
@@ -96,6 +101,10 @@ int fm_state_scale(fm_engine* e, float w);
  * fm_comm_size returns the rank count (0 = no communicator).  Without a communicator (or with a
  * world of 1) the fm_fedavg_* calls compute the single-client result locally. */
 #define FM_COMM_ID_BYTES 128
+/* Local, non-collective: load librccl and resolve its entry points.  fm_comm_init is a collective (ncclCommInitRank
+ * blocks until every rank has entered it), so call this on every rank first and agree on the result over the
+ * transport that ships the id: a rank whose RCCL cannot be loaded must not leave its peers waiting inside the init. */
+int fm_comm_preflight(void);
 int fm_comm_unique_id(uint8_t* id128);
 int fm_comm_init(fm_engine* e, const uint8_t* id128, int32_t rank, int32_t world);
 int fm_comm_destroy(fm_engine* e);

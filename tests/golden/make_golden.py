@@ -74,6 +74,29 @@ class FixedLoader(torch.utils.data.DataLoader):
 
 LT.DataLoader = FixedLoader
 
+# ---- taps on the reference's tagging step (utils/local_training.py:1052-1112): the similarity row the reference
+# ranks (the first argument of max_m_indices, one call per tagged class) and the pool it was computed over
+# (find_indices_in_a, stage-2 rounds after the first).  Recorded so that the GPU replays can judge a differing pick by
+# the REFERENCE's own margin at the selection boundary.
+SIM_TAP, POOL_TAP = [], []
+_max_m = LT.max_m_indices
+_find = LT.LocalUpdate.find_indices_in_a
+
+
+def _max_m_tap(lst, n):
+    SIM_TAP.append(np.asarray(lst, dtype=np.float32))
+    return _max_m(lst, n)
+
+
+def _find_tap(self, a, b):
+    r = _find(self, a, b)
+    POOL_TAP.append(a[r].to(torch.int64).numpy().copy())
+    return r
+
+
+LT.max_m_indices = _max_m_tap
+LT.LocalUpdate.find_indices_in_a = _find_tap
+
 
 class SynthDataset(torch.utils.data.Dataset):
     """Output contract of dataset/all_dataset.py:64-83 on synthetic tensors."""
@@ -293,8 +316,17 @@ def g_fedmlp_traj(out, C=4, n_cl=2, N=512, hw=32, data_seed=23, order_seed=202, 
                 locals_[i].ldr_train = FixedLoader(locals_[i].local_dataset, 32, True)
                 ORDERS.append(to)        # consumed by the DatasetSplit_pseudo loader (:1167)
                 r["feat_orders"].append(fo); r["train_orders"].append(to)
+                del SIM_TAP[:], POOL_TAP[:]
                 ret = locals_[i].train_FedMLP(rnd, tao, Prototype, None, neg_lists[i],
                                               act_lists[i], net=deepcopy(netglob))
+                # the reference's similarity row and pool (dataset indices) of every class tagged this round
+                first = rnd == args.rounds_FedMLP_stage1
+                assert len(SIM_TAP) == len(neg_lists[i]) and (first or len(POOL_TAP) == len(neg_lists[i]))
+                for k in range(len(neg_lists[i])):
+                    pool = np.asarray([users[i][p] for p in fo], dtype=np.int64) if first else POOL_TAP[k]
+                    assert len(pool) == len(SIM_TAP[k])
+                    protos_npz[f"r{rnd}_c{i}_k{k}_sim"] = SIM_TAP[k].copy()
+                    protos_npz[f"r{rnd}_c{i}_k{k}_pool"] = pool.astype(np.int32)
                 r.setdefault("traindata_idx", []).append(
                     [[int(v) for v in lst] for lst in locals_[i].traindata_idx])
                 r.setdefault("class_num_list", []).append(list(locals_[i].class_num_list))
@@ -323,12 +355,34 @@ def g_fedmlp_traj(out, C=4, n_cl=2, N=512, hw=32, data_seed=23, order_seed=202, 
         rec["rounds"].append(r)
     json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
     np.savez_compressed(os.path.join(out, name + "_protos.npz"), **protos_npz)
+    report_margins(rec, protos_npz, args)
+
+
+def report_margins(rec, P, args):
+    """the reference's own margins at every selection boundary (gap between the last pick and the first non-pick, as a
+    fraction of the similarity row's range): what decides whether an implementation with different rounding picks the same sets"""
+    worst = 1.0
+    for rnd in range(rec["S1"], len(rec["rounds"])):
+        for i in range(rec["n_clients"]):
+            for k, cls in enumerate(rec["neg_lists"][i]):
+                sim = P[f"r{rnd}_c{i}_k{k}_sim"].astype(np.float64)
+                if np.isnan(sim).all():
+                    continue
+                rng = float(np.nanmax(sim) - np.nanmin(sim))
+                kt = int(args.clean_threshold * (sim >= 0).sum()); kb = int(args.noise_threshold * (sim < 0).sum())
+                d = np.sort(sim)[::-1]
+                mt = (d[kt - 1] - d[kt]) / rng if 0 < kt < len(d) else None
+                mb = (d[::-1][kb] - d[::-1][kb - 1]) / rng if 0 < kb < len(d) else None
+                print(f"margins {rec.get('data_seed')} rnd {rnd} client {i} cls {cls}: k_top {kt} margin {mt}  k_bot {kb} margin {mb}")
+                worst = min([worst] + [m for m in (mt, mb) if m is not None])
+    print(f"worst boundary margin (data_seed {rec.get('data_seed')}): {worst:.4g} of the row's range", flush=True)
 
 
 def g_fedmlp64(out):
     """the same two-stage flow on a conditioned problem: 64x64 inputs (layer 4 keeps 2x2 pixels,
     128 values per channel at bs 32), 2 clients x 1024 samples, non-trivial BatchNorm affine."""
-    g_fedmlp_traj(out, C=4, n_cl=2, N=1024, hw=64, data_seed=29, order_seed=212, bn_seed=77, name="traj_fedmlp64")
+    g_fedmlp_traj(out, C=4, n_cl=2, N=1024, hw=64, data_seed=int(os.environ.get("GOLDEN_FEDMLP64_SEED", 29)), order_seed=212,
+                  bn_seed=77, name="traj_fedmlp64")
 
 
 def g_fedmlp_c14(out):
@@ -507,6 +561,9 @@ def g_baselines(out):
 
 
 if __name__ == "__main__":
+    if os.environ.get("GOLDEN_OUT"):          # write somewhere else (seed searches, reproducibility checks)
+        HERE = os.environ["GOLDEN_OUT"]
+        os.makedirs(HERE, exist_ok=True)
     which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224", "eval", "baselines"]
     fns = {"kat": g_kat, "train": g_train_traj, "fedmlp": g_fedmlp_traj,
            "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval, "baselines": g_baselines,

@@ -20,7 +20,7 @@ def _run(argv):
 
 def test_driver_fedmlp_two_stage_smoke():
     log = _run(["--exp", "FedMLP", "--n_clients", "2", "--n_classes", "4", "--rounds_warmup", "3",
-                "--rounds_FedMLP_stage1", "2", "--batch_size", "32", "--n_local", "448", "--hw", "64"])
+                "--rounds_FedMLP_stage1", "2", "--batch_size", "32", "--n_local", "448", "--hw", "64", "--pretrained", "0"])
     assert len(log) == 3
     assert all(np.isfinite(r["mean_loss"]) for r in log)
     assert log[1]["mean_loss"] < log[0]["mean_loss"] * 1.5
@@ -28,7 +28,7 @@ def test_driver_fedmlp_two_stage_smoke():
 
 def test_driver_fedavg_smoke():
     log = _run(["--exp", "FedAVG", "--n_clients", "2", "--n_classes", "4", "--rounds_warmup", "2",
-                "--batch_size", "32", "--n_local", "96", "--hw", "64"])
+                "--batch_size", "32", "--n_local", "96", "--hw", "64", "--pretrained", "0"])
     assert len(log) == 2 and all(np.isfinite(r["mean_loss"]) for r in log)
 
 

@@ -486,17 +486,15 @@ def test_stage1_two_stream_step_is_deterministic_and_equals_one_stream(monkeypat
     """Stage-1 steps enqueue the frozen teacher's forward on a side stream with its own buffers next to the student's
     train forward, and the backward's weight gradients on the side stream next to the data-gradient chain (gradient
     tensors double-buffered by block parity).  Three steps twice from the same state must agree bit for bit (no race
-    between the streams), and with the inline / one-stream orders (FM_SIDE_WGRAD=0, FM_SIDE_TEACHER=0) as well."""
+    between the streams), and with the teacher-only / one-stream orders (Engine(streams=2 / 1)) as well."""
     from fedmlp_amd.engine import Engine
     g = torch.Generator().manual_seed(43)
     x1 = torch.randn((B, 3, hw, hw), generator=g); x2 = torch.randn((B, 3, hw, hw), generator=g)
     y = (torch.rand((B, C_), generator=g) < 0.3).float()
     mask = [0.0, 1.0, 0.0, 0.0, 0.0]
     outs = []
-    for side, sidew in (("1", "1"), ("1", "1"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("FM_SIDE_TEACHER", side)
-        monkeypatch.setenv("FM_SIDE_WGRAD", sidew)      # weight gradients of the backward on the side stream as well
-        e = Engine(M, C_, hw, hw, 4 * B)
+    for streams in (0, 0, 2, 1):        # 0 teacher + weight gradients on the side stream, 2 teacher only, 1 one stream
+        e = Engine(M, C_, hw, hw, 4 * B, streams=streams)
         try:
             e.stochastic = False
             _load(e)

@@ -196,6 +196,7 @@ def test_step_fixmatch(eng):
         loss = R.loss_fixmatch(zw, zs, y, pw, pwu, act, neg, 8, 1, C_)
         opt.zero_grad(); loss.backward()
     opt.step()
+    assert rm.flips <= 32, rm.flips
     assert abs(lo.item() - loss.item()) < 1e-4 * abs(loss.item()) + 1e-7
     # fc weights x40 saturate sigmoids (p(1-p) ~ 1e-9): gradients are ill-conditioned there
     _cmp_grads(eng, net, rtol=2e-3, what='fixmatch')
@@ -258,13 +259,14 @@ def test_step_stage1_chestxray14_shape():
         e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 3, 8, lo)
         net.train()
         opt = torch.optim.Adam(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=5e-4)
-        with relu_masks_from_engine(e, 2, 6):
+        with relu_masks_from_engine(e, 2, 6) as rm:
             _, z1 = net(x1); _, z2 = net(x2)
             with torch.no_grad():
                 _, g1 = glob(x1); _, g2 = glob(x2)
             loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, 8, 3)
             opt.zero_grad(); loss.backward()
         opt.step()
+        assert rm.flips <= 32, rm.flips
         assert abs(lo.item() - loss.item()) < 1e-5 * abs(loss.item()) + 1e-7
         gsd = spec.flat_to_state_dict("Resnet18", C, e.debug_get_grads(), np.zeros(e.ni, np.int64))
         for k, p in net.named_parameters():
@@ -318,15 +320,15 @@ def test_step_is_run_to_run_deterministic(eng):
 
 
 def test_stage1_two_stream_teacher_equals_one_stream(monkeypatch):
-    """FM_SIDE_TEACHER=2 runs ResNet-18's frozen-teacher forward on a side stream (own activations and stream-K workspace)
-    next to the student's train forward; the default keeps one stream.  Both orders must give the same bits, twice."""
+    """By default ResNet-18's frozen-teacher forward runs on a side stream (own activations and stream-K workspace) next to the
+    student's train forward and the backward's weight gradients next to the data-gradient chain; Engine(streams=1) keeps one
+    stream, streams=2 forks the teacher only.  Every order must give the same bits, twice."""
     from fedmlp_amd.engine import Engine
     (x1, x2), y = _data(6, 44, views=2)
     mask = [0.0, 1.0, 0.0, 0.0, 0.0]
     outs = []
-    for side in ("2", "2", "0"):
-        monkeypatch.setenv("FM_SIDE_TEACHER", side)
-        e = Engine("Resnet18", C_, HW, HW, 16)
+    for streams in (0, 0, 1, 2):
+        e = Engine("Resnet18", C_, HW, HW, 16, streams=streams)
         try:
             _load(e)
             e.teacher_snapshot()
@@ -337,7 +339,7 @@ def test_stage1_two_stream_teacher_equals_one_stream(monkeypatch):
             outs.append((flat.copy(), lo.cpu().numpy().copy()))
         finally:
             e.close()
-    for k in (1, 2):
+    for k in (1, 2, 3):
         np.testing.assert_array_equal(outs[0][1], outs[k][1])
         np.testing.assert_array_equal(outs[0][0], outs[k][0])
 

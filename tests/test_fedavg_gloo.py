@@ -94,8 +94,13 @@ class FakeCommEngine:
     """stand-in with the four communicator methods fedavg.comm_init touches"""
     device = "cpu"
 
-    def __init__(self, fail_init=False, fail_id=False):
+    def __init__(self, fail_init=False, fail_id=False, fail_preflight=False):
         self.fail_init, self.fail_id, self.size, self.destroyed = fail_init, fail_id, 0, False
+        self.fail_preflight, self.entered_init = fail_preflight, False
+
+    def comm_preflight(self):
+        if self.fail_preflight:
+            raise RuntimeError("cannot load librccl")
 
     def comm_unique_id(self):
         if self.fail_id:
@@ -104,6 +109,7 @@ class FakeCommEngine:
 
     def comm_init(self, uid, rank, world):
         assert uid == bytes(range(128))
+        self.entered_init = True
         if self.fail_init:
             raise RuntimeError("ncclCommInitRank failed")
         self.size = world
@@ -119,18 +125,19 @@ def _comm_worker(rank, port, out_dir, case):
     from fedmlp_amd.fedavg import comm_init
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
-    eng = FakeCommEngine(fail_init=(case == "init_fails_on_rank1" and rank == 1), fail_id=(case == "id_fails" and rank == 0))
+    eng = FakeCommEngine(fail_init=(case == "init_fails_on_rank1" and rank == 1), fail_id=(case == "id_fails" and rank == 0),
+                         fail_preflight=(case == "preflight_fails_on_rank1" and rank == 1))
     try:
         res = ("ok", comm_init(eng))
     except RuntimeError as ex:
         res = ("raised", str(ex))
     with open(os.path.join(out_dir, f"c{rank}.txt"), "w") as f:
-        f.write(f"{res[0]}|{res[1]}|{eng.comm_size()}|{int(eng.destroyed)}")
+        f.write(f"{res[0]}|{res[1]}|{eng.comm_size()}|{int(eng.destroyed)}|{int(eng.entered_init)}")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["all_fine", "init_fails_on_rank1", "id_fails"])
+@pytest.mark.parametrize("case", ["all_fine", "init_fails_on_rank1", "id_fails", "preflight_fails_on_rank1"])
 def test_comm_init_failure_is_agreed_on_by_all_ranks(tmp_path, case):
     """A library communicator that forms on some ranks only would leave the ranks on different all-reduce paths
     (deadlock): comm_init either returns the rank count everywhere or raises everywhere, and a rank whose own
@@ -145,3 +152,6 @@ def test_comm_init_failure_is_agreed_on_by_all_ranks(tmp_path, case):
         assert [r[2] for r in res] == ["0", "0"], res               # nobody keeps a communicator
         if case == "init_fails_on_rank1":
             assert res[0][3] == "1"                                  # rank 0 had one and destroyed it
+        if case == "preflight_fails_on_rank1":
+            # librccl missing on one rank: NO rank may enter the collective ncclCommInitRank (its peers would block in it)
+            assert [r[4] for r in res] == ["0", "0"], res

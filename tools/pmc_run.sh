@@ -5,7 +5,7 @@
 TAG=$1; KEY=$2; STEPS=$3; WARM=$4; shift 4
 OUT=gpurun_out/pmc
 mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/$TAG.$C

@@ -4,7 +4,7 @@
 TAG=$1; shift
 OUT=gpurun_out/pmc
 mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 CNT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"
 rm -rf $OUT/$TAG.sq

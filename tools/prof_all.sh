@@ -2,7 +2,7 @@
 # rocprofv3 stats + PMC traffic of the four single-GPU workloads, op profiles.  usage: tools/prof_all.sh <tag>
 # (ONE gpurun call: gpurun_out/ starts empty on every box, so pmc_traffic.json only holds all four keys this way)
 TAG=$1
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d /tmp/envprobe -- python3 -c "import os; print('profiler env:', sorted(k for k in os.environ if 'ROCP' in k.upper() or k == 'LD_PRELOAD'))" 2>/dev/null | grep "profiler env"
 bash tools/prof_stats.sh ${TAG}_s1 > /dev/null 2>&1
