@@ -16,8 +16,8 @@ tensors [N,3,H,W] (the HBM-resident cache of SURVEY 8f), batches are gathered
 on the GPU instead of being collated on the host.
 
 Batch order: the reference's DataLoader(shuffle=True) draws from the global
-torch RNG (:47-48, 1166-1167).  Here `torch.randperm` does, unless explicit
-orders are queued in `self.order_queue` (parity tests).
+torch RNG (:47-48, 1166-1167).  Here `torch.randperm` does (`_order`; the parity
+tests replay recorded orders through a subclass, tests/helpers.ReplayLocalUpdate).
 """
 import logging
 
@@ -98,18 +98,11 @@ class LocalUpdate(object):
         self.lr = args.base_lr
         self.traindata_idx = []
         self.idxss = []
-        self.order_queue = []
-        self.tagging_log = None            # set to [] to record (class, pool, similarities) of every tagging call
-        self.selection_hook = None         # parity replays: f(rnd, k, cls, clean, noise) -> (clean, noise), called once
-                                           # per tagged class between selection and stage-2 training
         self._dev = {}
 
     # ---- data plumbing -------------------------------------------------------------------
     def _order(self, n):
-        if self.order_queue:
-            o = list(self.order_queue.pop(0))
-            assert len(o) == n
-            return o
+        """one shuffled pass over the local set: DataLoader(shuffle=True) of :47-48, 1166-1167"""
         return torch.randperm(n).tolist()
 
     def _views(self, eng):
@@ -369,6 +362,24 @@ class LocalUpdate(object):
         t, proto = eng.proto_finalize(zero_guard, n, act)
         return t, torch.from_numpy(proto)
 
+    # ---- cosine tagging + stable top-/bottom-k selection of one missing class (:1052-1112) ---------------
+    def _similarity(self, eng, rnd, cls, pool_f, pool_idx, proto_dev):
+        """cos(f, P0) - cos(f, P1) of every pool sample, on the device (CosineSimilarityFast :1417-1435)"""
+        return eng.cos_tag(pool_f.contiguous(), proto_dev, [cls])[0]
+
+    def _select(self, eng, rnd, cls, pool_f, pool_idx, proto_dev):
+        """-> (clean, noise): dataset indices of the int(clean_threshold * #(sim >= 0)) most similar and the
+        int(noise_threshold * #(sim < 0)) least similar pool samples (stable ranks, utils/utils.py:24-35)"""
+        if not len(pool_idx):
+            return [], []
+        sim = self._similarity(eng, rnd, cls, pool_f, pool_idx, proto_dev)
+        top, bot = eng.select_topk(sim, self.args.clean_threshold, self.args.noise_threshold)
+        if not len(top):
+            # the reference's first branch tests the CLEAN list twice (`len(max_m_indices_list) == 0 and
+            # len(max_m_indices_list) == 0`, :1076 / :1099): without a clean pick it keeps no noise pick either
+            bot = []
+        return [int(pool_idx[j]) for j in top], [int(pool_idx[j]) for j in bot]
+
     # ---- LocalUpdate.train_FedMLP (:904-1256) --------------------------------------------------------
     def train_FedMLP(self, rnd, tao, Prototype, writer1, negetive_class_list, active_class_list_client_i, net):
         a = self.args
@@ -425,18 +436,7 @@ class LocalUpdate(object):
                 pool_idx = [ds_idx[r] for r in rows]
                 pool_f = f.index_select(0, torch.as_tensor(rows, device=eng.device, dtype=torch.long)) \
                     if rows else f[:0]
-            if len(pool_idx):
-                sim = eng.cos_tag(pool_f.contiguous(), proto_dev, [cls])
-                top, bot = eng.select_topk(sim[0], a.clean_threshold, a.noise_threshold)
-                if self.tagging_log is not None:       # parity tests: similarity of every pool sample of this round
-                    self.tagging_log.append({"rnd": rnd, "cls": cls, "pool_idx": list(pool_idx),
-                                             "sim": sim[0].cpu().numpy()})
-            else:
-                top, bot = [], []
-            clean = [int(pool_idx[j]) for j in top]
-            noise = [int(pool_idx[j]) for j in bot]
-            if self.selection_hook is not None:
-                clean, noise = self.selection_hook(rnd, k, cls, clean, noise)
+            clean, noise = self._select(eng, rnd, cls, pool_f, pool_idx, proto_dev)
             if first:
                 self.traindata_idx += [clean, noise]
             else:

@@ -241,6 +241,10 @@ def select_for_class(sim, pool_idx, clean_thr, noise_thr):
     k_noise = int(1 * noise_thr * n_noise)
     top = max_m_indices(sim, k_clean)
     bot = min_n_indices(sim, k_noise)
+    if len(top) == 0:
+        # :1076 / :1099 test `len(max_m_indices_list) == 0 and len(max_m_indices_list) == 0` (the clean list twice):
+        # a class without a clean pick keeps no noise pick either
+        bot = []
     return [int(pool_idx[j]) for j in top], [int(pool_idx[j]) for j in bot]
 
 

@@ -126,10 +126,14 @@ def make_args(**kw):
     return a
 
 
-def build_net(C, seed):
-    net = ResNet18Ref(C)
-    flat, cnt = spec.init_state("Resnet18", C, seed)
-    sd = spec.flat_to_state_dict("Resnet18", C, flat, cnt)
+def build_net(C, seed, model="Resnet18"):
+    if model == "Efficient_b0":
+        from oracle.efficientnet_ref import EfficientNetB0Ref
+        net = EfficientNetB0Ref(C)          # the reference's net(x) call passes no stochastic multipliers: p = 0 on both sides
+    else:
+        net = ResNet18Ref(C)
+    flat, cnt = spec.init_state(model, C, seed)
+    sd = spec.flat_to_state_dict(model, C, flat, cnt)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     return net
 
@@ -275,21 +279,38 @@ def perturb_bn(net, seed):
 
 
 def g_fedmlp_traj(out, C=4, n_cl=2, N=512, hw=32, data_seed=23, order_seed=202, bn_seed=None,
-                  name="traj_fedmlp", p_pos=0.3):
+                  name="traj_fedmlp", p_pos=0.3, model="Resnet18", calibrate_bn=False):
     """full FedMLP two-stage flow (train_FedMLP, utils/local_training.py:904-1256
     + main.py:178-237 aggregation): 2 clients x 512 samples, C=4, bs 32, 32x32,
     S1 = 2 (rounds 0-1 stage 1, prototype pass at rnd 1; rounds 2-3 stage 2)."""
-    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=2)
+    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=2, model=model,
+                     feature_dim=spec.FEATURE_DIM[model])
     ds = SynthDataset(n_cl * N, C, hw, data_seed, True, p_pos)
     pos, neg = class_lists(ds.targets, C)
     users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
     rs = np.random.RandomState(order_seed)
-    netglob = build_net(C, 1037)
+    netglob = build_net(C, 1037, model)
     if bn_seed is not None:
         perturb_bn(netglob, bn_seed)
+    bnstats = None
+    if calibrate_bn:
+        # EfficientNet's BatchNorm momentum is 0.01: after the flow's 32 train steps the running statistics would still
+        # be the (0, 1) init and every eval-mode feature the same constant (the tagging would rank rounding noise).  The
+        # reference starts from ImageNet weights; here the init's running statistics are set to the batch statistics of
+        # the first 64 samples (one train-mode forward at momentum 1) and shipped as a fixture with the golden.
+        bns = [m for m in netglob.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        for m in bns:
+            m.momentum = 1.0
+        netglob.train()
+        with torch.no_grad():
+            netglob(torch.from_numpy(ds.x1[:64]))
+        for m in bns:
+            m.momentum = 0.01
+            m.num_batches_tracked.zero_()
+        bnstats = {k: v.numpy().copy() for k, v in netglob.state_dict().items() if "running_" in k}
     locals_ = [LT.LocalUpdate(args, i, deepcopy(ds), users[i], pos, neg, active_class_list=[i])
                for i in range(n_cl)]
-    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": data_seed, "init_seed": 1037,
+    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": data_seed, "init_seed": 1037, "model": model,
            "bn_seed": bn_seed, "p_pos": p_pos, "bs": 32, "S1": 2, "users": users, "rounds": []}
     xprobe = torch.from_numpy(ds.x1[:4])
     tao, Prototype = [0] * C, []
@@ -355,6 +376,8 @@ def g_fedmlp_traj(out, C=4, n_cl=2, N=512, hw=32, data_seed=23, order_seed=202, 
         rec["rounds"].append(r)
     json.dump(rec, open(os.path.join(out, name + ".json"), "w"), indent=1)
     np.savez_compressed(os.path.join(out, name + "_protos.npz"), **protos_npz)
+    if bnstats is not None:
+        np.savez_compressed(os.path.join(out, name + "_bnstats.npz"), **bnstats)
     report_margins(rec, protos_npz, args)
 
 
@@ -414,6 +437,151 @@ def g_step_full(out):
     rec = {"C": C, "N": N, "hw": hw, "data_seed": 61, "init_seed": 1037, "bn_seed": 79, "bs": 128,
            "loss": float(ret[1]), "grads": grads, "norms": tensor_norms(ret[0])}
     json.dump(rec, open(os.path.join(out, "step_full.json"), "w"), indent=1)
+
+
+# LocalUpdate.train / train_FixMatch end with optimizer.zero_grad() (:701), which drops the gradients: keep a copy of what
+# the LAST optimizer.step() of a trainer call consumed (the reference's own Adam, untouched otherwise)
+LAST_GRADS = {}
+_adam_step = torch.optim.Adam.step
+
+
+def _adam_step_tap(self, *a, **k):
+    LAST_GRADS.clear()
+    for grp in self.param_groups:
+        for p in grp["params"]:
+            if p.grad is not None:
+                LAST_GRADS[id(p)] = p.grad.detach().clone()
+    return _adam_step(self, *a, **k)
+
+
+torch.optim.Adam.step = _adam_step_tap
+
+
+def _grad_record(work):
+    """gradient of every parameter as the trainer's last optimizer.step() saw it: L2 norm, sum, first 3 values, max |.|"""
+    out = {}
+    for k, p in work.named_parameters():
+        g = LAST_GRADS[id(p)]
+        out[k] = {"norm": float(torch.linalg.vector_norm(g.double())), "sum": float(g.double().sum()),
+                  "head": [float(v) for v in g.reshape(-1)[:3]], "absmax": float(g.abs().max())}
+    return out
+
+
+def g_step_full_variants(out):
+    """The OTHER step variants at the benchmarked size (bs 128, 3x224x224, ResNet-18, C = 5), each ONE step through
+    the reference's own trainer, like g_step_full does for stage 1:
+      train    -- LocalUpdate.train (utils/local_training.py:628-703)
+      fixmatch -- train_FixMatch (:771-825), fc weights x40 so that some rows are confident
+      stage2   -- train_FedMLP with rnd == rounds_FedMLP_stage1 == 0 (:1017-1256): feature pass, tagging against random
+                  prototypes, selection (thresholds 0.05 / 0.1: int(0.005 * 64) would select nothing from 128 samples),
+                  one pseudo-label step.  Recorded: the reference's similarity rows / picks, loss, gradients."""
+    C, N, hw = 5, 128, 224
+    rec = {"C": C, "N": N, "hw": hw, "init_seed": 1037, "bn_seed": 79, "bs": 128}
+    # ---- train -------------------------------------------------------------------------------
+    args = make_args(n_classes=C, n_clients=1, batch_size=128)
+    ds1 = SynthDataset(N, C, hw, 62, False)
+    pos, neg = class_lists(ds1.targets, C)
+    net = perturb_bn(build_net(C, 1037), 79)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds1), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 128, True)
+    work = deepcopy(net)
+    ret = loc.train(0, work, None)
+    rec["train"] = {"data_seed": 62, "loss": float(ret[1]), "grads": _grad_record(work), "norms": tensor_norms(ret[0]),
+                    "loss_w": [float(v) for v in loc.loss_w]}
+    print("train done", flush=True)
+    # ---- FixMatch ------------------------------------------------------------------------------
+    ds2 = SynthDataset(N, C, hw, 63, True)
+    pos, neg = class_lists(ds2.targets, C)
+    netf = deepcopy(net)
+    with torch.no_grad():
+        netf.fc.weight.mul_(40.0)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds2), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 128, True)
+    work = deepcopy(netf)
+    ret = loc.train_FixMatch(0, work)
+    rec["fixmatch"] = {"data_seed": 63, "fc_scale": 40.0, "loss": float(ret[1]), "grads": _grad_record(work),
+                       "norms": tensor_norms(ret[0]), "loss_w": [float(v) for v in loc.loss_w],
+                       "loss_w_unknown": [float(v) for v in loc.loss_w_unknown]}
+    print("fixmatch done", flush=True)
+    # ---- stage 2 (first stage-2 round with rounds_FedMLP_stage1 = 0) ----------------------------
+    args2 = make_args(n_classes=C, n_clients=1, batch_size=128, rounds_FedMLP_stage1=0, clean_threshold=0.05,
+                      noise_threshold=0.1)
+    ds3 = SynthDataset(N, C, hw, 64, True)
+    pos, neg = class_lists(ds3.targets, C)
+    loc = LT.LocalUpdate(args2, 0, deepcopy(ds3), list(range(N)), pos, neg, active_class_list=[0])
+    rs = np.random.RandomState(65)
+    proto = torch.from_numpy(rs.standard_normal((2 * C, 512)).astype(np.float32)).abs()   # features are post-ReLU means
+    fo = list(range(N)); to = rs.permutation(N).tolist()
+    ORDERS.append(fo)
+    loc.ldr_train = FixedLoader(loc.local_dataset, 128, True)
+    ORDERS.append(to)
+    del SIM_TAP[:], POOL_TAP[:]
+    work = deepcopy(net)
+    ret = loc.train_FedMLP(0, [0.5] * C, proto, None, [1, 2, 3, 4], [0], net=work)
+    rec["stage2"] = {"data_seed": 64, "proto_seed": 65, "feat_order": fo, "train_order": to, "loss": float(ret[1]),
+                     "clean_threshold": 0.05, "noise_threshold": 0.1, "negative": [1, 2, 3, 4],
+                     "grads": _grad_record(work), "norms": tensor_norms(ret[0]),
+                     "traindata_idx": [[int(v) for v in l] for l in loc.traindata_idx],
+                     "sim": [[float(v) for v in s_] for s_ in SIM_TAP], "t": [float(v) for v in ret[6]]}
+    json.dump(rec, open(os.path.join(out, "step_full_variants.json"), "w"), indent=1)
+
+
+def g_effnet_step(out):
+    """EfficientNet-B0 through the reference's own trainer (model/all_models.py:73-75, 121-124 builds it; the trainer calls
+    net(images) without stochastic multipliers on this restatement, so drop-connect / dropout are the identity on both
+    sides): ONE stage-1 step of train_FedMLP (:907-970) and ONE LocalUpdate.train step (:628-703) at 3x224x224, bs 16,
+    plus the gradients of every parameter."""
+    C, N, hw = 5, 16, 224
+    args = make_args(n_classes=C, n_clients=1, batch_size=16, model="Efficient_b0", feature_dim=1280)
+    ds = SynthDataset(N, C, hw, 71, True)
+    ds1 = SynthDataset(N, C, hw, 71, False)
+    pos, neg = class_lists(ds.targets, C)
+    net = perturb_bn(build_net(C, 1037, "Efficient_b0"), 81)
+    rec = {"C": C, "N": N, "hw": hw, "data_seed": 71, "init_seed": 1037, "bn_seed": 81, "bs": 16, "model": "Efficient_b0"}
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 16, True)
+    work = deepcopy(net)
+    ret = loc.train_FedMLP(0, [0] * C, [], None, None, None, net=work)
+    rec["stage1"] = {"loss": float(ret[1]), "grads": _grad_record(work), "norms": tensor_norms(ret[0])}
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds1), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 16, True)
+    work = deepcopy(net)
+    ret = loc.train(0, work, None)
+    rec["train"] = {"loss": float(ret[1]), "grads": _grad_record(work), "norms": tensor_norms(ret[0]),
+                    "loss_w": [float(v) for v in loc.loss_w]}
+    f, z = probe(net, torch.from_numpy(ds.x1[:4]))
+    rec["init_probe_logits"] = z.tolist()
+    json.dump(rec, open(os.path.join(out, "effnet_step.json"), "w"), indent=1)
+
+
+def g_effnet_step_bs256(out):
+    """EfficientNet-B0 stage-1 step at the CONFIGURED batch of BASELINE configs[3] (bs 256, two views = 512 train-mode
+    images, BatchNorm statistics over 256 images per view) through the reference's trainer.  64x64 inputs: 512 images of
+    224x224 need ~100 GB of autograd state in this 64-GB container; the full spatial size is pinned at bs 16 (effnet_step)."""
+    C, N, hw = 5, 256, 64
+    args = make_args(n_classes=C, n_clients=1, batch_size=256, model="Efficient_b0", feature_dim=1280)
+    ds = SynthDataset(N, C, hw, 72, True)
+    pos, neg = class_lists(ds.targets, C)
+    net = perturb_bn(build_net(C, 1037, "Efficient_b0"), 81)
+    loc = LT.LocalUpdate(args, 0, deepcopy(ds), list(range(N)), pos, neg, active_class_list=[0])
+    ORDERS.append(list(range(N)))
+    loc.ldr_train = FixedLoader(loc.local_dataset, 256, True)
+    work = deepcopy(net)
+    ret = loc.train_FedMLP(0, [0] * C, [], None, None, None, net=work)
+    rec = {"C": C, "N": N, "hw": hw, "data_seed": 72, "init_seed": 1037, "bn_seed": 81, "bs": 256, "model": "Efficient_b0",
+           "stage1": {"loss": float(ret[1]), "grads": _grad_record(work), "norms": tensor_norms(ret[0])}}
+    json.dump(rec, open(os.path.join(out, "effnet_step_bs256.json"), "w"), indent=1)
+
+
+def g_effnet_traj(out):
+    """EfficientNet-B0 two-stage FedMLP flow through the reference's trainer: 2 clients x 512 samples, 64x64, C = 4, bs 32,
+    conditioned BatchNorm affine (the ResNet-18 counterpart is traj_fedmlp64)."""
+    g_fedmlp_traj(out, C=4, n_cl=2, N=512, hw=64, data_seed=int(os.environ.get("GOLDEN_EFFNET_SEED", 83)), order_seed=232,
+                  bn_seed=82, name="traj_effnet64", model="Efficient_b0", calibrate_bn=True)
 
 
 def g_fixmatch_traj(out):
@@ -567,7 +735,9 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["kat", "train", "fedmlp", "fixmatch", "step224", "eval", "baselines"]
     fns = {"kat": g_kat, "train": g_train_traj, "fedmlp": g_fedmlp_traj,
            "fixmatch": g_fixmatch_traj, "step224": g_step224, "eval": g_eval, "baselines": g_baselines,
-           "fedmlp64": g_fedmlp64, "fedmlp_c14": g_fedmlp_c14, "step_full": g_step_full}
+           "fedmlp64": g_fedmlp64, "fedmlp_c14": g_fedmlp_c14, "step_full": g_step_full,
+           "step_full_variants": g_step_full_variants, "effnet_step": g_effnet_step, "effnet_traj": g_effnet_traj,
+           "effnet_step_bs256": g_effnet_step_bs256}
     for w in which:
         print("==> golden:", w, flush=True)
         fns[w](HERE)

@@ -155,3 +155,54 @@ def conditioned_seed(net, make_views, seeds, margin=1e-5):
         if relu_margin(net, make_views(sd)) > margin:
             return sd
     raise AssertionError(f"no seed in {list(seeds)} is {margin}-conditioned")
+
+
+def replay_local_update():
+    """-> ReplayLocalUpdate: fedmlp_amd.local_training.LocalUpdate with the two things a golden replay needs and the
+    product class does not carry: recorded batch orders instead of torch.randperm (`order_queue`), and a log of every
+    tagging call's pool and similarity row (`tagging_log`).  A factory, so importing tests.helpers needs no GPU library."""
+    from fedmlp_amd.local_training import LocalUpdate
+
+    class ReplayLocalUpdate(LocalUpdate):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.order_queue = []
+            self.tagging_log = []
+
+        def _order(self, n):
+            if self.order_queue:
+                o = list(self.order_queue.pop(0))
+                assert len(o) == n
+                return o
+            return super()._order(n)
+
+        def _similarity(self, eng, rnd, cls, pool_f, pool_idx, proto_dev):
+            sim = super()._similarity(eng, rnd, cls, pool_f, pool_idx, proto_dev)
+            self.tagging_log.append({"rnd": rnd, "cls": cls, "pool_idx": list(pool_idx), "sim": sim.cpu().numpy()})
+            return sim
+
+    return ReplayLocalUpdate
+
+
+def grad_errors(gsd, gold):
+    """Engine gradients (state_dict-keyed arrays) against a golden's per-tensor record {norm, sum, head, absmax}
+    (tests/golden/make_golden.py::_grad_record).  Per tensor the worst of: |norm - norm_ref| / norm_ref, |sum - sum_ref|
+    relative to norm * sqrt(n), and the first three values relative to the tensor's max.  -> (worst tensor, worst, median)
+    Tensors whose REFERENCE gradient is numerically zero (norm below 1e-4 of the median tensor's: a BatchNorm bias in front of
+    another train-mode BatchNorm has an exactly cancelling gradient, both sides hold rounding noise of ~1e-9 there) are held
+    to that floor in absolute terms instead of a ratio of two noises."""
+    med_norm = float(np.median([v["norm"] for v in gold.values()]))
+    typ = float(np.median([v["absmax"] for v in gold.values()]))
+    worst = {}
+    for k, w in gold.items():
+        got = np.asarray(gsd[k], dtype=np.float64)
+        if w["norm"] < 1e-4 * med_norm:
+            worst[k] = float(np.linalg.norm(got) / (1e-4 * med_norm)) * 1e-3      # < 1e-3 while the engine's is below the floor too
+            continue
+        e_norm = abs(np.linalg.norm(got) - w["norm"]) / (w["norm"] + 1e-3 * typ)
+        e_sum = abs(got.sum() - w["sum"]) / (w["norm"] * np.sqrt(got.size) + 1e-30)
+        e_head = np.abs(got.ravel()[:3] - np.array(w["head"])).max() / (w["absmax"] + 1e-30)
+        worst[k] = float(max(e_norm, e_sum, e_head))
+    k_bad = max(worst, key=worst.get)
+    grad_errors.p90 = float(np.percentile(list(worst.values()), 90))          # (read by the bf16 tests: stated 90th percentile)
+    return k_bad, worst[k_bad], float(np.median(list(worst.values())))

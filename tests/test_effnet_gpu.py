@@ -259,7 +259,8 @@ def test_localupdate_surface_efficient_b0():
     LocalUpdate.train follows the oracle's RefClient.train on the same batch order."""
     import types
     from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     from tests.helpers import make_args, data_dict
     from tests.test_local_training_gpu import SynthDataset
     from tests.synth import class_lists

@@ -53,7 +53,8 @@ def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, av
     import os
     import torch
     from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     from fedmlp_amd.fedavg import FedAvg
     from fedmlp_amd.evaluations import globaltest, multilabel_metrics
     from oracle import steps_ref as R

@@ -95,67 +95,105 @@ def test_stage1_step_at_the_benchmarked_size_matches_the_reference():
         eng.close()
 
 
-def _replay_two_stage(name, tol, replace_near_ties=True):
-    """The FedMLP two-stage flow (stage 1, prototype pass, tagging + selection, stage 2, FedAvg*) against a golden
-    trajectory of the reference.  tol: fixed bounds {loss, norm, bn_bias_norm, proto, logits, t_count}.
-    replace_near_ties=False leaves the engine's own picks in place (free-running): near-ties are then checked in the
-    first stage-2 round only, because afterwards the two runs' pools differ."""
-    from fedmlp_amd.local_training import LocalUpdate
+def _boundary(sim, k, top):
+    """midpoint between the k-th pick and the first non-pick of a similarity row (descending for the top picks,
+    ascending for the bottom picks); +-inf when the selection takes nothing / everything"""
+    o = np.sort(sim)[::-1] if top else np.sort(sim)
+    if k <= 0:
+        return np.inf if top else -np.inf
+    if k >= len(o):
+        return -np.inf if top else np.inf
+    return 0.5 * (float(o[k - 1]) + float(o[k]))
+
+
+def _check_picks(rep, mx, P, rnd, i, k, cls, log, got_clean, got_noise, args, delta):
+    """Discrete picks of one tagging call against the REFERENCE's similarity row (recorded by make_golden.py from the
+    reference's own run).  Nothing is replaced: the engine's picks stand.  With delta = the similarity noise allowed
+    between two implementations (as a fraction of the reference row's range):
+      * every reference pick whose reference margin to the selection boundary exceeds delta must be picked here too,
+      * nothing may be picked here that the reference ranks more than delta behind its boundary,
+      * the pick COUNTS int(thr * #(sim >= 0)) / int(thr * #(sim < 0)) may differ only as far as the samples within
+        delta of zero can move the sign counts,
+      * on the samples both pools hold, the similarities themselves agree to delta (reported as mx["sim"]).
+    Picks inside the band that fall the other way are counted in rep["picks_differing"]."""
+    s_ref = P[f"r{rnd}_c{i}_k{k}_sim"].astype(np.float64)
+    pool_ref = [int(v) for v in P[f"r{rnd}_c{i}_k{k}_pool"]]
+    if np.isnan(s_ref).all():                       # no prototype for this class: the reference selects nothing either
+        assert not got_clean and not got_noise
+        return
+    rng = float(np.nanmax(s_ref) - np.nanmin(s_ref))
+    ref_of = dict(zip(pool_ref, s_ref))
+    eng_of = dict(zip(log["pool_idx"], log["sim"].astype(np.float64)))
+    common = [v for v in pool_ref if v in eng_of]
+    if common:
+        mx["sim"] = max(mx.get("sim", 0.0), max(abs(eng_of[v] - ref_of[v]) for v in common) / rng)
+    nz = int((np.abs(s_ref) <= delta * rng).sum())
+    npos, nneg = int((s_ref >= 0).sum()), int((s_ref < 0).sum())
+    kt, kb = int(args.clean_threshold * npos), int(args.noise_threshold * nneg)
+    if kt == 0:
+        kb = 0          # the reference keeps no noise pick for a class without a clean pick (:1076 tests the clean list twice)
+    if len(pool_ref) == len(log["pool_idx"]):      # same pool size: the counts are bounded by the sign-flip band
+        ok_t = {int(args.clean_threshold * n) for n in range(max(0, npos - nz), npos + nz + 1)}
+        ok_b = {int(args.noise_threshold * n) for n in range(max(0, nneg - nz), nneg + nz + 1)}
+        if 0 in ok_t:
+            ok_b.add(0)
+        assert len(got_clean) in ok_t and len(got_noise) in ok_b, (rnd, i, cls, len(got_clean), kt, len(got_noise), kb)
+    for top, got, kk in ((True, got_clean, kt), (False, got_noise, kb)):
+        b = _boundary(s_ref, kk, top)
+        sgn = 1.0 if top else -1.0
+        want = [v for v in pool_ref if sgn * (ref_of[v] - b) > 0]          # the reference's picks of this call
+        for v in want:
+            margin = sgn * (ref_of[v] - b) / rng
+            if v in eng_of and margin > delta:
+                assert v in got, ("reference pick with a clear margin is missing", rnd, i, cls, v, margin)
+        for v in got:
+            if v in ref_of:
+                behind = -sgn * (ref_of[v] - b) / rng
+                mx["pick_behind"] = max(mx["pick_behind"], behind)
+                assert behind <= delta, ("pick far behind the reference's boundary", rnd, i, cls, v, behind)
+        rep["picks_total"] += len(want)
+        rep["picks_differing"] += len(set(want) - set(got))
+
+
+def _replay_two_stage(name, tol, tol_after_split, delta=(2.5e-2, 6e-2), model="Resnet18", precision="fp32"):
+    """The FedMLP two-stage flow (stage 1, prototype pass, tagging + selection, stage 2, FedAvg*) FREE-RUNNING against a
+    golden trajectory of the reference: the engine's own picks train the following rounds, nothing is replaced.
+    tol: fixed bounds {loss, norm, bn_bias_norm, proto, logits, t_count} that hold while every pick so far equals the
+    reference's (the two runs are the same experiment); tol_after_split: the bounds from the first round in which a
+    near-tie pick fell the other way (two experiments that differ in a few pseudo-labelled samples out of ~1000).
+    delta = similarity band of _check_picks in the first / in later stage-2 rounds; the similarities themselves must agree to
+    delta[0] while the runs are the same experiment (and to 2 * delta[1] afterwards).  ResNet-18 from a random init: after
+    the two stage-1 rounds (64 Adam steps) the engine's and the reference's similarity rows differ by 1.6-1.7e-2 of the row's
+    range (measured, both goldens) -- the chaos amplification of fp32 rounding DESIGN.md section 5 quantifies."""
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     from fedmlp_amd.fedavg import FedAvg, FedAvg_tao, FedAvg_proto
     g = load_golden(name + ".json")
     P = np.load(os.path.join(GOLDEN, name + "_protos.npz"))
     C, n_cl, N, S1 = g["C"], g["n_clients"], g["N"], g["S1"]
-    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=S1, seed=g["init_seed"], pretrained=0)
+    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=S1, seed=g["init_seed"], pretrained=0, model=model,
+                     feature_dim=spec.FEATURE_DIM[model], precision=precision)
     ds = SynthDataset(n_cl * N, C, g["hw"], g["data_seed"], True, g.get("p_pos", 0.3))
     pos, neg = class_lists(ds.targets, C)
     netglob = _init_net(args, g.get("bn_seed"))
+    bnstats = os.path.join(GOLDEN, name + "_bnstats.npz")
+    if os.path.exists(bnstats):                 # calibrated running statistics of the golden's initial net (make_golden.py)
+        sd = netglob.state_dict()
+        for k, v in np.load(bnstats).items():
+            sd[k] = torch.from_numpy(v)
+        netglob.load_state_dict(sd)
     locs = [LocalUpdate(args, i, ds, g["users"][i], pos, neg, active_class_list=[i]) for i in range(n_cl)]
-    for l in locs:
-        l.tagging_log = []
-    cur = {}                                   # round record of the golden being replayed
-
-    def make_hook(i):
-        """Discrete picks against the reference's.  The index work itself is pinned bit-exactly on identical inputs by
-        tests/test_kat_gpu.py; here the inputs are features of a net trained on another machine, so a pick may differ
-        ONLY where the engine's own similarities of the two candidates are a near-tie: <= 5e-3 of the row's range in
-        the first stage-2 round, <= 2e-2 in later ones (their features come from a net that has meanwhile trained a
-        round on pseudo-labels; its probe logits are 2-3e-2 of their range from the reference's by then) -- checked
-        for every differing element of every stage-2 round.  A near-tie pick that differs is then REPLACED by
-        the reference's: otherwise the two runs train on different pseudo-labelled sets from that round on and the
-        continuous comparisons below (loss, norms, prototypes, t) would compare different experiments."""
-        def hook(rnd, k, cls, clean, noise):
-            r, prev = cur["r"], cur["prev"]
-            out = []
-            for side, got in ((0, clean), (1, noise)):
-                full = r["traindata_idx"][i][2 * k + side]
-                want = full[len(prev["traindata_idx"][i][2 * k + side]):] if prev is not None and rnd > S1 else full
-                assert len(got) == len(want), (rnd, i, cls, side, len(got), len(want))
-                got_s, want_s = set(got), set(want)
-                if not replace_near_ties and rnd > S1:
-                    out.append(list(got))
-                    continue
-                if got_s != want_s:
-                    t = [t for t in locs[i].tagging_log if t["rnd"] == rnd and t["cls"] == cls][-1]
-                    where = {v: j for j, v in enumerate(t["pool_idx"])}
-                    rng = float(np.nanmax(t["sim"]) - np.nanmin(t["sim"]))
-                    for gi, wi in zip(sorted(got_s - want_s), sorted(want_s - got_s)):
-                        gap = abs(float(t["sim"][where[gi]]) - float(t["sim"][where[wi]]))
-                        mx["pick_gap"] = max(mx["pick_gap"], gap / rng)
-                        assert gap <= (5e-3 if rnd == S1 else 2e-2) * rng, (rnd, i, cls, gi, wi, gap, rng)
-                    rep["picks_replaced"] += len(got_s - want_s)
-                rep["picks_total"] += len(want)
-                out.append(list(want) if replace_near_ties else list(got))
-            return out[0], out[1]
-        return hook
-
-    for i, l in enumerate(locs):
-        l.selection_hook = make_hook(i)
+    if model == "Efficient_b0":                 # the reference trainer passes no drop-connect / dropout multipliers
+        locs[0]._bind(netglob, "image_aug_1").stochastic = False
     tao, Prototype = [0] * C, []
     neg_lists, act_lists = g["neg_lists"], g["act_lists"]
-    rep = {"max": {"loss": 0.0, "norm": 0.0, "bn_bias_norm": 0.0, "proto": 0.0, "logits": 0.0, "t_count": 0.0,
-                   "pick_gap": 0.0},
-           "picks_replaced": 0, "picks_total": 0}
+    keys = ("loss", "norm", "bn_bias_norm", "proto", "logits", "t_count")
+    rep = {"max": {k: 0.0 for k in keys}, "max_after_split": {k: 0.0 for k in keys}, "picks_differing": 0,
+           "picks_total": 0, "split_round": None}
+    rep["max"].update(sim=0.0, pick_behind=-1.0)
+    rep["max_after_split"].update(sim=0.0, pick_behind=-1.0)
     mx = rep["max"]
+    cur = mx                                       # the record the continuous deviations go to
 
     def cmp_norms(got, want):
         for k, w in want.items():
@@ -163,10 +201,9 @@ def _replay_two_stage(name, tol, replace_near_ties=True):
                 assert abs(got[k] - w) < 0.5, k
                 continue
             kind = "bn_bias_norm" if (k.endswith(".bias") and not k.startswith("fc.")) else "norm"
-            mx[kind] = max(mx[kind], abs(got[k] - w) / (abs(w) + 1e-12))
+            cur[kind] = max(cur[kind], abs(got[k] - w) / (abs(w) + 1e-12))
 
     for rnd, r in enumerate(g["rounds"]):
-        cur["r"], cur["prev"] = r, (g["rounds"][rnd - 1] if rnd > 0 else None)
         w, taos, protos = [], [], []
         for i in range(n_cl):
             if rnd < S1:
@@ -175,73 +212,79 @@ def _replay_two_stage(name, tol, replace_near_ties=True):
             else:
                 locs[i].order_queue += [r["feat_orders"][i], r["train_orders"][i]]
                 a1 = (neg_lists[i], act_lists[i])
+                before = [list(l) for l in locs[i].traindata_idx] if rnd > S1 else None
+                nlog = len(locs[i].tagging_log)
             ret = locs[i].train_FedMLP(rnd, tao, Prototype, None, a1[0], a1[1], net=copy.deepcopy(netglob))
-            mx["loss"] = max(mx["loss"], abs(ret[1] - r["loss"][i]) / abs(r["loss"][i]))
+            if rnd >= S1:
+                # the tagging of this call happened before its stage-2 training: judge the picks, then the continuous
+                # quantities of the round go to the record that matches the state of the experiment
+                logs = locs[i].tagging_log[nlog:]
+                by_cls = {l["cls"]: l for l in logs}
+                for k, cls in enumerate(neg_lists[i]):
+                    new_c = locs[i].traindata_idx[2 * k][len(before[2 * k]) if before else 0:]
+                    new_n = locs[i].traindata_idx[2 * k + 1][len(before[2 * k + 1]) if before else 0:]
+                    if cls in by_cls:
+                        _check_picks(rep, cur, P, rnd, i, k, cls, by_cls[cls], new_c, new_n, args,
+                                     delta[0] if rnd == S1 else delta[1])
+                    else:
+                        assert not new_c and not new_n
+                same = [sorted(a) for a in locs[i].traindata_idx] == [sorted(b) for b in r["traindata_idx"][i]]
+                if not same and rep["split_round"] is None:
+                    rep["split_round"] = rnd
+                    cur = rep["max_after_split"]
+            cur["loss"] = max(cur["loss"], abs(ret[1] - r["loss"][i]) / abs(r["loss"][i]))
             cmp_norms(_norms(ret[0]), r["norms"][i])
             if rnd == 0:
                 assert ret[4] == neg_lists[i] and ret[5] == act_lists[i]
-            if rnd >= S1:
-                # after the hook the lists equal the reference's as sets (membership is all DatasetSplit_pseudo uses,
-                # :1462-1469); how many picks the hook had to replace is in the report
-                if replace_near_ties:
-                    assert [sorted(a) for a in locs[i].traindata_idx] == [sorted(b) for b in r["traindata_idx"][i]]
             w.append(copy.deepcopy(ret[0]))
             if len(ret) == 8:
                 taos.append(ret[6]); protos.append(ret[7])
-                mx["t_count"] = max(mx["t_count"], float(np.abs(ret[6] - P[f"r{rnd}_c{i}_t"]).max() * N))
+                cur["t_count"] = max(cur["t_count"], float(np.abs(ret[6] - P[f"r{rnd}_c{i}_t"]).max() * N))
                 want = P[f"r{rnd}_c{i}_proto"]
                 assert np.array_equal(np.isnan(ret[7].numpy()), np.isnan(want))
-                mx["proto"] = max(mx["proto"], float(np.nanmax(np.abs(ret[7].numpy() - want)) / np.nanmax(np.abs(want))))
+                cur["proto"] = max(cur["proto"], float(np.nanmax(np.abs(ret[7].numpy() - want)) / np.nanmax(np.abs(want))))
         netglob.load_state_dict(FedAvg(w, [N] * n_cl))
         if rnd >= S1 - 1:
             tao = FedAvg_tao(taos, [N] * n_cl, g["class_negative_client_list"])
             Prototype = FedAvg_proto(protos, [N] * n_cl, g["class_active_client_list"])
             want = P[f"r{rnd}_glob_proto"]
             assert np.array_equal(np.isnan(Prototype.numpy()), np.isnan(want))              # NaN rows
-            mx["proto"] = max(mx["proto"], float(np.nanmax(np.abs(Prototype.numpy() - want)) / np.nanmax(np.abs(want))))
-            mx["t_count"] = max(mx["t_count"], float(np.abs(tao - np.array(r["tao"])).max() * N))
+            cur["proto"] = max(cur["proto"], float(np.nanmax(np.abs(Prototype.numpy() - want)) / np.nanmax(np.abs(want))))
+            cur["t_count"] = max(cur["t_count"], float(np.abs(tao - np.array(r["tao"])).max() * N))
         cmp_norms(_norms(netglob.state_dict()), r["glob_norms"])
         netglob.eval()
         _, z = netglob(ds.x1[:4])
         want = np.array(r["probe_logits"])
-        mx["logits"] = max(mx["logits"], float(np.abs(z.cpu().numpy() - want).max() / np.abs(want).max()))
-        rep.setdefault("running_max_after_round", []).append(dict(mx))
-    _dump(rep, f"parity_{name}.json" if replace_near_ties else f"parity_{name}_free_running.json")
+        cur["logits"] = max(cur["logits"], float(np.abs(z.cpu().numpy() - want).max() / np.abs(want).max()))
+        rep.setdefault("running_max_after_round", []).append({"same_experiment": dict(mx), "after_split": dict(rep["max_after_split"])})
+    _dump(rep, f"parity_{name}.json" if precision == "fp32" else f"parity_{name}_{precision}.json")
     for k, bound in tol.items():
-        assert mx[k] <= bound, (name, k, mx[k], bound, mx)
+        assert mx[k] <= bound, (name, k, mx[k], bound, rep)
+    for k, bound in tol_after_split.items():
+        assert rep["max_after_split"][k] <= bound, (name, "after the split", k, rep["max_after_split"][k], bound, rep)
+    assert mx["sim"] <= delta[0] and rep["max_after_split"]["sim"] <= 2 * delta[1], (name, mx["sim"], rep["max_after_split"]["sim"])
     return rep
 
 
 def test_two_stage_flow_conditioned_golden_64():
-    """Bounds are fixed numbers over all four rounds (no per-round growth factor, no oracle-sensitivity excuse).
-    Measured on MI355X (gpurun_out/parity_traj_fedmlp64.json) over both stem K layouts and three stream-K / tile-order
-    variants of the kernels: loss 0.9-1.4e-3, weight norms 1.9-2.4e-3, BN-bias norms 1.8-2.5e-4 (the 32x32 / beta = 0
-    golden needed 5e-2 per round there), prototypes 1.5-1.7e-2 and probe logits 2.2-2.7e-2 of their range after 128
-    Adam steps from a random init, t off by at most 9-12 of 1024 samples; 1-3 of the 20 picks are near-ties
-    (gap <= 3.8e-3 of the row's range) that fall the other way and are replaced by the reference's."""
-    _replay_two_stage("traj_fedmlp64", {"loss": 3e-3, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 3e-2,
-                                        "logits": 4e-2, "t_count": 16})
-
-
-def test_two_stage_flow_conditioned_golden_64_free_running(monkeypatch):
-    """The same replay with NO pick replaced, on the stem layout whose rounding happens to keep every first-round pick
-    on the reference's side (FM_STEM_PACKED=0): the whole flow then stays inside the same bounds by itself (measured
-    loss 1.4e-3, t off by 11 of 1024) -- the replacement above is not what holds the other runs in."""
-    from fedmlp_amd.engine import release_engines
-    monkeypatch.setenv("FM_STEM_PACKED", "0")
-    release_engines()                      # the stem layout is fixed when an engine is built
-    try:
-        rep = _replay_two_stage("traj_fedmlp64", {"loss": 3e-3, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 3e-2,
-                                                  "logits": 4e-2, "t_count": 16}, replace_near_ties=False)
-    finally:
-        release_engines()
-    assert rep["picks_replaced"] == 0
+    """Free-running on the library defaults; bounds are fixed numbers over the rounds (no per-round growth factor).
+    While the picks equal the reference's: loss 3e-3, weight norms 5e-3, BN-bias norms 1e-3, prototypes 3e-2, probe
+    logits 4e-2 of their range after 128 Adam steps from a random init, t within 16 of 1024 samples.  One boundary of
+    this golden is a near-tie IN THE REFERENCE (client 1, class 0, first stage-2 round: the 4th and 5th most similar
+    samples are 1.2e-3 of the row's range apart, `make_golden.py` prints every margin): an implementation with other
+    rounding may take the other one, after which the two runs train on pseudo-labelled sets that differ in one sample
+    of 1024 and are compared with the `after the split` bounds (t moves by tens of samples: its thresholds L / U cut
+    through the bulk of a barely trained classifier's probabilities)."""
+    rep = _replay_two_stage("traj_fedmlp64",
+                            {"loss": 3e-3, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 3e-2, "logits": 4e-2, "t_count": 16},
+                            {"loss": 1e-2, "norm": 5e-3, "bn_bias_norm": 1e-3, "proto": 6e-2, "logits": 8e-2, "t_count": 96})
+    assert rep["picks_total"] == 20
 
 
 def test_two_stage_flow_c14_golden():
-    """14 labels, 3 clients (configs[2] shape).  Measured (both stem layouts): loss 1.6-2.5e-3, norms 1.3-1.5e-3,
-    BN-bias norms 1.3-1.5e-4, prototypes 2.3-3.1e-2, probe logits 3.2-3.7e-2, t off by <= 8 of 448; 4 of 18 picks are
-    near-ties replaced by the reference's (gap <= 8.9e-3 of range, second stage-2 round)."""
-    rep = _replay_two_stage("traj_fedmlp_c14", {"loss": 4e-3, "norm": 4e-3, "bn_bias_norm": 1e-3, "proto": 6e-2,
-                                                "logits": 6e-2, "t_count": 14})
+    """14 labels, 3 clients (configs[2] shape), free-running: NaN prototype rows for the 11 classes nobody annotates,
+    tagging only where a prototype exists."""
+    rep = _replay_two_stage("traj_fedmlp_c14",
+                            {"loss": 4e-3, "norm": 4e-3, "bn_bias_norm": 1e-3, "proto": 6e-2, "logits": 6e-2, "t_count": 14},
+                            {"loss": 1.2e-2, "norm": 4e-3, "bn_bias_norm": 1e-3, "proto": 1e-1, "logits": 1e-1, "t_count": 64})
     assert rep["picks_total"] > 0

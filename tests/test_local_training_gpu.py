@@ -60,10 +60,9 @@ def _norms(sd):
 
 
 COND = load_golden("conditioning.json")["norms"]
-FLOW = load_golden("conditioning.json")["flow_1e-7"]      # oracle's own sensitivity to a 1e-7 perturbation
 
 
-def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6, rnd=0):
+def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6):
     """Per-tensor tolerance = max(rtol, 3x the deviation the CPU oracle itself shows for that
     tensor under a 1e-7 input perturbation / a different summation order, measured by
     tests/golden/make_conditioning.py): zero-initialised BN biases move by +-lr*sign(g) per
@@ -78,9 +77,9 @@ def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6, rnd=0):
         rel = err / (abs(w) + 1e-12)
         kind = "bn_bias" if (k.endswith(".bias") and not k.startswith("fc.")) else "other"
         worst[kind] = max(worst.get(kind, 0.0), rel)
-        # BN biases: the oracle's own deviation reaches 1.1e-2 per round and compounds over rounds
-        # (the deviation compounds across rounds: every round restarts from FedAvg of deviated nets)
-        tol = (5e-2 if kind == "bn_bias" else max(rtol, 3.0 * COND.get(k, 0.0))) * (rnd + 1)
+        # BN biases of a beta = 0 init (this golden's; the conditioned goldens of test_golden_r2_gpu.py start from
+        # beta = 0.1 n and hold 1e-3): the oracle's own deviation reaches 1.1e-2.  Fixed bounds, no per-round factor.
+        tol = 5e-2 if kind == "bn_bias" else max(rtol, 3.0 * COND.get(k, 0.0))
         if err > tol * abs(w) + atol:
             bad.append(f"{k}: got {got[k]} want {w} rel {rel:.2e} tol {tol:.1e}")
     report[what + " max norm rel err"] = worst
@@ -96,7 +95,8 @@ def _dump(report, name):
 def test_traj_train_config1():
     """BASELINE configs[0]: 2 clients, ResNet-18, warm-up BCE only, bs 32 (32x32 inputs)."""
     from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     from fedmlp_amd.fedavg import FedAvg
     g = load_golden("traj_train.json")
     C, n_cl, N = g["C"], g["n_clients"], g["N"]
@@ -127,82 +127,10 @@ def test_traj_train_config1():
     _dump(report, "parity_traj_train.json")
 
 
-def test_traj_fedmlp_two_stage():
-    """Full FedMLP flow (stage 1, prototype pass, tagging + selection, stage 2, FedAvg*)."""
-    from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
-    from fedmlp_amd.fedavg import FedAvg, FedAvg_tao, FedAvg_proto
-    g = load_golden("traj_fedmlp.json")
-    P = np.load(os.path.join(GOLDEN, "traj_fedmlp_protos.npz"))
-    C, n_cl, N, S1 = g["C"], g["n_clients"], g["N"], g["S1"]
-    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=S1, seed=g["init_seed"])
-    ds = SynthDataset(n_cl * N, C, g["hw"], g["data_seed"], True)
-    pos, neg = class_lists(ds.targets, C)
-    netglob = build_model(args)
-    locs = [LocalUpdate(args, i, ds, g["users"][i], pos, neg, active_class_list=[i]) for i in range(n_cl)]
-    tao, Prototype = [0] * C, []
-    neg_lists, act_lists = g["neg_lists"], g["act_lists"]
-    report = {}
-    for rnd, r in enumerate(g["rounds"]):
-        w, taos, protos = [], [], []
-        for i in range(n_cl):
-            if rnd < S1:
-                locs[i].order_queue.append(r["train_orders"][i])
-                a1 = (None, None) if rnd < S1 - 1 else (neg_lists[i], act_lists[i])
-            else:
-                locs[i].order_queue += [r["feat_orders"][i], r["train_orders"][i]]
-                a1 = (neg_lists[i], act_lists[i])
-            ret = locs[i].train_FedMLP(rnd, tao, Prototype, None, a1[0], a1[1], net=copy.deepcopy(netglob))
-            rel = abs(ret[1] - r["loss"][i]) / abs(r["loss"][i])
-            report[f"r{rnd}c{i} loss rel err"] = rel
-            assert rel < 2e-3 * (rnd + 1), (rnd, i, ret[1], r["loss"][i])
-            _cmp_norms(_norms(ret[0]), r["norms"][i], 1e-3, f"r{rnd}c{i}", report, rnd=rnd)
-            if rnd == 0:
-                assert ret[4] == neg_lists[i] and ret[5] == act_lists[i]
-            if rnd >= S1:
-                # selected lists only grow; every golden pick whose similarity margin to the next
-                # candidate exceeds the measured similarity sensitivity must be reproduced, and the
-                # list lengths (k = int(thr * count)) may move by the count sensitivity only
-                for got_l, want_l in zip(locs[i].traindata_idx, r["traindata_idx"][i]):
-                    assert abs(len(got_l) - len(want_l)) <= 1, (rnd, i, got_l, want_l)
-                report[f"r{rnd}c{i} selection identical"] = locs[i].traindata_idx == r["traindata_idx"][i]
-                if rnd == S1:
-                    assert locs[i].traindata_idx == r["traindata_idx"][i], (rnd, i)
-            w.append(copy.deepcopy(ret[0]))
-            if len(ret) == 8:
-                taos.append(ret[6]); protos.append(ret[7])
-                # t counts samples past a probability threshold and the prototypes are eval-mode
-                # features: the oracle itself moves them by FLOW[...] under a 1e-7 perturbation
-                dt = np.abs(ret[6] - P[f"r{rnd}_c{i}_t"]).max() * N
-                report[f"r{rnd}c{i} t count dev"] = float(dt)
-                assert dt <= 2 * FLOW["t_count_dev"] + 2, (rnd, i, ret[6], P[f"r{rnd}_c{i}_t"])
-                want = P[f"r{rnd}_c{i}_proto"]
-                dp = np.nanmax(np.abs(ret[7].numpy() - want)) / np.abs(want).max()
-                report[f"r{rnd}c{i} proto rel-to-max dev"] = float(dp)
-                assert dp <= 3 * FLOW["proto_rel_to_max_dev"], (rnd, i, dp)
-                assert np.array_equal(np.isnan(ret[7].numpy()), np.isnan(want))
-        netglob.load_state_dict(FedAvg(w, [N] * n_cl))
-        if rnd >= S1 - 1:
-            tao = FedAvg_tao(taos, [N] * n_cl, g["class_negative_client_list"])
-            Prototype = FedAvg_proto(protos, [N] * n_cl, g["class_active_client_list"])
-            assert np.abs(tao - np.array(r["tao"])).max() * N <= 2 * FLOW["t_count_dev"] + 2
-            want = P[f"r{rnd}_glob_proto"]
-            assert np.array_equal(np.isnan(Prototype.numpy()), np.isnan(want))      # NaN rows (Q12)
-            assert np.nanmax(np.abs(Prototype.numpy() - want)) <= 3 * FLOW["proto_rel_to_max_dev"] * \
-                np.nanmax(np.abs(want))
-        _cmp_norms(_norms(netglob.state_dict()), r["glob_norms"], 1e-3, f"r{rnd}glob", report, rnd=rnd)
-        netglob.eval()
-        _, z = netglob(ds.x1[:4])
-        want = np.array(r["probe_logits"])
-        dz = np.abs(z.cpu().numpy() - want).max() / np.abs(want).max()
-        report[f"r{rnd} probe logits rel-to-max dev"] = float(dz)
-        assert dz <= 3 * FLOW["proto_rel_to_max_dev"], (rnd, dz)
-    _dump(report, "parity_traj_fedmlp.json")
-
-
 def test_traj_fixmatch():
     from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     g = load_golden("traj_fixmatch.json")
     C, N = g["C"], g["N"]
     args = make_args(n_classes=C, n_clients=1, seed=g["init_seed"])
@@ -225,7 +153,8 @@ def test_traj_fixmatch():
 def test_step224_full_size():
     """One train step and one stage-1 step at the real 3x224x224 input size."""
     from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     g = load_golden("step224.json")
     C, N = g["C"], g["N"]
     args = make_args(n_classes=C, n_clients=1, batch_size=g["bs"], seed=g["init_seed"])
@@ -256,7 +185,8 @@ def test_traj_baselines_rscfed_fednoro_cbafed():
     """train_RSCFed / train_FedNoRo (warm-up) / train_CBAFed through the drop-in
     surface replay the trajectories recorded from the imported reference."""
     from fedmlp_amd.model import build_model
-    from fedmlp_amd.local_training import LocalUpdate
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     from fedmlp_amd.fedavg import consistency_weight
     g = load_golden("traj_baselines.json")
     C, N, hw = g["C"], g["N"], g["hw"]
@@ -315,7 +245,7 @@ def test_traj_baselines_rscfed_fednoro_cbafed():
     out = loc.train_CBAFed(1, net, pt=None, tao=r["tao"])
     report["cbafed stage-2 loss rel err"] = abs(out[1] - r["loss"][1]) / abs(r["loss"][1])
     assert report["cbafed stage-2 loss rel err"] < 5e-3, (out[1], r["loss"][1])
-    _cmp_norms(_norms(out[0]), r["norms"][1], 1e-3, "cbafed stage 2", report, rnd=1)
+    _cmp_norms(_norms(out[0]), r["norms"][1], 1e-3, "cbafed stage 2", report)
     # thresholded counts: a probability within rounding of tao may fall on the other side
     np.testing.assert_allclose(out[6].tolist(), r["class_num_list"][1], atol=2)
     assert abs(out[7] - r["data_num"][1]) <= 4

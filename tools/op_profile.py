@@ -17,9 +17,10 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--hw", type=int, default=224)
+ap.add_argument("--streams", type=int, default=0, help="engine stream mode: 1 = one stream (solo per-op times)")
 a = ap.parse_args()
 B, C = a.batch, 5
-eng = Engine("Efficient_b0", C, a.hw, a.hw, 2 * B, precision=a.precision)
+eng = Engine("Efficient_b0", C, a.hw, a.hw, 2 * B, precision=a.precision, streams=a.streams)
 flat, cnt = spec.init_state("Efficient_b0", C, 1037)
 eng.set_state(flat, cnt); eng.teacher_snapshot(); eng.adam_reset(3e-5)
 g = torch.Generator(device="cuda").manual_seed(1)
