@@ -127,3 +127,38 @@ def test_map_after_converged_training_matches_oracle():
     GPU box's host for the same three rounds), so 0.6 % is agreement within the metric's own resolution on a 4096-sample
     test set; the north star's +-0.2 % needs a real dataset to be decidable.  Bound: 1 % absolute."""
     _map_flow(512, 10, 3e-4, 4096, 1e-2, "parity_map_converged.json", signal=0.25, label_noise=0.06, avg_last=3)
+
+
+def test_map_two_stage_flow_paired_study():
+    """BASELINE.json's `mAP vs ref` as a measurable statement: the TWO-STAGE FedMLP flow (tests/map_flow.py: 4 clients, 5
+    stage-1 + 5 stage-2 rounds, 6 % label noise) for the same 16 seeds on both sides, test mAP / AUROC of the final global
+    model on a 32 768-sample test set.  The oracle half was run in the build container (tools/map_study.py ->
+    tests/golden/map_study_oracle.json); this is the HIP half.  Paired differences d_s = HIP_s - oracle_s:
+    |mean d| <= 0.2 % (the north star's figure), or <= 2 standard errors of the mean with s.e. <= 0.1 % -- a single pair
+    differs by a few tenths of a percent either way (two trajectories of a chaotic optimisation), the MEANS agree."""
+    import json
+    import os
+    from tests import map_flow as F
+    from tests.helpers import load_golden
+    g = load_golden("map_study_oracle.json")
+    seeds = sorted(int(s) for s in g["runs"])
+    assert len(seeds) >= 8, "the committed oracle fixture must hold at least 8 seeds"
+    x, _, y = F.make_split(F.N_TEST, F.TEST_SEED, False)
+    test_ds = F._DS(x, None, y)
+    runs, d_map, d_auc = {}, [], []
+    for s in seeds:
+        m, a = F.run_hip(s, test_ds)
+        runs[str(s)] = {"mAP": m, "auc": a}
+        d_map.append(m - g["runs"][str(s)]["mAP"]); d_auc.append(a - g["runs"][str(s)]["auc"])
+    rep = {"config": g["config"], "prevalence": g["prevalence"], "seeds": seeds,
+           "hip": {"runs": runs, "mAP": F.summarise([r["mAP"] for r in runs.values()]), "auc": F.summarise([r["auc"] for r in runs.values()])},
+           "oracle": {"runs": g["runs"], "mAP": g["mAP"], "auc": g["auc"]},
+           "paired_difference_hip_minus_oracle": {"mAP": F.summarise(d_map), "auc": F.summarise(d_auc),
+                                                  "max_abs_mAP": float(np.abs(d_map).max())}}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_map_two_stage.json", "w") as f:
+        json.dump(rep, f, indent=1)
+    assert g["mAP"]["mean"] > g["prevalence"] + 0.4, "the oracle did not learn"
+    for k in ("mAP", "auc"):
+        d = rep["paired_difference_hip_minus_oracle"][k]
+        assert abs(d["mean"]) <= 2e-3 or (abs(d["mean"]) <= 2 * d["se"] and d["se"] <= 1e-3), (k, d)
