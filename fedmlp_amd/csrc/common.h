@@ -3,7 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Tuning knobs of the kernels (tile orders, split counts, variant choices that were measured and settled): the shipped
+// library uses the defaults; a `make TUNING=1` build (-DFM_TUNING) reads them from the environment for measurements.
+// The few RUNTIME switches the shipped library does read are listed in DESIGN.md section 9, each with the test that
+// exercises it (FM_IGEMM_BLOCKS, FM_STEM_PACKED, FM_BN_MASK_FROM_Y, FM_EW_ROWS / FM_EW_ROWS_F32, FM_DW_GENERIC, FM_FUSE_GATE).
+inline int fm_tune(const char* name, int dflt)
+{
+#ifdef FM_TUNING
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // ---- activation storage types -------------------------------------------------------------------
 // The EfficientNet-B0 path stores its NHWC activations either as fp32 (the reference's arithmetic)

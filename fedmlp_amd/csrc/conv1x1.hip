@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
 // Returns false when the conv is not a plain small-K 1x1 stride-1 GEMM (the caller then runs igemm).
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
 {
-    static const int enabled = getenv("FM_STREAM1X1") ? atoi(getenv("FM_STREAM1X1")) : 1;
+    static const int enabled = fm_tune("FM_STREAM1X1", 1);
     if (!enabled || p.stem_kw || p.ntaps != 1 || p.dh[0] != 0 || p.dw[0] != 0) return false;
     if (p.sg != 1 || p.os != 1 || p.oh0 != 0 || p.ow0 != 0) return false;
     if (p.Hg != p.Ho || p.Wg != p.Wo || p.Hi != p.Ho || p.Wi != p.Wo) return false;
@@ -188,7 +188,7 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     // virtual tiles per block: enough pixels that staging the weight slice (MT*K*4 B) stays ~10 % of the block's
     // traffic, but no more -- small blocks launched in order keep the concurrently running ones on
     // neighbouring memory (DRAM locality, tools/ew_bw.hip)
-    static const int vt_env = getenv("FM_STREAM_VT") ? atoi(getenv("FM_STREAM_VT")) : 0;
+    static const int vt_env = fm_tune("FM_STREAM_VT", 0);
     const int bnv = p.M >= 128 ? 128 : 256;
     int vt = std::max(1, (int)((10LL * MT * p.Ci + (long long)bnv * (p.Ci + MT) - 1) / ((long long)bnv * (p.Ci + MT))));
     if (vt_env > 0) vt = vt_env;

@@ -443,28 +443,16 @@ void k_bnact_bwd_apply(const void* dz, int ta, const void* y, int ty, const floa
 }
 
 // ------------------------------------------------------------ depthwise conv ---
-// Three generations of kernels live here; the shipped path for EfficientNet-B0's shapes (TF-"same" padding of even inputs)
-// is the row-uniform family dw_rowu_* further down.  The register-blocked kernels (dw_*_blk*, round 1) and the generic
-// per-pixel ones remain as the fallback for other paddings / odd inputs and behind FM_DW_ROWU=0 / FM_DW_GENERIC=1.
-// FM_DW_BRANCHFREE=1 (compile time) builds the register-blocked kernels with address clamp + select (ld4z) and fenced
-// rows instead of predicated loads: measured, with the VGPR cap needed for 4 waves per SIMD the 5x5 forms spill
-// (straight-line code lets the scheduler hoist the whole (K+1) x (K+3) window), so it stays off.
-#ifndef FM_DW_BRANCHFREE
-#define FM_DW_BRANCHFREE 0
-#endif
-#if FM_DW_BRANCHFREE
-#define LD4Z(row, idx, stride, ok) ld4z((row) + (size_t)((ok) ? (idx) : 0) * (stride), (ok))
-#define ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define DW_LB(n) __launch_bounds__(256, n)
-#define ROW_SKIP(rv)
-#define ROW_OK(rv) true
-#else
+// The shipped path for EfficientNet-B0's shapes (TF-"same" padding of even inputs) is the row-uniform family dw_rowu_*
+// further down.  The generic per-pixel kernels remain as the fallback for other paddings / odd inputs and as the yardstick
+// of tests/test_effnet_gpu.py (FM_DW_GENERIC=1); the register-blocked weight-gradient kernels dw_wgrad_blk* still run the
+// fp32 3x3 layers (dw_wgrad_full).  The register-blocked forward / data-gradient kernels, the LDS-tiled kernel and the
+// kernel-row weight gradient of rounds 1-2 lost to the row-uniform family on every layer and were removed in round 3.
 #define LD4Z(row, idx, stride, ok) ((ok) ? ld4((row) + (size_t)(idx) * (stride)) : f32x4{0.f, 0.f, 0.f, 0.f})
 #define ROW_FENCE()
 #define DW_LB(n) __launch_bounds__(256)
 #define ROW_SKIP(rv) if (!(rv)) continue
 #define ROW_OK(rv) (rv)
-#endif
 // x [imgs][Hi][Wi][C], w [K*K][C], y [imgs][Ho][Wo][C]; pad_t/pad_l = TF-same top/left padding.
 // Optional fused eval epilogue: y = act(y*scale+shift).
 template <int K, typename T>
@@ -500,328 +488,10 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
     }
     st4(y + i * 4, acc);
 }
-// Register-blocked forms (the ones that run for EfficientNet-B0's shapes): one thread computes 4
-// consecutive output columns of one channel quad, so a K-wide row of taps costs 3*S+K loads
-// instead of 4*K.  Compile-time TF-"same" padding of an even input: (K-1)/2 at stride 1,
-// (K-2)/2 at stride 2; other paddings take the generic kernels above.
-template <int K, int S, typename T>
-__global__ DW_LB(4) void dw_fwd_blk_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                         T* __restrict__ y, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int imgs, int Hi, int Wi,
-                                                         int Ho, int Wo, int C, int act)
-{
-    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
-    constexpr int NIN = 3 * S + K;
-    const int Q = C >> 2, WB = (Wo + 3) >> 2;
-    const int64_t n = (int64_t)imgs * Ho * WB * Q;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int cq = (int)(i % Q);
-    int64_t t = i / Q;
-    const int ow0 = (int)(t % WB) * 4; t /= WB;
-    const int oh = (int)(t % Ho);
-    const int img = (int)(t / Ho);
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int iw0 = ow0 * S - PT;
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-        const int ih = oh * S + kh - PT;
-        const bool rv = (unsigned)ih < (unsigned)Hi;
-        ROW_SKIP(rv);
-        const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
-        f32x4 xin[NIN], wr[K];
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) {
-            const int iw = iw0 + j;
-            const bool ok = rv && (unsigned)iw < (unsigned)Wi;
-            xin[j] = LD4Z(xr, iw, C, ok);
-        }
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) wr[kw] = ld4(w + (kh * K + kw) * C + cq * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) acc[j] += xin[j * S + kw] * wr[kw];
-        ROW_FENCE();
-    }
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (scale) {
-        sc = ld4(scale + cq * 4);
-        sh = ld4(shift + cq * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (ow0 + j >= Wo) continue;
-        f32x4 v = acc[j];
-        if (scale) v = act_fwd<VecOf<T>::NV == 2>(v * sc + sh, act);
-        st4(y + ((size_t)(img * Ho + oh) * Wo + ow0 + j) * C + cq * 4, v);
-    }
-}
-// stride-1 forward, 2 output rows x 4 columns per thread: K+1 input rows serve both output rows (each row of
-// taps is loaded once and used with kernel row ir for the upper output row and ir-1 for the lower one), so a
-// 5x5 costs 6 loads per output instead of 10 and its weights are read once per 8 outputs -- the 5x5 layers are
-// bound by L1 bandwidth (16 float4 of L1 traffic per float4 of output in the one-row form).
-template <int K, typename T>
-__global__ DW_LB(4) void dw_fwd_blk2_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                          T* __restrict__ y, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, int imgs, int Hi, int Wi,
-                                                          int Ho, int Wo, int C, int act, int flip)
-{
-    // flip = 1 reads the kernel rotated by 180 degrees: the stride-1 data gradient is this same convolution
-    // of dy with the rotated kernel (same "same" padding), so it runs through this kernel too
-    constexpr int PT = (K - 1) / 2;
-    constexpr int NIN = 3 + K;
-    const int Q = C >> 2, WB = (Wo + 3) >> 2, HB = (Ho + 1) >> 1;
-    const int64_t n = (int64_t)imgs * HB * WB * Q;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int cq = (int)(i % Q);
-    int64_t t = i / Q;
-    const int ow0 = (int)(t % WB) * 4; t /= WB;
-    const int oh0 = (int)(t % HB) * 2;
-    const int img = (int)(t / HB);
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int iw0 = ow0 - PT;
-    // (PRELOAD: the thread's whole (K+1) x (K+3) input window requested up front and kept packed in registers.  Built and
-    // measured for bf16: 244 VGPRs = 2 waves per SIMD, depthwise forward 6.2 -> 8.4 ms per step -- off.)
-    constexpr bool PRELOAD = false;
-    uint2 raw[PRELOAD ? K + 1 : 1][PRELOAD ? NIN : 1];
-    if constexpr (PRELOAD) {
-#pragma unroll
-        for (int ir = 0; ir <= K; ++ir) {
-            const int ih = oh0 + ir - PT;
-            const bool rv = (unsigned)ih < (unsigned)Hi;
-            const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
-#pragma unroll
-            for (int j = 0; j < NIN; ++j) {
-                const int iw = iw0 + j;
-                raw[ir][j] = (rv && (unsigned)iw < (unsigned)Wi) ? *reinterpret_cast<const uint2*>(xr + (size_t)iw * C)
-                                                                 : make_uint2(0u, 0u);
-            }
-        }
-    }
-    f32x4 wprev[K];
-#pragma unroll
-    for (int ir = 0; ir <= K; ++ir) {
-        f32x4 wcur[K];
-        if (ir < K) {
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int wi = flip ? K * K - 1 - (ir * K + kw) : ir * K + kw;
-                wcur[kw] = ld4(w + wi * C + cq * 4);
-            }
-        }
-        const int ih = oh0 + ir - PT;
-        if (ROW_OK((unsigned)ih < (unsigned)Hi)) {
-            f32x4 xin[NIN];
-            if constexpr (PRELOAD) {
-#pragma unroll
-                for (int j = 0; j < NIN; ++j)
-                    xin[j] = __builtin_convertvector(__builtin_bit_cast(bf16x4, raw[ir][j]), f32x4);
-            } else {
-                const bool rv = (unsigned)ih < (unsigned)Hi;
-                const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
-#pragma unroll
-                for (int j = 0; j < NIN; ++j) {
-                    const int iw = iw0 + j;
-                    const bool ok = rv && (unsigned)iw < (unsigned)Wi;
-                    xin[j] = LD4Z(xr, iw, C, ok);
-                }
-            }
-            if (ir < K) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int kw = 0; kw < K; ++kw) acc[0][j] += xin[j + kw] * wcur[kw];
-            }
-            if (ir >= 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int kw = 0; kw < K; ++kw) acc[1][j] += xin[j + kw] * wprev[kw];
-            }
-        }
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
-        ROW_FENCE();
-    }
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (scale) {
-        sc = ld4(scale + cq * 4);
-        sh = ld4(shift + cq * 4);
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (oh0 + r >= Ho) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ow0 + j >= Wo) continue;
-            f32x4 v = acc[r][j];
-            if (scale) v = act_fwd<VecOf<T>::NV == 2>(v * sc + sh, act);
-            st4(y + ((size_t)(img * Ho + oh0 + r) * Wo + ow0 + j) * C + cq * 4, v);
-        }
-    }
-}
-
 static inline bool dw_blk_ok(int K, int S, int Hi, int Wi, int pad_t, int pad_l)
 {
     const int pt = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
     return (K == 3 || K == 5) && (S == 1 || S == 2) && pad_t == pt && pad_l == pt && !getenv("FM_DW_GENERIC");
-}
-// ---- LDS-tiled stride-1 depthwise convolution (forward; with the rotated kernel also the stride-1 data gradient) ----
-// The register-blocked kernels above re-read every input value (K+1)(K+3)/8 = 3 (3x3) or 6 (5x5) times through L1 and
-// run at 1.2-2.7 TB/s of their tensors' bytes while using ~7 % of the FMA rate.  Here a block owns ONE image x a
-// TH x TW output tile x CG = 4 CQ channels: the (TH+K-1) x (TW+K-1) input window is fetched once (16-B loads), converted
-// once, optionally passed through BN + Swish once (PRO: the expand conv's raw output is consumed directly and the
-// post-BN activation never exists in HBM), and parked in LDS as fp32; every thread then computes 2 rows x 4 columns
-// of one channel quad from LDS (ds_read_b128, pixel stride padded by 16 B so that the positions of a lane group fall on
-// different banks).  Weights sit in LDS too ([K*K][CG], rotated for the data gradient).
-template <int K, int TH, int TW, int CQ, typename T, bool PRO>
-__global__ __launch_bounds__(256) void dw_tile_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      const float* __restrict__ psc, const float* __restrict__ psh, int ipg,
-                                                      int H, int W, int C, int act, int flip, int tiles_x, int tiles_y)
-{
-    constexpr int PT = (K - 1) / 2;
-    constexpr int TIH = TH + K - 1, TIW = TW + K - 1;
-    constexpr int CG = 4 * CQ, PS = CG + 4;                  // channels per block, padded pixel stride (floats)
-    constexpr int NV = VecOf<T>::NV;                         // 16-B global pieces: 4 (fp32) or 8 (bf16) channels
-    constexpr int CPP = CG / (4 * NV);                       // pieces per pixel
-    constexpr bool FAST = NV == 2;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xs = lds;                                         // [TIH][TIW][PS]
-    float* ws = lds + TIH * TIW * PS;                        // [K*K][CG]
-    const int tid = threadIdx.x;
-    int b = blockIdx.x;
-    const int tx = b % tiles_x; b /= tiles_x;
-    const int ty = b % tiles_y;
-    const int img = b / tiles_y;
-    const int c0 = blockIdx.y * CG;
-    const int oh0 = ty * TH, ow0 = tx * TW;
-    // ---- stage weights (rotated by 180 degrees for the data gradient) and the input window ----------------------
-    for (int i = tid; i < K * K * CQ; i += 256) {
-        const int t = i / CQ, q = i - t * CQ;
-        const int c = c0 + 4 * q;
-        const int wi = flip ? K * K - 1 - t : t;
-        st4(ws + t * CG + 4 * q, c < C ? ld4(w + wi * C + c) : f32x4{0.f, 0.f, 0.f, 0.f});
-    }
-    const int g = PRO ? img / ipg : 0;
-    for (int i = tid; i < TIH * TIW * CPP; i += 256) {
-        const int pix = i / CPP, pc = i - pix * CPP;
-        const int r = pix / TIW, cc = pix - r * TIW;
-        const int ih = oh0 + r - PT, iw = ow0 + cc - PT;
-        const int c = c0 + pc * 4 * NV;
-        f32x4 v[NV];
-#pragma unroll
-        for (int h = 0; h < NV; ++h) v[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && c < C) {
-            ldv<NV>(x + ((size_t)(img * H + ih) * W + iw) * C + c, v);
-            if constexpr (PRO) {
-                f32x4 sc[NV], sh[NV];
-                ldf<NV>(psc + g * C + c, sc);
-                ldf<NV>(psh + g * C + c, sh);
-#pragma unroll
-                for (int h = 0; h < NV; ++h) v[h] = act_fwd<FAST>(v[h] * sc[h] + sh[h], 2);
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < NV; ++h) st4(xs + pix * PS + pc * 4 * NV + 4 * h, v[h]);
-    }
-    __syncthreads();
-    // ---- compute: thread = (channel quad, 2 x 4 output block) ---------------------------------------------------------
-    const int cq = tid % CQ, pos = tid / CQ;
-    const int pr = pos / (TW / 4), pcb = pos - pr * (TW / 4);
-    const int r0 = 2 * pr, cb = 4 * pcb;                      // tile-local output row / column of the thread's block
-    const int c = c0 + 4 * cq;
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 wprev[K];
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw) wprev[kw] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // a REAL loop over the K+1 input rows (not unrolled): unrolled, the compiler hoists all (K+1)(K+3) LDS reads to the
-    // top and the kernel needs 256 VGPRs (one block per CU); one row at a time it needs ~110
-#pragma unroll 1
-    for (int ir = 0; ir <= K; ++ir) {
-        f32x4 wcur[K], xin[K + 3];
-        const int irw = ir < K ? ir : K - 1;                 // row K has no taps of its own (feeds the lower output row only)
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) wcur[kw] = ld4(ws + (irw * K + kw) * CG + 4 * cq);
-        const float* xr = xs + ((r0 + ir) * TIW + cb) * PS + 4 * cq;
-#pragma unroll
-        for (int j = 0; j < K + 3; ++j) xin[j] = ld4(xr + j * PS);
-        if (ir < K) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int kw = 0; kw < K; ++kw) acc[0][j] += xin[j + kw] * wcur[kw];
-        }
-        if (ir >= 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int kw = 0; kw < K; ++kw) acc[1][j] += xin[j + kw] * wprev[kw];
-        }
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) wprev[kw] = wcur[kw];
-        ROW_FENCE();
-    }
-    if (c >= C) return;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (scale) { sc = ld4(scale + c); sh = ld4(shift + c); }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int oh = oh0 + r0 + r;
-        if (oh >= H) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ow = ow0 + cb + j;
-            if (ow >= W) continue;
-            f32x4 v = acc[r][j];
-            if (scale) v = act_fwd<FAST>(v * sc + sh, act);
-            st4(y + ((size_t)(img * H + oh) * W + ow) * C + c, v);
-        }
-    }
-}
-template <int K, int TH, int TW, int CQ, typename T>
-static void dw_tile_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, const float* psc,
-                           const float* psh, int ipg, int imgs, int H, int W, int C, int act, int flip, hipStream_t s)
-{
-    static_assert((TH / 2) * (TW / 4) * CQ == 256, "one 2x4 output block per thread");
-    constexpr int CG = 4 * CQ;
-    constexpr size_t lds = ((size_t)(TH + K - 1) * (TW + K - 1) * (CG + 4) + (size_t)K * K * CG) * sizeof(float);
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const dim3 grid(tiles_x * tiles_y * imgs, (C + CG - 1) / CG);
-    static bool done = false;
-    if (!done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&dw_tile_kernel<K, TH, TW, CQ, T, false>), (int)lds, "dw_tile_kernel");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&dw_tile_kernel<K, TH, TW, CQ, T, true>), (int)lds, "dw_tile_kernel");
-        done = true;
-    }
-    if (psc)
-        hipLaunchKernelGGL((dw_tile_kernel<K, TH, TW, CQ, T, true>), grid, dim3(256), lds, s, x, w, y, scale, shift, psc, psh, ipg, H, W,
-                           C, act, flip, tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL((dw_tile_kernel<K, TH, TW, CQ, T, false>), grid, dim3(256), lds, s, x, w, y, scale, shift, psc, psh, ipg, H, W,
-                           C, act, flip, tiles_x, tiles_y);
-}
-// tile shape by image width: 16x16 tiles of 32 channels tile 112 exactly; narrower images trade rows for columns / channels
-template <int K, typename T>
-static void dw_tile_t(const T* x, const float* w, T* y, const float* scale, const float* shift, const float* psc, const float* psh,
-                      int ipg, int imgs, int H, int W, int C, int act, int flip, hipStream_t s)
-{
-    if (W >= 100) dw_tile_launch<K, 16, 16, 8, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
-    else if (W >= 40) dw_tile_launch<K, 8, 32, 8, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
-    else if (W >= 12) dw_tile_launch<K, 8, 16, 16, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
-    else dw_tile_launch<K, 8, 8, 32, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, H, W, C, act, flip, s);
 }
 // ---- row-uniform stride-1 depthwise convolution -----------------------------------------------------------------------
 // The register-blocked kernels above spend ~5 VALU instructions per FMA on 64-bit addresses, bounds compares / selects
@@ -894,7 +564,7 @@ static inline int rowu_grid(int nchunk, int nrg, int xr)
     const int ngroups = (nrg + xr - 1) / xr;
     return (ngroups + 7) / 8 * 8 * nchunk * xr;
 }
-static inline int rowu_xr() { static const int v = getenv("FM_DW_XR") ? atoi(getenv("FM_DW_XR")) : 4; return v; }
+static inline int rowu_xr() { static const int v = fm_tune("FM_DW_XR", 4); return v; }
 // ST = 2 (data gradient of a block with an expand conv): the BN0-backward sums  S1 = sum dz*swish'(v),  S2 = sum dz*swish'(v)*xhat
 // (dz = the gradient this kernel stores, v = y_e*scale+shift, xhat = (y_e-mean)*istd) are taken here as well: y_e is read
 // at the output positions, the separate reduction pass over (dz, y_e) is gone.  bnq = {mean, istd, scale, shift} [groups][C].
@@ -1253,11 +923,6 @@ __global__ __launch_bounds__(256) void dw_rowu_dgrad_s2_kernel(const T* __restri
         }
     }
 }
-static inline int dw_rowu_mode() { static const int v = getenv("FM_DW_ROWU") ? atoi(getenv("FM_DW_ROWU")) : 2; return v; }
-static inline int dw_tile_mode() { static const int v = getenv("FM_DW_TILE") ? atoi(getenv("FM_DW_TILE")) : 1; return v; }
-static inline bool dw_tile_on(int W) { return dw_tile_mode() == 2 || (dw_tile_mode() == 1 && W >= 100); }
-// FM_DW_ROWU: 0 off / 1 wherever the LDS-tiled kernel is not selected / 2 everywhere
-static inline bool dw_rowu_on(int W) { return dw_rowu_mode() == 2 || (dw_rowu_mode() == 1 && !dw_tile_on(W)); }
 __global__ void dw_rowu_wgrad_reduce(const f32x4* __restrict__ part, float* __restrict__ out, int KK, int Q, int WB, int nchunk,
                                      int nrg, int nsplit);
 // Train-mode statistics request of a depthwise forward: rec = record workspace, out = [groups][1][2][C] partials for
@@ -1286,7 +951,7 @@ static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
 {
     const int WB = (W + 3) / 4, HB = (H + 1) / 2, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nrp = imgs * HB;
-    static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
+    static const int rpb_env = fm_tune("FM_DW_RPB", 16);
     int rpb = std::max(4, rpb_env);
     const int xr = rowu_xr();
     const BnQuad nobn{nullptr, nullptr, nullptr, nullptr};
@@ -1322,10 +987,6 @@ static bool dw_rowu_launch(const T* x, const float* w, T* y, const float* scale,
                        nrp, H, W, C, act, flip, nchunk, rpb, norec, noy, nobn, 1, xr);
     return false;
 }
-// Measured (bf16, 1024 images, FM_DW_TILE=2 forces the tiled kernel everywhere): it beats the register-blocked kernels
-// only where 16x16 tiles of 32 channels fit exactly -- block 0's 112x112x32: 0.61 -> 0.53 ms (3.1 TB/s) -- and loses
-// on every narrower layer (56x56x144: 0.77 -> 1.32 ms; 28x28x240: 0.59 -> 0.66 ms): two blocks per CU (57-76 KB of LDS)
-// with a barrier between staging and compute hide latency worse than 16 independent waves.  Default: tiled for W >= 100.
 
 template <int K, typename T>
 static bool dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* scale, const float* shift, int imgs, int Hi, int Wi,
@@ -1333,8 +994,8 @@ static bool dw_rowu_s2_launch(const T* x, const float* w, T* y, const float* sca
 {
     const int WB = (Wo + 3) / 4, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nrows = imgs * Ho;
-    static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
-    static const int pf_env = getenv("FM_DW_PF") ? atoi(getenv("FM_DW_PF")) : -1;
+    static const int rpb_env = fm_tune("FM_DW_RPB", 16);
+    static const int pf_env = fm_tune("FM_DW_PF", -1);
     int rpb = std::max(4, rpb_env);
     const bool pf = pf_env >= 0 ? pf_env != 0 : true;      // fp32 5x5 stride 2: 0.44 -> 0.32 ms with the second row buffer
     if (st && st->pool) {
@@ -1368,7 +1029,7 @@ static bool dw_rowu_dgrad_s2_launch(const T* dy, const float* w, T* dx, int imgs
 {
     const int WB = (Wi + 3) / 4, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nrows = imgs * Hi;
-    static const int rpb_env = getenv("FM_DW_RPB") ? atoi(getenv("FM_DW_RPB")) : 16;
+    static const int rpb_env = fm_tune("FM_DW_RPB", 16);
     int rpb = std::max(4, rpb_env);
     if (st && st->ye && nrows % st->groups == 0) {
         const int nrg_g = dw_stats_rowgroups(nrows / st->groups, nchunk, st->groups);
@@ -1393,36 +1054,15 @@ static bool dw_fwd_t(const T* x, const float* w, T* y, const float* scale, const
                      int Ho, int Wo, int C, int K, int stride, int pad_t, int pad_l, int act, hipStream_t s,
                      const float* psc = nullptr, const float* psh = nullptr, int ipg = 1, const DwStats* st = nullptr)
 {
-    static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
-    static const int fuse_st = getenv("FM_DW_STATS") ? atoi(getenv("FM_DW_STATS")) : 1;
-    if (!fuse_st) st = nullptr;
+    if (!fm_tune("FM_DW_STATS", 1)) st = nullptr;
     const dim3 blk(256);
-    if (dw_rowu_on(Wi) && !psc && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+    if (!psc && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
         if (K == 3) return dw_rowu_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s, st);
         return dw_rowu_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, C, act, 0, s, st);
     }
-    if (dw_rowu_mode() && !psc && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
+    if (!psc && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
         if (K == 3) return dw_rowu_s2_launch<3, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s, st);
         return dw_rowu_s2_launch<5, T>(x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, s, st);
-    }
-    if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        if (K == 3) dw_tile_t<3, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
-        else dw_tile_t<5, T>(x, w, y, scale, shift, psc, psh, ipg, imgs, Hi, Wi, C, act, 0, s);
-        return false;
-    }
-    if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const dim3 grid(cdiv((int64_t)imgs * ((Ho + 1) / 2) * ((Wo + 3) / 4) * (C / 4), 256));
-        if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
-        else hipLaunchKernelGGL((dw_fwd_blk2_kernel<5, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act, 0);
-        return false;
-    }
-    if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const dim3 grid(cdiv((int64_t)imgs * Ho * ((Wo + 3) / 4) * (C / 4), 256));
-        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_fwd_blk_kernel<3, 1, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
-        else if (K == 3) hipLaunchKernelGGL((dw_fwd_blk_kernel<3, 2, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
-        else if (stride == 1) hipLaunchKernelGGL((dw_fwd_blk_kernel<5, 1, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
-        else hipLaunchKernelGGL((dw_fwd_blk_kernel<5, 2, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, act);
-        return false;
     }
     const dim3 grid(cdiv((int64_t)imgs * Ho * Wo * (C / 4), 256));
     if (K == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, T>), grid, blk, 0, s, x, w, y, scale, shift, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, act);
@@ -1479,101 +1119,21 @@ __global__ void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restric
     }
     st4(dx + i * 4, acc);
 }
-// dgrad, register-blocked: 4 consecutive input columns per thread.  For input column iw0+j and tap
-// kw the output column is (iw0 + j + PT - kw)/S when that is an exact division; iw0 is a multiple
-// of 4, so which (j, kw) pairs are exact and their column offsets are compile-time.
-template <int K, int S, typename T>
-__global__ DW_LB(4) void dw_dgrad_blk_kernel(const T* __restrict__ dy, const float* __restrict__ w,
-                                                           T* __restrict__ dx, int imgs, int Hi, int Wi, int Ho,
-                                                           int Wo, int C)
-{
-    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
-    constexpr int OMIN = -((K - PT) / S);            // lowest column offset any (j, kw) can need (generous)
-    constexpr int OMAX = (3 + PT) / S;
-    constexpr int NC = OMAX - OMIN + 1;
-    const int Q = C >> 2, WB = (Wi + 3) >> 2;
-    const int64_t n = (int64_t)imgs * Hi * WB * Q;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int cq = (int)(i % Q);
-    int64_t t = i / Q;
-    const int iw0 = (int)(t % WB) * 4; t /= WB;
-    const int ih = (int)(t % Hi);
-    const int img = (int)(t / Hi);
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int cbase = iw0 / S + OMIN;
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-        const int a = ih + PT - kh;
-        if (a < 0 || (a % S) != 0) continue;
-        const int oh = a / S;
-        if (oh >= Ho) continue;
-        const T* dr = dy + ((size_t)(img * Ho + oh) * Wo) * C + cq * 4;
-        f32x4 din[NC], wr[K];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int ow = cbase + c;
-            const bool ok = (unsigned)ow < (unsigned)Wo;
-            din[c] = LD4Z(dr, ow, C, ok);
-        }
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) wr[kw] = ld4(w + (kh * K + kw) * C + cq * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int d = j + PT - kw;              // compile-time after unrolling
-                if (d % S != 0) continue;
-                acc[j] += din[d / S - OMIN] * wr[kw];
-            }
-        ROW_FENCE();
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (iw0 + j < Wi)
-            st4(dx + ((size_t)(img * Hi + ih) * Wi + iw0 + j) * C + cq * 4, acc[j]);
-}
-
 template <typename T>
 static bool dw_dgrad_t(const T* dy, const float* w, T* dx, int imgs, int Hi, int Wi, int Ho, int Wo, int C, int K,
                        int stride, int pad_t, int pad_l, hipStream_t s, const DwStats* st = nullptr)
 {
-    static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
-    static const int fuse_st = getenv("FM_DW_STATS") ? atoi(getenv("FM_DW_STATS")) : 1;
-    if (!fuse_st) st = nullptr;
+    if (!fm_tune("FM_DW_STATS", 1)) st = nullptr;
     const dim3 blk(256);
-    if (dw_rowu_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+    if (stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        // stride 1: dx = dy (*) rot180(w), the forward kernel with the rotated kernel (Hi == Ho, Wi == Wo)
         const float* nul = nullptr;
         if (K == 3) return dw_rowu_launch<3, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s, st);
         return dw_rowu_launch<5, T>(dy, w, dx, nul, nul, imgs, Hi, Wi, C, 0, 1, s, st);
     }
-    if (dw_rowu_mode() && stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
+    if (stride == 2 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == 2 * Wo && Hi == 2 * Ho) {
         if (K == 3) return dw_rowu_dgrad_s2_launch<3, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s, st);
         return dw_rowu_dgrad_s2_launch<5, T>(dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, s, st);
-    }
-    if (dw_tile_on(Wi) && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const float* nul = nullptr;
-        if (K == 3) dw_tile_t<3, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
-        else dw_tile_t<5, T>(dy, w, dx, nul, nul, nul, nul, 1, imgs, Hi, Wi, C, 0, 1, s);
-        return false;
-    }
-    if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        // stride 1: dx = dy (*) rot180(w), the forward kernel with the rotated kernel (Hi == Ho, Wi == Wo)
-        const dim3 grid(cdiv((int64_t)imgs * ((Hi + 1) / 2) * ((Wi + 3) / 4) * (C / 4), 256));
-        const float* nul = nullptr;
-        if (K == 3) hipLaunchKernelGGL((dw_fwd_blk2_kernel<3, T>), grid, blk, 0, s, dy, w, dx, nul, nul, imgs, Ho, Wo, Hi, Wi, C, 0, 1);
-        else hipLaunchKernelGGL((dw_fwd_blk2_kernel<5, T>), grid, blk, 0, s, dy, w, dx, nul, nul, imgs, Ho, Wo, Hi, Wi, C, 0, 1);
-        return false;
-    }
-    if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        const dim3 grid(cdiv((int64_t)imgs * Hi * ((Wi + 3) / 4) * (C / 4), 256));
-        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_dgrad_blk_kernel<3, 1, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
-        else if (K == 3) hipLaunchKernelGGL((dw_dgrad_blk_kernel<3, 2, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
-        else if (stride == 1) hipLaunchKernelGGL((dw_dgrad_blk_kernel<5, 1, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
-        else hipLaunchKernelGGL((dw_dgrad_blk_kernel<5, 2, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C);
-        return false;
     }
     const dim3 grid(cdiv((int64_t)imgs * Hi * Wi * (C / 4), 256));
     if (K == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, T>), grid, blk, 0, s, dy, w, dx, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l);
@@ -1772,77 +1332,6 @@ __global__ DW_LB(2) void dw_wgrad_blk2_kernel(const T* __restrict__ dy, const T*
         }
     }
 }
-// 5x5 weight gradient with the kernel ROWS dealt to threads: thread = (channel quad, kernel row kh, pixel lane) keeps 5
-// accumulators instead of 25 (the all-taps kernels above need 170-185 VGPRs = 2 waves per SIMD and run the 5x5 layers at
-// 0.45-0.8 TB/s of their tensors' bytes: latency-bound).  It re-reads dy once per kernel row (L1 hits) in exchange for
-// ~70 VGPRs.  S = 1: 2 rows x 4 columns of dy per step (2 input rows serve them); S = 2: 1 row x 4 columns.
-template <int K, int S, typename T>
-__global__ DW_LB(4) void dw_wgrad_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            float* __restrict__ part, int imgs, int Hi, int Wi, int Ho,
-                                                            int Wo, int C, int QT, int P)
-{
-    constexpr int PT = S == 1 ? (K - 1) / 2 : (K - 2) / 2;
-    constexpr int RB = S == 1 ? 2 : 1;                         // dy rows per step
-    constexpr int NIN = 3 * S + K;                             // input columns feeding 4 output columns
-    __shared__ f32x4 red[256];
-    const int Q = C >> 2;
-    const int t = threadIdx.x;
-    const int cql = t % QT, kh = (t / QT) % K, pl = t / (QT * K);
-    const int cq = blockIdx.y * QT + cql;
-    const bool act = pl < P && cq < Q;
-    const int WB = (Wo + 3) >> 2, HB = (Ho + RB - 1) / RB;
-    const int npb = imgs * HB * WB, nblk = gridDim.x;
-    const int chunk = (npb + nblk - 1) / nblk;
-    const int pb = blockIdx.x * chunk, pe = min(npb, pb + chunk);
-    f32x4 acc[K];
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw) acc[kw] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (act)
-        for (int p = pb + pl; p < pe; p += P) {
-            const int img = p / (HB * WB);
-            const int rem = p - img * HB * WB;
-            const int oh0 = (rem / WB) * RB, ow0 = (rem % WB) * 4;
-            const int iw0 = ow0 * S - PT;
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int oh = oh0 + r;
-                const int ih = oh * S + kh - PT;
-                const bool rv = oh < Ho && (unsigned)ih < (unsigned)Hi;
-                ROW_SKIP(rv);
-                const T* dr = dy + ((size_t)(img * Ho + (rv ? oh : 0)) * Wo) * C + cq * 4;
-                const T* xr = x + ((size_t)(img * Hi + (rv ? ih : 0)) * Wi) * C + cq * 4;
-                f32x4 d[4], xin[NIN];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = rv && ow0 + j < Wo;
-                    d[j] = LD4Z(dr, ow0 + j, C, ok);
-                }
-#pragma unroll
-                for (int j = 0; j < NIN; ++j) {
-                    const int iw = iw0 + j;
-                    const bool ok = rv && (unsigned)iw < (unsigned)Wi;
-                    xin[j] = LD4Z(xr, iw, C, ok);
-                }
-#pragma unroll
-                for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[kw] += d[j] * xin[j * S + kw];
-            }
-        }
-    // fold the P pixel lanes (fixed order) and store this thread's kernel row
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw) {
-        __syncthreads();
-        red[t] = acc[kw];
-        __syncthreads();
-        if (pl == 0 && t < QT * K && cq < Q) {
-            f32x4 v = red[t];
-            for (int k = 1; k < P; ++k) v += red[k * QT * K + t];
-            st4(part + ((size_t)blockIdx.x * K * K + kh * K + kw) * C + cq * 4, v);
-        }
-    }
-}
-
 // ---- row-uniform weight gradient ---------------------------------------------------------------------------------------
 // Same wave geometry as dw_rowu_kernel: a wave step = one (image, RB rows of dy) (RB = 2 at stride 1, 1 at stride 2),
 // lanes = (4-column block of dy, channel quad); every lane keeps ALL K*K tap accumulators of its quad and walks the
@@ -1979,7 +1468,7 @@ static void dw_rowu_wgrad_launch(const T* dy, const T* x, float* part, float* ou
     constexpr int RB = S == 1 ? 2 : 1;
     const int WB = (Wo + 3) / 4, HB = (Ho + RB - 1) / RB, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nsteps = imgs * HB;
-    static const int tgt = getenv("FM_DW_WG_BLOCKS") ? atoi(getenv("FM_DW_WG_BLOCKS")) : 1536;
+    static const int tgt = fm_tune("FM_DW_WG_BLOCKS", 1536);
     int spb = std::max(8, (int)(((int64_t)nsteps * nchunk + tgt - 1) / tgt));
     spb = (spb + 3) / 4 * 4;
     const int nrg = (nsteps + spb - 1) / spb;
@@ -2010,7 +1499,7 @@ static void dw_wgrad_full(const T* dy, const T* x, float* part, float* out, int 
     // quad) kernels below (block 3: 1.41 -> 0.41, block 9: 0.89 -> 0.22; sum 10.5 -> 4.1); fp32 gains on the 5x5 layers
     // (0.33 -> 0.17) and loses on the wide 3x3 ones (112x112x32: 0.35 -> 0.63, one row of lookahead is too little in
     // flight for 16-B loads), so fp32 3x3 keeps the older kernels.  FM_DW_WG_ROWU: 0 never / 1 this rule / 2 always.
-    static const int mode = getenv("FM_DW_WG_ROWU") ? atoi(getenv("FM_DW_WG_ROWU")) : 1;
+    static const int mode = fm_tune("FM_DW_WG_ROWU", 1);
     const bool pick = mode == 2 || (mode == 1 && (sizeof(T) == 2 || K == 5));
     if (pick && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l) && Wi == stride * Wo && Hi == stride * Ho) {
         if (K == 3 && stride == 1) dw_rowu_wgrad_launch<3, 1, T>(dy, x, part, out, imgs, Hi, Wi, Ho, Wo, C, s);
@@ -2029,32 +1518,13 @@ static void dw_wgrad_t(const T* dy, const T* x, float* part, int imgs, int Hi, i
     int QT, P, yt;
     dw_map(C, QT, P, yt);
     const dim3 grid(dw_wgrad_blocks(imgs * Ho * Wo), yt), blk(QT * P);
-    static const int rows2 = getenv("FM_DW_ROWS2") ? atoi(getenv("FM_DW_ROWS2")) : 1;
-    static const int krows = getenv("FM_DW_WGRAD_ROWS") ? atoi(getenv("FM_DW_WGRAD_ROWS")) : 1;
-    // Measured per layer (bf16, 1024 images): the row-split kernel wins where a block can take >= 42 channel quads of one
-    // pixel (C = 672: 1.08 -> 0.89 ms, its stride-2 layer 0.69 -> 0.41; C = 1152: 0.52 -> 0.30) and loses on the narrower
-    // layers (C = 144 / 240: fewer contiguous bytes per pixel, or a third of the block idle), which keep the all-taps kernel.
-    if (krows && K == 5 && C >= 640 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        // threads = QTr quads x 5 kernel rows x Pr pixel lanes <= 256
-        const int Q = C / 4;
-        int QTr = std::min(Q, 51);
-        while (Q % QTr) --QTr;
-        const int Pr = std::max(1, 256 / (QTr * 5));
-        const dim3 g2(dw_wgrad_blocks(imgs * Ho * Wo), Q / QTr), b2(256);
-        if (stride == 1) hipLaunchKernelGGL((dw_wgrad_rows_kernel<5, 1, T>), g2, b2, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QTr, Pr);
-        else hipLaunchKernelGGL((dw_wgrad_rows_kernel<5, 2, T>), g2, b2, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QTr, Pr);
+    // (reached by the fp32 3x3 layers only -- dw_wgrad_full -- and by paddings / sizes the row-uniform kernels do not take)
+    if (K == 3 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        hipLaunchKernelGGL((dw_wgrad_blk2_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
         return;
     }
-    if (rows2 && stride == 1 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        if (K == 3) hipLaunchKernelGGL((dw_wgrad_blk2_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
-        else hipLaunchKernelGGL((dw_wgrad_blk2_kernel<5, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
-        return;
-    }
-    if (dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
-        if (K == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_blk_kernel<3, 1, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
-        else if (K == 3) hipLaunchKernelGGL((dw_wgrad_blk_kernel<3, 2, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
-        else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_blk_kernel<5, 1, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
-        else hipLaunchKernelGGL((dw_wgrad_blk_kernel<5, 2, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
+    if (K == 3 && dw_blk_ok(K, stride, Hi, Wi, pad_t, pad_l)) {
+        hipLaunchKernelGGL((dw_wgrad_blk_kernel<3, 2, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, QT, P);
         return;
     }
     if (K == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, T>), grid, blk, 0, s, dy, x, part, imgs, Hi, Wi, Ho, Wo, C, stride, pad_t, pad_l, QT, P);

@@ -503,9 +503,123 @@ void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* i
 int bn_bwd_blocks(int pix_per_group)
 {
     // blocks per group of the channel reductions (<= 1024: ws_part is sized for that)
-    static const int cap = getenv("FM_BN_BLOCKS") ? std::min(1024, std::max(1, atoi(getenv("FM_BN_BLOCKS")))) : 1024;
+    static const int cap = std::min(1024, std::max(1, fm_tune("FM_BN_BLOCKS", 1024)));
     return max(1, min(cap, cdiv(pix_per_group, 64)));
 }
+
+// ---- stem: max-pool backward + BatchNorm backward without the dense intermediate ------------------------------------
+// The unfused order writes the dense 112x112 gradient of relu(bn(y0)) (stem_pool_bwd), reduces it against y0 and re-reads
+// both in the apply pass: 5.4 GB per bs-128 stage-1 step.  Here (a) the two BatchNorm-backward sums are taken over the
+// POOLED positions -- every window's gradient goes to its argmax, whose y0 is gathered -- and (b) the apply pass forms the
+// pooled-gradient sum of a dense position on the fly (the pool-backward loop) and applies ca*g + cb*y + cc in the same
+// thread: 3.4 GB.  Sums: s1 = sum g, s2 = sum g * xhat(y0 at the argmax), g = dp where pooled > 0 (the ReLU mask).
+__global__ void stem_pool_bn_reduce_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
+                                           const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                           const float* __restrict__ mean, const float* __restrict__ istd,
+                                           float* __restrict__ part, int imgs_per_group, int H, int W, int C)
+{
+    __shared__ f32x4 red[2][256];
+    const int g = blockIdx.y, nblk = gridDim.x;
+    const int Hp = H / 2, Wp = W / 2, Q = C >> 2, P = 256 / Q;
+    const int cq = threadIdx.x % Q, pl = threadIdx.x / Q;
+    const int npool = imgs_per_group * Hp * Wp;
+    const int TP = 8 * P;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + cq * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(istd + g * C + cq * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = blockIdx.x * TP; t0 < npool; t0 += nblk * TP)
+        for (int pp = t0 + pl; pp < min(npool, t0 + TP); pp += P) {
+            const int ow = pp % Wp;
+            const int t = pp / Wp;
+            const int oh = t % Hp;
+            const int img = g * imgs_per_group + t / Hp;
+            const size_t o = ((size_t)(img * Hp + oh) * Wp + ow) * C + cq * 4;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dp + o);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pooled + o);
+            const uchar4 c4 = *reinterpret_cast<const uchar4*>(idx + o);
+            const unsigned char code[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(pv[k] > 0.f)) continue;
+                const int ih = 2 * oh - 1 + code[k] / 3, iw = 2 * ow - 1 + code[k] % 3;
+                const float yy = y[((size_t)(img * H + ih) * W + iw) * C + cq * 4 + k];
+                s1[k] += d[k];
+                s2[k] += d[k] * ((yy - mu[k]) * is[k]);
+            }
+        }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < P; ++k) {
+            s1 += red[0][k * Q + cq];
+            s2 += red[1][k * Q + cq];
+        }
+        float* o = part + ((size_t)(g * nblk + blockIdx.x) * 2) * C + cq * 4;
+        *reinterpret_cast<f32x4*>(o) = s1;
+        *reinterpret_cast<f32x4*>(o + C) = s2;
+    }
+}
+__global__ void stem_pool_bn_apply_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
+                                          const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                          const float* __restrict__ ca, const float* __restrict__ cb,
+                                          const float* __restrict__ cc, float* __restrict__ dy, int imgs_per_group, int H,
+                                          int W, int C)
+{
+    const int g = blockIdx.y;
+    const int Hp = H / 2, Wp = W / 2, Q = C >> 2;
+    const int64_t n = (int64_t)imgs_per_group * H * W * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int iw = (int)(t % W); t /= W;
+    const int ih = (int)(t % H);
+    const int img = g * imgs_per_group + (int)(t / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oh_lo = ih >> 1, oh_hi = (ih + 1) >> 1;      // equal when ih is even
+    const int ow_lo = iw >> 1, ow_hi = (iw + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        if (oh >= Hp) continue;
+        const int kh = ih - (2 * oh - 1);
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            if (ow >= Wp) continue;
+            const int kw = iw - (2 * ow - 1);
+            const size_t o = ((size_t)(img * Hp + oh) * Wp + ow) * C + cq * 4;
+            const uchar4 c4 = *reinterpret_cast<const uchar4*>(idx + o);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pooled + o);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(dp + o);
+            const int code = kh * 3 + kw;
+            if (c4.x == code && pv[0] > 0.f) acc[0] += gg[0];
+            if (c4.y == code && pv[1] > 0.f) acc[1] += gg[1];
+            if (c4.z == code && pv[2] > 0.f) acc[2] += gg[2];
+            if (c4.w == code && pv[3] > 0.f) acc[3] += gg[3];
+        }
+    }
+    const size_t od = ((size_t)(img * H + ih) * W + iw) * C + cq * 4;
+    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + od);
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ca + g * C + cq * 4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(cb + g * C + cq * 4);
+    const f32x4 c4v = *reinterpret_cast<const f32x4*>(cc + g * C + cq * 4);
+    *reinterpret_cast<f32x4*>(dy + od) = a4 * acc + b4 * yy + c4v;
+}
+int stem_pool_bn_blocks(int pooled_per_group) { return bn_bwd_blocks(pooled_per_group); }
+void k_stem_pool_bn_reduce(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* mean,
+                           const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s)
+{
+    dim3 grid(stem_pool_bn_blocks(imgs_per_group * (H / 2) * (W / 2)), groups);
+    hipLaunchKernelGGL(stem_pool_bn_reduce_kernel, grid, dim3(256), 0, s, dpooled, pooled, idx, y, mean, istd, part,
+                       imgs_per_group, H, W, C);
+}
+void k_stem_pool_bn_apply(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* ca,
+                          const float* cb, const float* cc, float* dy, int groups, int imgs_per_group, int H, int W, int C,
+                          hipStream_t s)
+{
+    const int64_t n = (int64_t)imgs_per_group * H * W * (C / 4);
+    hipLaunchKernelGGL(stem_pool_bn_apply_kernel, dim3(cdiv(n, 256), groups), dim3(256), 0, s, dpooled, pooled, idx, y, ca, cb,
+                       cc, dy, imgs_per_group, H, W, C);
+}
+
 
 // ReLU mask of dz: from z (the stored post-activation, z > 0) or -- msc/msh given, z null -- recomputed from the conv
 // output the kernel reads anyway: relu(bn(y)) > 0  <=>  y*scale + shift > 0 with the forward's own per-group scale /
@@ -620,7 +734,7 @@ void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count
                        float* dbeta, hipStream_t s)
 {
     const float* src = part;
-    if (nblk > 64 && !getenv("FM_NO_BWD_FOLD")) {      // fold the per-block partials with many blocks first (same kernel as the forward statistics)
+    if (nblk > 64) {      // fold the per-block partials with many blocks first (same kernel as the forward statistics)
         float* folded = const_cast<float*>(part) + (size_t)groups * nblk * 2 * C;
         hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3(32, groups), dim3(256), 0, s, part, folded, nblk, 2 * C);
         src = folded;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/fedmlp_hip.h"
+#include "../../include/fedmlp_hip_debug.h"
 #include "comm.h"
 #include "common.h"
 #include "kernels.h"
@@ -1144,8 +1145,16 @@ void backward_and_step(fm_engine* e, int groups, int B)
         std::swap(ga, ge);
     }
     const Conv& c0 = e->convs[0];
-    k_stem_pool_bwd(ga, e->p0, e->idx0, e->dyh0, imgs, c0.hout, c0.wout, 64, e->st);
-    bn_bwd(e, 0, e->dyh0, nullptr, e->dyh0, nullptr, groups, B);
+    {
+        // max-pool backward + BatchNorm backward of the stem in two passes, without the dense intermediate (elementwise.hip)
+        Bn& b0 = e->bns[0];
+        const int pooled_pg = B * (c0.hout / 2) * (c0.wout / 2), pix = B * c0.hout * c0.wout;
+        k_stem_pool_bn_reduce(ga, e->p0, e->idx0, c0.y, b0.mean, b0.istd, e->ws_part, groups, B, c0.hout, c0.wout, 64, e->st);
+        k_bn_bwd_finalize(e->ws_part, groups, stem_pool_bn_blocks(pooled_pg), 64, pix, e->state + e->off_gamma + b0.ch_off,
+                          b0.mean, b0.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b0.ch_off,
+                          e->grad + e->off_beta + b0.ch_off, e->st);
+        k_stem_pool_bn_apply(ga, e->p0, e->idx0, c0.y, e->ca, e->cb, e->cc, e->dyh0, groups, B, c0.hout, c0.wout, 64, e->st);
+    }
     conv_wgrad(e, 0, e->x4, e->dyh0, imgs);
     if (sw) {
         soft(e, hipEventRecord(e->ev_wdone, e->st2));

@@ -409,7 +409,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     }
     // K per LDS stage: 32 (two stages) stages a whole 128-B line per DMA row -- the L1 hands out whole
     // lines, so the 64-B rows of the 16-k stages use half of what it moves.  Needs Ci % 32 == 0.
-    static const int ks32_mode = getenv("FM_KS32") ? atoi(getenv("FM_KS32")) : 2;
+    static const int ks32_mode = fm_tune("FM_KS32", 2);
     const bool ks32 = !p.stem_kw && p.Ci % 32 == 0 && (ks32_mode == 2 || (ks32_mode == 1 && p.M < 128));
     if (ks32) p.nsteps /= 2;           // the caller counts 16-k steps
     const long long T = (long long)p.tilesM * p.tilesN * groups;
@@ -418,7 +418,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     p.tapcode = 0;
     for (int t = 0; t < p.ntaps; ++t)      // taps of 3x3 / 1x1 convs and of their dgrad parity classes lie in [-1, 1]
         p.tapcode |= (unsigned long long)(((p.dh[t] + 1) & 3) | (((p.dw[t] + 1) & 3) << 2)) << (4 * t);
-    static const int tn_fast = getenv("FM_TN_FAST") ? atoi(getenv("FM_TN_FAST")) : 2;
+    static const int tn_fast = fm_tune("FM_TN_FAST", 2);
     // weights of one M-tile: BM rows x K floats; beyond ~1 MB per M-tile the all-M-tiles working set no longer fits L2
     p.tn_fast = tn_fast == 1 ? 1 : (tn_fast == 2 ? (p.tilesM > 1 && (long long)p.M * p.nsteps * 64 > (2LL << 20)) : 0);
     // persistent grid: every block slot whenever there are >= 4 K-steps for each of them, otherwise

@@ -58,6 +58,15 @@ void k_stem_pool(const float* y, const float* scale, const float* shift, float* 
                  int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);
 void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* idx, float* dy,
                      int imgs, int H, int W, int C, hipStream_t s);
+// stem: max-pool backward + BatchNorm backward without the dense 112x112 intermediate.  reduce: the two BN-backward sums over the
+// pooled positions (each window's gradient at its argmax, ReLU mask = pooled > 0) -> part[groups][stem_pool_bn_blocks()][2][C];
+// apply: dy[dense] = ca * (sum of the window gradients that chose this position) + cb * y + cc
+int stem_pool_bn_blocks(int pooled_per_group);
+void k_stem_pool_bn_reduce(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* mean,
+                           const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);
+void k_stem_pool_bn_apply(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* ca,
+                          const float* cb, const float* cc, float* dy, int groups, int imgs_per_group, int H, int W, int C,
+                          hipStream_t s);
 // backward: partial sums of dyh = dz*(z>0) and dyh*xhat -> part[groups][nblk][2][C]
 int bn_bwd_blocks(int pix_per_group);
 // ReLU mask of dz: z > 0 (z = stored post-activation), or, with z null and mask_scale / mask_shift given, y*scale+shift > 0

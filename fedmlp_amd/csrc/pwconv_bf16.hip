@@ -600,7 +600,7 @@ __global__ void cast_weights_kernel(const float* __restrict__ state, bf16* __res
 // ---- launchers ------------------------------------------------------------------------------------------
 // row tiles per block: 4 (64 channels).  K > 640: the slice is 86-147 KB -- one 8-wave block per CU (FM_PW_W8=0: two
 // 4-wave blocks of 32-channel tiles, the round-2 first form)
-static int pw_w8() { static const int v = getenv("FM_PW_W8") ? atoi(getenv("FM_PW_W8")) : 1; return v; }
+static int pw_w8() { static const int v = fm_tune("FM_PW_W8", 1); return v; }
 static int pw_rt(int K) { return (K <= 640 || (pw_w8() && K <= 1152)) ? 4 : 2; }     // K = 1280 (head dgrad): 164 KB, stays 32-channel
 static int pw_ppb(int npix_per_group, int groups, int M, int K)
 {
@@ -642,7 +642,7 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     const bool pro = p.gate != nullptr;
     size_t lds = (size_t)(p.K >> 5) * RT * 1024 + (size_t)RT * 512 + (pro ? (size_t)2 * p.K * 4 : 0);
     lds = std::max<size_t>(lds, (size_t)8 * MT * 2 * 4);
-    static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
+    static const int xcd = fm_tune("FM_PW_XCD", 1);
     p.tiles_m = (p.M + MT - 1) / MT;
     p.xcd = xcd;
     const dim3 grid(p.tiles_m * p.nblk * p.groups);
@@ -650,7 +650,7 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     // block 1's expand conv 1.07 -> 0.90 ms, the K <= 64 layers together -1.0 ms per step); 1 = 8 groups for K <= 32
     // (372 registers = 1 wave per SIMD: slower than 2).  Outputs are bit-identical across the settings; the BN partial
     // sums are taken in a different (still fixed) order.
-    static const int smallk = getenv("FM_PW_SMALLK") ? atoi(getenv("FM_PW_SMALLK")) : 2;
+    static const int smallk = fm_tune("FM_PW_SMALLK", 2);
     if (RT == 4 && smallk == 1 && p.K <= 32) pw_launch_t<4, 8, 1>(p, pro, grid, lds, s);
     else if (RT == 4 && smallk && p.K <= 64) pw_launch_t<4, 4, 2>(p, pro, grid, lds, s);
     else if (RT == 4 && p.K > 640) pw_launch_t<4, 2, 4, 8>(p, pro, grid, lds, s);
@@ -683,7 +683,7 @@ int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
     a.psc = w.psc; a.psh = w.psh; a.gate = w.gate; a.HW = w.HW; a.pix_per_group = w.pix_per_group;
     const int cc = a.S / 16;
     {   // small high-resolution layers: the barrier-free one-wave-per-tile kernel
-        static const int wave_on = getenv("FM_PW_WG_WAVE") ? atoi(getenv("FM_PW_WG_WAVE")) : 1;
+        static const int wave_on = fm_tune("FM_PW_WG_WAVE", 1);
         const int nrt = a.L / 16;
         const bool shape = (nrt == 2 && cc == 1) || (nrt == 6 && (cc == 1 || cc == 2)) || (nrt == 9 && cc == 2);
         // measured (ms, 1024 images): without prologue 96x16 0.77 -> 0.55, 144x32 0.35 -> 0.31; with the gate prologue 32x16
@@ -730,15 +730,15 @@ int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
     // more slab bytes than activations (bf16 bs-512 step 59.1 -> 58.3 ms) -- while layers whose partial is small
     // (<= FM_PW_WG_SMALL_KB, default 64: the early high-resolution ones, 24 x 96 = 12 KB) keep 2 048 blocks of >= 8 steps:
     // their gate / BN prologue is issue-bound and needs every SIMD busy (at 512 blocks the two largest ran 0.78 -> 1.9 ms).
-    static const int wg_blocks = getenv("FM_PW_WG_BLOCKS") ? atoi(getenv("FM_PW_WG_BLOCKS")) : 512;
-    static const int wg_minsteps = getenv("FM_PW_WG_MINSTEPS") ? atoi(getenv("FM_PW_WG_MINSTEPS")) : 32;
-    static const int wg_small_kb = getenv("FM_PW_WG_SMALL_KB") ? atoi(getenv("FM_PW_WG_SMALL_KB")) : 64;
+    static const int wg_blocks = fm_tune("FM_PW_WG_BLOCKS", 512);
+    static const int wg_minsteps = fm_tune("FM_PW_WG_MINSTEPS", 32);
+    static const int wg_small_kb = fm_tune("FM_PW_WG_SMALL_KB", 64);
     const bool small_partial = (size_t)w.M * w.K * 4 <= ((size_t)wg_small_kb << 10);
     int splits = std::max(1, (small_partial ? 2048 : wg_blocks) / tilesL);
     splits = std::min(splits, std::max(1, tsteps / (small_partial ? 8 : wg_minsteps)));
     splits = (int)std::min<size_t>(splits, std::max<size_t>(1, slab_floats / ((size_t)w.M * w.K)));
     const size_t lds = (size_t)2 * (32 * WG_STRIDE_BIG + 32 * a.strideS);
-    static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
+    static const int xcd = fm_tune("FM_PW_XCD", 1);
     a.tilesL = tilesL; a.nsplit = splits; a.xcd = xcd;
     const dim3 grid(tilesL * splits);
     const bool pro = w.gate != nullptr;

@@ -376,7 +376,7 @@ int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
     splits = (int)std::min<size_t>(splits, std::max<size_t>(1, slab_floats / ((size_t)w.M * w.Nw)));
     p.pix_per_split = (((w.npix + splits - 1) / splits) + 31) & ~31;
     splits = (w.npix + p.pix_per_split - 1) / p.pix_per_split;
-    static const int xcd = getenv("FM_PW_XCD") ? atoi(getenv("FM_PW_XCD")) : 1;
+    static const int xcd = fm_tune("FM_PW_XCD", 1);
     p.tilesL = tilesL; p.nsplit = splits; p.xcd = xcd;
     dim3 grid(tilesL * splits);
     const int cc = (S + 15) / 16;
@@ -397,7 +397,7 @@ int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
 // (ResNet layer 1: 576 = 3 x 192) and 256 otherwise for the 64-row tiles
 int wgrad_tile_n(int M, int Nw)
 {
-    static const int t192 = getenv("FM_WGRAD192") ? atoi(getenv("FM_WGRAD192")) : 1;
+    static const int t192 = fm_tune("FM_WGRAD192", 1);
     if (M >= 128) return 128;
     return (t192 && (Nw % 192 == 0 || Nw <= 192)) ? 192 : 256;      // Nw = 176: the packed 7x7 stem
 }

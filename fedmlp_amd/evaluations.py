@@ -35,7 +35,7 @@ def roc_auc(y_true, score):
     tps = np.r_[0.0, np.cumsum(y)[idx]]
     fps = np.r_[0.0, (1 + idx) - np.cumsum(y)[idx]]
     tpr, fpr = tps / tps[-1], fps / fps[-1]
-    return float(np.trapz(tpr, fpr))
+    return float((np.trapezoid if hasattr(np, "trapezoid") else np.trapz)(tpr, fpr))
 
 
 def multilabel_metrics(all_labels, all_probs, threshold=0.5):

@@ -256,41 +256,8 @@ int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms,
  * 399..415 / 500 backward. */
 int fm_profile_ops(fm_engine* e, int32_t enable, char* buf, int32_t cap);
 
-/* ---- kernel-level test hooks (tests/ only; not part of the drop-in surface) -- */
-/* info[0..12] = cin, cout, k, stride, pad, hin, win, hout, wout, cin_p (padded
- * input channels of the NHWC operand), Kw (row length of the engine-layout
- * weight matrix [cout_p][Kw] = [cout_p][k][kw_p][cin_p]), kw_p, cout_p (padded output
- * channels of the NHWC result; = cout for ResNet-18); info[13..15] = 0. */
-int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info16);
-int fm_debug_num_convs(fm_engine* e);
-/* op 0: raw forward  x[imgs,hin,win,cin_p] -> out[imgs,hout,wout,cout]; if stats_dev
- *       != NULL also the per-group per-channel (sum, sumsq) [groups][2][cout]
- * op 1: data gradient dy[imgs,hout,wout,cout] -> out[imgs,hin,win,cin]
- * op 2: weight gradient (x, dy) -> out[cout][Kw] (engine layout)
- * All tensors NHWC fp32 on device; weights are the engine's current state. */
-int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, const float* dy_dev,
-                  float* out_dev, int32_t imgs, int32_t groups, float* stats_dev);
-
-/* bf16 pointwise-convolution kernels of a precision-1 engine (conv must be a 1x1 convolution):
- * op 0: x bf16 [imgs,h,w,cin_p] -> out bf16 [imgs,h,w,cout_p] raw; stats_dev (optional) per-group (sum, sumsq)
- *       [groups][2][cout_p] fp32; gate_dev != NULL applies the operand prologue
- *       x <- swish(x*psc[g]+psh[g]) * gate[img]   (psc_dev NULL: x * gate[img]); psc/psh [groups][cin_p], gate [imgs][cin_p]
- * op 1: dy bf16 [imgs,h,w,cout_p] -> out bf16 [imgs,h,w,cin_p]; x_dev (optional) = residual added to the result
- * op 2: (x, dy) -> out fp32 [cout_p][cin_p], with the same optional prologue on x */
-int fm_debug_pw(fm_engine* e, int32_t op, int32_t conv, const void* x_dev, const void* dy_dev, void* out_dev,
-                int32_t imgs, int32_t groups, const float* psc_dev, const float* psh_dev, const float* gate_dev,
-                float* stats_dev);
-
-/* Post-ReLU activations the last train-mode forward kept (ResNet-18): kind 0 = relu(bn1(conv1)) of
- * basic block `block`, kind 1 = the block's output relu(bn2(conv2) + identity); NHWC fp32 for the first
- * `imgs` images, dims4 = {imgs, H, W, C}.  host_nhwc may be NULL to query the dims only.  Parity tests
- * hand the ReLU masks (value > 0) to the oracle's backward pass, so a pre-activation within rounding
- * distance of zero cannot turn a 1e-6 forward difference into a percent-level gradient difference. */
-int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs, float* host_nhwc,
-                        int32_t* dims4);
-
-/* Gradients of the last step in state_dict order (running-stat slots are 0). */
-int fm_debug_get_grads(fm_engine* e, float* host_f32);
+/* Kernel-level test hooks (fm_debug_*: single-kernel entry points, saved activations, last gradients) are declared in
+ * fedmlp_hip_debug.h; they are not part of the drop-in surface. */
 
 #ifdef __cplusplus
 }

@@ -114,7 +114,7 @@ def test_map_after_training_matches_oracle():
     random init) the CPU oracle's OWN mAP spreads over 0.9354 ... 0.9403 between 1, 4 and 8 threads and under a
     +-1e-6 weight perturbation (and 0.923 ... 0.928 on a 256-sample test set across hosts), so the test allows
     1.5 % absolute; the +-0.2 % of the north star is a statement about converged training on a real test set."""
-    _map_flow(96, 4, 3e-4, 1024, 1.5e-2, "parity_map.json")
+    _map_flow(96, 4, 3e-4, 1024, 1.5e-2, "parity_map_small.json")
 
 
 def test_map_after_converged_training_matches_oracle():
@@ -156,7 +156,7 @@ def test_map_two_stage_flow_paired_study():
            "paired_difference_hip_minus_oracle": {"mAP": F.summarise(d_map), "auc": F.summarise(d_auc),
                                                   "max_abs_mAP": float(np.abs(d_map).max())}}
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_map_two_stage.json", "w") as f:
+    with open("gpurun_out/parity_map.json", "w") as f:
         json.dump(rep, f, indent=1)
     assert g["mAP"]["mean"] > g["prevalence"] + 0.4, "the oracle did not learn"
     for k in ("mAP", "auc"):

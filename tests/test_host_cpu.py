@@ -120,7 +120,9 @@ def test_cabi_library_exports_every_declared_symbol():
     the ctypes table must cover the header one-to-one."""
     from fedmlp_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "fedmlp_hip.h")).read()
-    declared = set(re.findall(r"\b(fm_[a-z0-9_]+)\s*\(", hdr))
+    dbg = open(os.path.join(ROOT, "include", "fedmlp_hip_debug.h")).read()
+    assert not re.search(r"\bfm_debug_[a-z0-9_]+\s*\(", hdr), "test hooks belong in include/fedmlp_hip_debug.h"
+    declared = set(re.findall(r"\b(fm_[a-z0-9_]+)\s*\(", hdr + dbg))
     declared -= {"fm_engine", "fm_config", "fm_adam"}
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     if not os.path.exists(_lib.LIB_PATH):
