@@ -261,8 +261,9 @@ int aalloc(fm_engine* e, float** p, size_t n) { return dalloc(e, p, e->precision
 hipError_t create_side_stream(hipStream_t* st)
 {
     int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
+    const int pr = fm_tune("FM_SIDE_PRIO", 1);         // tuning builds: 1 lowest (shipped), 0 default, -1 highest
+    if (!pr || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr > 0 ? least : greatest);
 }
 
 int upload_tab(fm_engine* e, const std::vector<int4>& h, int4** d)

@@ -81,7 +81,10 @@ __device__ __forceinline__ int tile_row_to_channel(int r, int i, int npairs)
 // NW = waves per block (4, or 8 for the K > 640 layers: the weight slice of a 64-channel M-tile is then 86-147 KB of LDS,
 // one block per CU, and eight waves share it -- half the M-tiles, i.e. half the re-reads of the pixel operand, of the
 // 32-channel tiles two 4-wave blocks would use).
-template <int RT, bool PRO, int P = 2, int KB = 4, int NW = 4>
+// MODE: 0 plain store (+ residual), 1 train forward (BN partial sums from the accumulators), 2 eval forward (folded BN affine +
+// Swish + residual).  A compile-time choice: the running sums (32 registers) and the eval affine (32) were live across the
+// pixel loop of EVERY variant (188-244 registers, two waves per SIMD).
+template <int RT, bool PRO, int P = 2, int KB = 4, int NW = 4, int MODE = 0>
 __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
 {
     constexpr int MT = 16 * RT, PPI = 16 * P, NT = 64 * NW;
@@ -151,17 +154,21 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
     __syncthreads();
     const bool affine = PRO && p.psc != nullptr;
 
-    f32x4 s1[RT], s2[RT];
+    f32x4 s1[MODE == 1 ? RT : 1], s2[MODE == 1 ? RT : 1];
+    if constexpr (MODE == 1) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
     // eval epilogue: this lane's per-channel affine, loaded once (register r holds the 4 channels of row tile r)
-    f32x4 esc[RT], esh[RT];
+    f32x4 esc[MODE == 2 ? RT : 1], esh[MODE == 2 ? RT : 1];
+    if constexpr (MODE == 2) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        esc[r] = f32x4{1.f, 1.f, 1.f, 1.f}; esh[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.scale && r < nrt) {
-            const int m = m0 + tile_row_to_channel(r, 4 * lg, npairs);
-            esc[r] = ld4(p.scale + m); esh[r] = ld4(p.shift + m);
+        for (int r = 0; r < RT; ++r) {
+            esc[r] = f32x4{1.f, 1.f, 1.f, 1.f}; esh[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < nrt) {
+                const int m = m0 + tile_row_to_channel(r, 4 * lg, npairs);
+                esc[r] = ld4(p.scale + m); esh[r] = ld4(p.shift + m);
+            }
         }
     }
 
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
             }
         }
         // ---- epilogue of the iteration: acc[r][g][q] = D[channel(r, 4 lg + q)][pixel pix0 + 16 g + li] -----
-        if (p.stats) {
+        if constexpr (MODE == 1) {
 #pragma unroll
             for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -248,33 +255,36 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
         for (int g = 0; g < P; ++g) {
             if (!pv[g]) continue;
             const size_t o = (gbase + pix0 + 16 * g + li) * (size_t)p.M;
-            auto finish = [&](f32x4 v, int m, f32x4 sc, f32x4 sh) {
-                v = v * sc + sh;
+            auto finish = [&](f32x4 v, int m, int r) {
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int rr = 0; rr < RT; ++rr)
+                        if (rr == r) v = v * esc[rr] + esh[rr];          // static register index
+                }
                 if (p.res) v += ld4(p.res + o + m);
-                if (p.act == 2) v = swish4(v);
+                if constexpr (MODE == 2) { if (p.act == 2) v = swish4(v); }
                 return v;
             };
 #pragma unroll
             for (int u = 0; u < RT / 2; ++u) {
                 if (u >= npairs) break;
                 const int m = m0 + 32 * u + 8 * lg;
-                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m, esc[2 * u], esh[2 * u]),
-                                                               finish(acc[2 * u + 1][g], m + 4, esc[2 * u + 1], esh[2 * u + 1]));
+                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m, 2 * u), finish(acc[2 * u + 1][g], m + 4, 2 * u + 1));
             }
             if (nrt & 1) {
                 const int r = nrt - 1;
                 const int m = m0 + 16 * r + 4 * lg;
-                f32x4 v = acc[0][g], sc = esc[0], sh = esh[0];
+                f32x4 v = acc[0][g];
 #pragma unroll
                 for (int rr = 1; rr < RT; ++rr)
-                    if (rr == r) { v = acc[rr][g]; sc = esc[rr]; sh = esh[rr]; }   // static register index
-                *reinterpret_cast<uint2*>(p.Y + o + m) = pack4(finish(v, m, sc, sh));
+                    if (rr == r) v = acc[rr][g];             // static register index
+                *reinterpret_cast<uint2*>(p.Y + o + m) = pack4(finish(v, m, r));
             }
         }
     }
 
     // ---- BN statistics: fold the 16 pixel lanes, then the 4 waves (fixed order) -----------------------
-    if (p.stats) {
+    if constexpr (MODE == 1) {
         __syncthreads();                       // every wave is done with the weight slice: reuse the LDS
         float* red = reinterpret_cast<float*>(smem);          // [NW waves][MT][2]
 #pragma unroll
@@ -620,18 +630,25 @@ int pw_blocks(int npix_per_group, int groups, int M, int K)
     return (npix_per_group + ppb - 1) / ppb;
 }
 
-template <int RT, int P, int KB, int NW = 4>
-static void pw_launch_t(const PwParams& p, bool pro, dim3 grid, size_t lds, hipStream_t s)
+template <int RT, int P, int KB, int NW, int MODE>
+static void pw_launch_m(const PwParams& p, bool pro, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool attr_done = false;
     constexpr int cap = NW == 8 ? 156 * 1024 : 96 * 1024;
     if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, false, P, KB, NW>), cap, "pw_conv_bf16_kernel");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, true, P, KB, NW>), cap, "pw_conv_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, false, P, KB, NW, MODE>), cap, "pw_conv_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_conv_bf16_kernel<RT, true, P, KB, NW, MODE>), cap, "pw_conv_bf16_kernel");
         attr_done = true;
     }
-    if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, true, P, KB, NW>), grid, dim3(64 * NW), lds, s, p);
-    else hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, false, P, KB, NW>), grid, dim3(64 * NW), lds, s, p);
+    if (pro) hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, true, P, KB, NW, MODE>), grid, dim3(64 * NW), lds, s, p);
+    else hipLaunchKernelGGL((pw_conv_bf16_kernel<RT, false, P, KB, NW, MODE>), grid, dim3(64 * NW), lds, s, p);
+}
+template <int RT, int P, int KB, int NW = 4>
+static void pw_launch_t(const PwParams& p, bool pro, dim3 grid, size_t lds, hipStream_t s)
+{
+    if (p.stats) pw_launch_m<RT, P, KB, NW, 1>(p, pro, grid, lds, s);          // train forward: raw store + BN partial sums
+    else if (p.scale) pw_launch_m<RT, P, KB, NW, 2>(p, pro, grid, lds, s);     // eval forward: folded BN (+ Swish, residual)
+    else pw_launch_m<RT, P, KB, NW, 0>(p, pro, grid, lds, s);                  // data gradient (+ residual)
 }
 void launch_pw_conv(PwParams p, hipStream_t s)
 {
@@ -651,7 +668,8 @@ void launch_pw_conv(PwParams p, hipStream_t s)
     // (372 registers = 1 wave per SIMD: slower than 2).  Outputs are bit-identical across the settings; the BN partial
     // sums are taken in a different (still fixed) order.
     static const int smallk = fm_tune("FM_PW_SMALLK", 2);
-    if (RT == 4 && smallk == 1 && p.K <= 32) pw_launch_t<4, 8, 1>(p, pro, grid, lds, s);
+    if (RT == 4 && smallk == 3 && p.K <= 64) pw_launch_t<4, 1, 2>(p, pro, grid, lds, s);
+    else if (RT == 4 && smallk == 4 && p.K <= 64) pw_launch_t<4, 2, 2>(p, pro, grid, lds, s);
     else if (RT == 4 && smallk && p.K <= 64) pw_launch_t<4, 4, 2>(p, pro, grid, lds, s);
     else if (RT == 4 && p.K > 640) pw_launch_t<4, 2, 4, 8>(p, pro, grid, lds, s);
     else if (RT == 4) pw_launch_t<4, 2, 4>(p, pro, grid, lds, s);

@@ -10,6 +10,7 @@ from fedmlp_amd.engine import Engine
 ap = argparse.ArgumentParser()
 ap.add_argument("--imgs", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--only", default="", help="comma-separated conv indices")
 a = ap.parse_args()
 e = Engine("Efficient_b0", 5, 224, 224, a.imgs, precision="bf16", streams=1)
 dev = e.device
@@ -29,7 +30,7 @@ tot = {"fwd": 0.0, "pro": 0.0, "dgrad": 0.0}
 print("conv   M    K     HW | fwd ms GB/s | fwd+prologue ms GB/s | dgrad ms GB/s")
 for ci in range(e.debug_num_convs()):
     info = e.debug_conv_info(ci)
-    if info["k"] != 1:
+    if info["k"] != 1 or (a.only and str(ci) not in a.only.split(",")):
         continue
     M, K, h, w = info["cout_p"], info["cin_p"], info["hout"], info["wout"]
     npix = a.imgs * h * w
