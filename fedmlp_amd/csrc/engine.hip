@@ -1404,12 +1404,39 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
             guard(2, par);
             { OP("k_dw_dgrad"); sums = k_dw_dgrad(T_mid, S + m.dw_off, T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
                        m.pad_t, m.pad_l, e->st, ce.y, b0.mean, b0.istd, b0.scale, b0.shift, e->ws_slab, e->ws_part, groups); }
-            { OP("bnact_bwd"); bnact_bwd(e, m.bn0, T_big, ce.y, T_big, nullptr, groups, B * HWi, HWi, 2, nullptr, nullptr, -1,
-                                         sums ? dw_stats_tiles() : 0); }
-            side_begin(2, par);
-            { OP("exp_wgrad"); conv_wgrad(e, m.c_exp, in, T_big, imgs); }
-            side_end(2, par);
-            { OP("exp_dgrad"); conv_dgrad(e, m.c_exp, S, T_big, gi, imgs, m.skip ? go : nullptr, false); }
+            bool fused = false;
+            if (e->precision && (ce.cout_p == 96 || ce.cout_p == 144) && ce.cin_p <= 32) {
+                // early blocks (62 % of the expanded-tensor bytes): BN0-backward apply + weight gradient + data gradient of the
+                // expand conv in ONE kernel that reads d a_e and y_e once (pw_exp_bwd_kernel) instead of five passes over them
+                OP("exp_bwd_fused");
+                const int pix = B * HWi;
+                if (!sums)
+                    k_chan_reduce(T_big, e->dt, ce.y, e->dt, b0.mean, b0.istd, b0.scale, b0.shift, nullptr, e->ws_part, groups, pix,
+                                  HWi, b0.C, 1, 2, nullptr, nullptr, e->st);
+                k_bn_bwd_finalize(e->ws_part, groups, sums ? dw_stats_tiles() : bn_bwd_blocks(pix), b0.C, pix,
+                                  e->state + e->off_gamma + b0.ch_off, b0.mean, b0.istd, e->ca, e->cb, e->cc,
+                                  e->grad + e->off_gamma + b0.ch_off, e->grad + e->off_beta + b0.ch_off, e->st);
+                PwExpBwdParams q{};
+                q.dA = reinterpret_cast<const bf16*>(T_big); q.Ye = reinterpret_cast<const bf16*>(ce.y);
+                q.X = reinterpret_cast<const bf16*>(in); q.Wt = shadow_of(e, S) + ce.wbt_off;
+                q.res = reinterpret_cast<const bf16*>(m.skip ? go : nullptr); q.dX = reinterpret_cast<bf16*>(gi);
+                q.slab = e->ws_slab; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc; q.sc = b0.scale; q.sh = b0.shift;
+                q.L = ce.cout_p; q.S = ce.cin_p; q.npix = imgs * HWi; q.pix_per_group = pix; q.groups = groups;
+                const int sk = launch_pw_exp_bwd(q, e->slab_floats, e->st);
+                if (sk > 0) {
+                    k_reduce_slabs(e->ws_slab, G + ce.w_off, sk, (int64_t)ce.w_numel, e->st);
+                    fused = true;
+                }
+            }
+            if (!fused) {
+                // (a refused fused launch has left ca / cb / cc and the BN gradients exactly as bnact_bwd is about to)
+                { OP("bnact_bwd"); bnact_bwd(e, m.bn0, T_big, ce.y, T_big, nullptr, groups, B * HWi, HWi, 2, nullptr, nullptr, -1,
+                                             sums ? dw_stats_tiles() : 0); }
+                side_begin(2, par);
+                { OP("exp_wgrad"); conv_wgrad(e, m.c_exp, in, T_big, imgs); }
+                side_end(2, par);
+                { OP("exp_dgrad"); conv_dgrad(e, m.c_exp, S, T_big, gi, imgs, m.skip ? go : nullptr, false); }
+            }
         } else {
             { OP("k_dw_dgrad"); k_dw_dgrad(T_mid, S + m.dw_off, gi, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s, m.pad_t,
                        m.pad_l, e->st); }

@@ -43,6 +43,18 @@ struct PwWgradParams {
 // returns the number of splits written (reduce with k_reduce_slabs), 0 = shape not handled
 int launch_pw_wgrad(const PwWgradParams& p, size_t slab_floats, hipStream_t s);
 
+// Fused backward of an expand conv + BatchNorm + Swish (early MBConv blocks): reads d a_e and y_e once, forms d y_e on the
+// fly, writes the data gradient dX (+ residual) and fp32 partial slabs [slabs][L][S] of the weight gradient.
+struct PwExpBwdParams {
+    const bf16 *dA, *Ye, *X, *Wt, *res;      // [npix][L], [npix][L], [npix][S], W^T [S][L] (the conv's transposed shadow), [npix][S] or null
+    bf16* dX;
+    float* slab;
+    const float *ca, *cb, *cc, *sc, *sh;     // BN-backward coefficients and the forward's scale / shift, [groups][L]
+    int L, S, npix, pix_per_group, groups;
+};
+// returns the number of slabs written (reduce with k_reduce_slabs), 0 = shape not handled
+int launch_pw_exp_bwd(const PwExpBwdParams& p, size_t slab_floats, hipStream_t s);
+
 // fp32 master weights -> bf16 shadows, all 1x1 convolutions in one launch:
 // wb[w_off ...] = bf16(W[m][k]) row-major and wbt[t_off ...] = its transpose [K][M]
 struct CastJob { long long src_off, w_off, t_off; int M, K, blk0; };

@@ -582,6 +582,166 @@ __global__ __launch_bounds__(256) void pw_wgrad_wave_kernel(const WgArgs p, int 
     }
 }
 
+
+// =====================================================================================================
+// Fused backward of an expand (1x1) convolution with its BatchNorm + Swish, for the early high-resolution MBConv blocks
+// (ce = L <= 144, cin = S <= 32: 62 % of the network's expanded-tensor bytes).  The unfused order moves the expanded gradient
+// five times -- BN-backward apply (read d a_e and y_e, write d y_e), weight gradient (read d y_e), data gradient (read d y_e) --
+// here d a_e and y_e are read ONCE: a wave owns 32-pixel tiles, forms
+//     d y_e = ca * (d a_e * swish'(y_e * sc + sh)) + cb * y_e + cc        (bnact_bwd_apply_kernel's arithmetic)
+// in registers, rounds it to bf16 (the value the unfused path would have stored) into a wave-private LDS tile and feeds two
+// MFMA products from it:  dW[l][s] += sum_pix dy[pix][l] x[pix][s]  (transposed reads, as pw_wgrad_wave_kernel) and
+// dX[pix][s] = sum_l dy[pix][l] W[l][s] (+ residual)  (plain row reads of the tile against W^T rows held in LDS by the block).
+struct ExpBwdArgs {
+    const bf16 *dA, *Ye, *X, *Wt, *res;      // [npix][L], [npix][L], [npix][S], [S][L], [npix][S] or null
+    bf16* dX;                                // [npix][S]
+    float* slab;                             // [waves][L][S] fp32 partial dW (conv weight layout [M = L][K = S])
+    const float *ca, *cb, *cc, *sc, *sh;     // [groups][L]
+    int npix, pix_per_group, groups;
+    int strideB, strideS, strideW;           // LDS row strides in bytes (32 x odd)
+};
+template <int NRT, int CC>
+__global__ __launch_bounds__(256, 2) void pw_exp_bwd_kernel(const ExpBwdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int L = 16 * NRT, S = 16 * CC;
+    constexpr int CPB = 2 * NRT, CPS = 2 * CC;              // 16-B chunks per row of the L-wide / S-wide tiles
+    constexpr int NBG = (32 * CPB + 63) / 64, NSM = (32 * CPS + 63) / 64;
+    constexpr int NFULL = L / 32, TAIL = (L / 16) & 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int strideB = p.strideB, strideS = p.strideS, strideW = p.strideW;
+    unsigned char* wt = smem;                                           // [S][strideW]
+    float* vec = reinterpret_cast<float*>(smem + S * strideW);          // [groups][5][L]: ca, cb, cc, sc, sh
+    unsigned char* base = smem + S * strideW + (size_t)p.groups * 5 * L * 4 + (size_t)wave * 32 * (strideB + strideS);
+    unsigned char* sbase = base + 32 * strideB;
+    for (int c = tid; c < S * CPB; c += 256) {
+        const int row = c / CPB, cb = c - row * CPB;
+        *reinterpret_cast<uint4*>(wt + row * strideW + cb * 16) = *reinterpret_cast<const uint4*>(p.Wt + (size_t)row * L + 8 * cb);
+    }
+    for (int i = tid; i < p.groups * L; i += 256) {
+        const int g = i / L, l = i - g * L;
+        float* v = vec + (size_t)g * 5 * L;
+        v[l] = p.ca[i]; v[L + l] = p.cb[i]; v[2 * L + l] = p.cc[i]; v[3 * L + l] = p.sc[i]; v[4 * L + l] = p.sh[i];
+    }
+    __syncthreads();
+    const int ws = blockIdx.x * 4 + wave, nws = gridDim.x * 4;
+    const int tsteps = (p.npix + 31) >> 5;
+    const int nsteps = ws < tsteps ? (tsteps - ws + nws - 1) / nws : 0;
+    uint4 va[NBG], vy[NBG], vs[NSM];
+    // a 32-pixel tile of an [npix][L] tensor is one contiguous run of 32 * 2L bytes: chunk c = lane + 64 q of the tile sits at
+    // tile base + 16 c (one base address per tensor and step; npix % 32 == 0 is the launcher's precondition)
+    auto gload = [&](int st) {
+        const size_t pb = (size_t)(ws + st * nws) * 32;
+        const uint4* ta = reinterpret_cast<const uint4*>(p.dA + pb * L) + lane;
+        const uint4* ty = reinterpret_cast<const uint4*>(p.Ye + pb * L) + lane;
+        const uint4* tx = reinterpret_cast<const uint4*>(p.X + pb * S) + lane;
+#pragma unroll
+        for (int q = 0; q < NBG; ++q) {
+            if (64 * q + 63 < 32 * CPB || lane + 64 * q < 32 * CPB) { va[q] = ta[64 * q]; vy[q] = ty[64 * q]; }
+            else { va[q] = make_uint4(0u, 0u, 0u, 0u); vy[q] = va[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NSM; ++q) {
+            if (64 * q + 63 < 32 * CPS || lane + 64 * q < 32 * CPS) vs[q] = tx[64 * q];
+            else vs[q] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    // BN-backward apply on 4 channels: d = dA * swish'(y*sc+sh); ca*d + cb*y + cc   (fast exp / rcp like the bf16 passes)
+    auto bn4 = [&](f32x4 d, f32x4 y, const float* v) {
+        const f32x4 u = y * ld4(v + 3 * L) + ld4(v + 4 * L);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-u[k]));
+            d[k] *= sg * (1.f + u[k] * (1.f - sg));
+        }
+        return ld4(v) * d + ld4(v + L) * y + ld4(v + 2 * L);
+    };
+    auto lstore = [&](int st) {
+        const int pb = (ws + st * nws) * 32;
+        const float* vg = vec + (size_t)(pb / p.pix_per_group) * 5 * L;         // a tile lies inside one statistics group
+#pragma unroll
+        for (int q = 0; q < NBG; ++q) {
+            const int c = lane + 64 * q;
+            const int row = c / CPB, cb = c - row * CPB;
+            if (c < 32 * CPB)
+                *reinterpret_cast<uint4*>(base + row * strideB + cb * 16) =
+                    pack8(bn4(lo4(va[q]), lo4(vy[q]), vg + 8 * cb), bn4(hi4(va[q]), hi4(vy[q]), vg + 8 * cb + 4));
+        }
+#pragma unroll
+        for (int q = 0; q < NSM; ++q) {
+            const int c = lane + 64 * q;
+            const int row = c / CPS, cb = c - row * CPS;
+            if (c < 32 * CPS) *reinterpret_cast<uint4*>(sbase + row * strideS + cb * 16) = vs[q];
+        }
+    };
+    f32x4 acc[NRT][CC];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) { gload(0); lstore(0); }
+    const int trow = 4 * lg + (li >> 2), tcol = 4 * (li & 3);
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + 1 < nsteps) gload(st + 1);
+        // ---- weight gradient: P[l][s] += sum_pix dy[pix][l] x[pix][s] (transposed fragments of both tiles) ----
+        uint4 b[CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const unsigned char* bb = sbase + trow * strideS + (16 * c + tcol) * 2;
+            const uint2 b0 = ds_read_tr16(bb), b1 = ds_read_tr16(bb + 16 * strideS);
+            b[c] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        }
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            const unsigned char* ab = base + trow * strideB + (16 * r + tcol) * 2;
+            const uint2 a0 = ds_read_tr16(ab), a1 = ds_read_tr16(ab + 16 * strideB);
+            const uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) acc[r][c] = mfma32(a, b[c], acc[r][c]);
+        }
+        // ---- data gradient: D[s][pix] = sum_l W^T[s][l] dy[pix][l]; lane (li, lg) ends with 4 consecutive s of pixel li ----
+        const int pb = (ws + st * nws) * 32;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            f32x4 dx[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) dx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* yrow = base + (16 * pt + li) * strideB;
+#pragma unroll
+            for (int kc = 0; kc < NFULL; ++kc) {
+                const uint4 bf = *reinterpret_cast<const uint4*>(yrow + (32 * kc + 8 * lg) * 2);
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    dx[c] = mfma32(*reinterpret_cast<const uint4*>(wt + (16 * c + li) * strideW + (32 * kc + 8 * lg) * 2), bf, dx[c]);
+            }
+            if (TAIL) {
+                const uint2 bf = *reinterpret_cast<const uint2*>(yrow + (32 * NFULL + 4 * lg) * 2);
+#pragma unroll
+                for (int c = 0; c < CC; ++c)
+                    dx[c] = mfma16(*reinterpret_cast<const uint2*>(wt + (16 * c + li) * strideW + (32 * NFULL + 4 * lg) * 2), bf, dx[c]);
+            }
+            const size_t o0 = ((size_t)pb + 16 * pt + li) * S + 4 * lg;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                f32x4 v = dx[c];
+                if (p.res) v += ld4(p.res + o0 + 16 * c);
+                *reinterpret_cast<uint2*>(p.dX + o0 + 16 * c) = pack4(v);
+            }
+        }
+        if (st + 1 < nsteps) lstore(st + 1);
+    }
+    // acc[r][c][q] = dW[l = 16 r + 4 lg + q][s = 16 c + li]; this wave's slab (zeros when it had no tile)
+    float* slab = p.slab + (size_t)ws * L * S;
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slab[(size_t)(16 * r + 4 * lg + q) * S + 16 * c + li] = acc[r][c][q];
+}
+
 // smallest 32 x odd >= bytes
 int odd32(int bytes)
 {
@@ -770,6 +930,37 @@ int launch_pw_wgrad(const PwWgradParams& w, size_t slab_floats, hipStream_t s)
     default: wg_launch<20>(a, pro, grid, lds, s); break;
     }
     return splits;
+}
+
+
+// Fused BN0-backward apply + expand-conv weight gradient + data gradient (pw_exp_bwd_kernel).  Returns the number of
+// [M][K] slabs written (reduce with k_reduce_slabs), 0 = shape not handled (the caller runs the three separate passes).
+int launch_pw_exp_bwd(const PwExpBwdParams& w, size_t slab_floats, hipStream_t s)
+{
+    const int nrt = w.L / 16, cc = w.S / 16;
+    const bool shape = (nrt == 6 && cc == 1) || (nrt == 9 && cc == 2);
+    if (!shape || (w.L & 15) || (w.S & 15) || w.pix_per_group % 32 != 0 || w.npix % 32 != 0 || w.groups < 1 || w.groups > 2) return 0;
+    static const int on = fm_tune("FM_PW_EXP_BWD", 1);
+    if (!on) return 0;
+    ExpBwdArgs a{};
+    a.dA = w.dA; a.Ye = w.Ye; a.X = w.X; a.Wt = w.Wt; a.res = w.res; a.dX = w.dX; a.slab = w.slab;
+    a.ca = w.ca; a.cb = w.cb; a.cc = w.cc; a.sc = w.sc; a.sh = w.sh;
+    a.npix = w.npix; a.pix_per_group = w.pix_per_group; a.groups = w.groups;
+    a.strideB = odd32(2 * w.L); a.strideS = odd32(2 * w.S); a.strideW = odd32(2 * w.L);
+    const int tsteps = (w.npix + 31) / 32;
+    int nblk = std::max(1, std::min(768, tsteps / 32));
+    nblk = (int)std::min<size_t>(nblk, std::max<size_t>(1, slab_floats / ((size_t)4 * w.L * w.S)));
+    const size_t lds = (size_t)w.S * a.strideW + (size_t)w.groups * 5 * w.L * 4 + (size_t)4 * 32 * (a.strideB + a.strideS);
+#define EXP_BWD(N, C)                                                                                                   \
+    do {                                                                                                                \
+        static bool done_ = false;                                                                                      \
+        if (!done_) { set_max_dyn_lds(reinterpret_cast<const void*>(&pw_exp_bwd_kernel<N, C>), 96 * 1024, "pw_exp_bwd"); done_ = true; } \
+        hipLaunchKernelGGL((pw_exp_bwd_kernel<N, C>), dim3(nblk), dim3(256), lds, s, a);                                \
+    } while (0)
+    if (nrt == 6) EXP_BWD(6, 1);
+    else EXP_BWD(9, 2);
+#undef EXP_BWD
+    return 4 * nblk;
 }
 
 void launch_cast_weights(const float* state, bf16* shadow, const CastJob* jobs, int njobs, int nblocks, hipStream_t s)

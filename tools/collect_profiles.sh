@@ -1,7 +1,7 @@
 #!/bin/bash
-# copy the judged records of a tools/gpu_full.sh + tools/prof_stats.sh pass from gpurun_out/ (scratch) into profiles/r02/
+# copy the judged records of a tools/gpu_full.sh + tools/prof_stats.sh pass from gpurun_out/ (scratch) into profiles/r03/
 # usage: tools/collect_profiles.sh <tag>      (expects gpurun_out/<tag>/ and gpurun_out/<tag>_{s1,cf,ef32,ebf}/)
-TAG=$1; D=profiles/r02
+TAG=$1; D=profiles/r03
 mkdir -p $D
 cp gpurun_out/$TAG/bench_*.json $D/ 2>/dev/null
 cp gpurun_out/$TAG/pytest.log $D/pytest_gpu.log 2>/dev/null

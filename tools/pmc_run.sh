@@ -9,11 +9,11 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/$TAG.$C
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$TAG.$C -- python3 bench.py "$@" --steps $STEPS --warmup $WARM --no-cpu-baseline --no-profile > $OUT/$TAG.$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$TAG.$C -- python3 bench.py "$@" --one-stream --steps $STEPS --warmup $WARM --no-cpu-baseline --no-profile > $OUT/$TAG.$C.log 2>&1
 done
 F=$(find $OUT/$TAG.FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/$TAG.WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python3 tools/pmc_traffic.py "$F" "$W" $OUT/pmc_traffic.json "$KEY" $((STEPS+WARM)) "bench.py $* --steps $STEPS --warmup $WARM"
+python3 tools/pmc_traffic.py "$F" "$W" $OUT/pmc_traffic.json "$KEY" $((STEPS+WARM)) "bench.py $* --one-stream --steps $STEPS --warmup $WARM"
 rm -rf $OUT/$TAG.FETCH_SIZE $OUT/$TAG.WRITE_SIZE
 python3 - <<PY
 import json

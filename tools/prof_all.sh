@@ -14,6 +14,6 @@ bash tools/pmc_run.sh s1 Resnet18/fp32/stage1/bs128/hw224/C5 6 2 2>&1 | tail -3
 bash tools/pmc_run.sh cf Resnet18/fp32/conv_fwd/bs256/hw224/C5 6 2 --workload conv_fwd --batch 256 2>&1 | tail -3
 bash tools/pmc_run.sh ef32 Efficient_b0/fp32/stage1/bs256/hw224/C5 4 2 --model Efficient_b0 --batch 256 2>&1 | tail -3
 bash tools/pmc_run.sh ebf Efficient_b0/bf16/stage1/bs512/hw224/C5 4 2 --model Efficient_b0 --precision bf16 --batch 512 2>&1 | tail -3
-python tools/op_profile.py --precision bf16 --batch 512 > gpurun_out/${TAG}_op_bf16.txt 2>&1
-python tools/op_profile.py --precision fp32 --batch 256 > gpurun_out/${TAG}_op_f32.txt 2>&1
+python tools/op_profile.py --precision bf16 --batch 512 --streams 1 > gpurun_out/${TAG}_op_bf16.txt 2>&1
+python tools/op_profile.py --precision fp32 --batch 256 --streams 1 > gpurun_out/${TAG}_op_f32.txt 2>&1
 head -12 gpurun_out/${TAG}_op_bf16.txt
