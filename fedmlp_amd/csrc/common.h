@@ -126,6 +126,10 @@ struct IgemmParams {
     int imgs_per_group;   // images per BN-statistics group (grid.y = group)
     int tilesM, tilesN;   // tiles per group
     int relu;
+    // conv1x1.hip only: per-image gate on the operand, Xe[pix][k] = X[pix][k] * gate[pix / gate_HW][k] (the squeeze-excite
+    // gate of an eval-mode project conv: the gated activation is never written); null = no prologue
+    const float* gate = nullptr;
+    int gate_HW = 1;
 };
 
 // Weight-gradient GEMM: dW[m][n] = sum_p dY[p][m] * Xg[p][n], split over p.
@@ -147,6 +151,7 @@ struct WgradParams {
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 // small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
+bool conv1x1_stream_takes(int Ci, int M, int Co);     // would a stride-1 1x1 conv of this shape stream through conv1x1.hip?
 int igemm_max_blocks();
 bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s);    // false = split exceeds the 32-bit offset span
 int wgrad_tile_n(int M, int Nw);

@@ -26,7 +26,10 @@ constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
 
 // RT = 16-row MFMA tiles per block (MT = 16*RT output channels), P = 16-pixel groups per wave iteration:
 // the shipped instantiation is <4,2> = 64 channels x 32 pixels
-template <int RT, int P>
+// STATS: train forward (BN partial sums kept in registers across the pixel loop) -- a template parameter so that the eval /
+// data-gradient launches do not carry the 32 sum registers (3 -> 4 waves per SIMD)
+// GATE: the operand is multiplied by a per-image, per-channel gate on load (IgemmParams::gate)
+template <int RT, int P, bool STATS, bool GATE = false>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p, int vt_per_block, int blocks_per_group)
 {
     constexpr int MT = 16 * RT;
@@ -56,9 +59,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
 
     const int aoff = li * 16 + ((lg ^ ((li >> 1) & 3)) << 2);       // fragment read offset inside a 16-row tile
     const int nrt = min(RT, (p.M - m0 + 15) >> 4);                   // 16-row tiles of this M-tile that hold real rows
-    f32x4 s1[RT], s2[RT];
+    f32x4 s1[STATS ? RT : 1], s2[STATS ? RT : 1];
+    if constexpr (STATS) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int r = 0; r < RT; ++r) { s1[r] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[r] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
 
     constexpr int PPI = 16 * P;                                     // pixels per wave iteration
     const int n_iter = (pe - pb + PPI - 1) / PPI;
@@ -70,9 +75,12 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
             const int px = pb + it * PPI + 16 * g + li;
             const bool v = px < pe;
             const float* xp = p.X + (gbase + (v ? px : pb)) * K + 4 * lg;
+            const float* gp = GATE ? p.gate + ((gbase + (v ? px : pb)) / p.gate_HW) * K + 4 * lg : nullptr;
 #pragma unroll
-            for (int k = 0; k < KB; ++k)
+            for (int k = 0; k < KB; ++k) {
                 b[g][k] = (v && kb + k < nkk) ? *reinterpret_cast<const f32x4*>(xp + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (GATE) { if (v && kb + k < nkk) b[g][k] *= *reinterpret_cast<const f32x4*>(gp + (kb + k) * 16); }
+            }
         }
     };
     for (int it = wave; it < n_iter; it += 4) {
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
             for (int r = 0; r < RT; ++r) {
                 const int m = m0 + 16 * r + 4 * lg;
                 f32x4 v = acc[r][g];
-                if (p.stats) { s1[r] += v; s2[r] += v * v; }     // rows of padded pixels are exact zeros
+                if constexpr (STATS) { s1[r] += v; s2[r] += v * v; }     // rows of padded pixels are exact zeros
                 if (!pv || m >= p.M) continue;
                 const size_t o = (gbase + px) * p.Co + m;
                 if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + m) + *reinterpret_cast<const f32x4*>(p.shift + m);
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
     }
 
     // ---- BN statistics: fold the 16 pixel lanes, then the 4 waves (fixed order) -----------------------
-    if (p.stats) {
+    if constexpr (STATS) {
         __syncthreads();                       // every wave is done with the weight slice: reuse the LDS
         float* red = As;                       // [4 waves][MT][2]
 #pragma unroll
@@ -168,6 +176,12 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
 }  // namespace
 
 // Returns false when the conv is not a plain small-K 1x1 stride-1 GEMM (the caller then runs igemm).
+// shapes the streaming kernel takes (also asked by the engine before it hands over a gate prologue)
+bool conv1x1_stream_takes(int Ci, int M, int Co)
+{
+    static const int enabled = fm_tune("FM_STREAM1X1", 1);
+    return enabled && Ci <= 256 && Ci % 16 == 0 && Co == M;
+}
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
 {
     static const int enabled = fm_tune("FM_STREAM1X1", 1);
@@ -177,7 +191,8 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (p.Ci > 256 || p.Ci % 16 != 0 || p.Co != p.M) return false;
     static bool attr_done = false;
     if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2>), 64 * 256 * 4, "conv1x1_stream_kernel<4, 2>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, true>), 64 * 256 * 4, "conv1x1_stream_kernel<4, 2, true>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, false>), 64 * 256 * 4, "conv1x1_stream_kernel<4, 2, false>");
         attr_done = true;
     }
     // (128-channel instantiations for wide outputs measured 2 % slower end to end, both <8,1> -- shorter pixel
@@ -194,6 +209,11 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;
     const size_t lds = std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
-    hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+    if (p.gate) {
+        static bool g_done = false;
+        if (!g_done) { set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, false, true>), 64 * 256 * 4, "conv1x1_stream_kernel<gate>"); g_done = true; }
+        hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false, true>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+    } else if (p.stats) hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, true>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+    else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
     return true;
 }

@@ -819,6 +819,10 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
     }
     p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
+    if (pro && pro->gate && !pro->psc) {         // fp32 eval project conv: only the streaming kernel (conv1x1.hip) applies the gate
+        p.gate = pro->gate; p.gate_HW = c.hout * c.wout;
+        if (!conv1x1_stream_takes(c.cin_p, c.cout_p, c.cout_p) || c.k != 1 || c.stride != 1) soft(e, hipErrorInvalidValue);
+    }
     p.M = c.cout_p; p.nsteps = c.nsteps;
     p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
     if (c.stem3) { p.Hi = c.Hp; p.Wi = c.Wp; }
@@ -1301,7 +1305,10 @@ void eff_forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool
                  m.k, m.s, m.pad_t, m.pad_l, 2, e->st, e->ws_slab, nullptr, 1, e->se_pool); }
         { OP("k_se_fwd"); k_se_fwd(m.y_d, e->dt, nullptr, nullptr, 1, e->se_pool, S + m.w1_off, S + m.b1_off, S + m.w2_off, S + m.b2_off, m.sq,
                  m.rpre, m.gate, imgs, HWo, m.ce_p, m.cs, e->st, pooled); }
-        if (fuse_for(e, m)) {      // the gate multiplies the activation on the project conv's operand load
+        // the gate multiplies the activation on the project conv's operand load: bf16 wherever the conv reads it once or twice,
+        // fp32 where the conv streams through conv1x1.hip (K <= 256: the high-resolution blocks)
+        const Conv& cpj = e->convs[m.c_proj];
+        if (fuse_for(e, m) || (!e->precision && conv1x1_stream_takes(cpj.cin_p, cpj.cout_p, cpj.cout_p))) {
             const Prologue pro{nullptr, nullptr, m.gate};
             { OP("proj_fwd"); conv_fwd(e, m.c_proj, S, m.y_d, m.out, imgs, 1, sc(m.bn2), sh(m.bn2), m.skip ? cur : nullptr, 0, nullptr, &pro); }
         } else {
