@@ -1860,15 +1860,17 @@ __global__ void bn1_sums_kernel(const float* __restrict__ pool5, int nch, const 
 void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, const float* shift, const float* mean,
                   const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
                   const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
-                  hipStream_t s)
+                  hipStream_t s, int nch_ready)
 {
     int QT, P, yt;
     dw_map(dt == DT_BF16 ? C / 2 : C, QT, P, yt);
     // fewer, longer pixel chunks than the forward pooling: the five-way fold at the end of a block is amortised over
     // >= 512 pixels, and imgs x nch blocks still fill the chip
-    const int nch = std::max(1, std::min(chan_pool_chunks(HW), std::max(HW / 512, imgs >= 512 ? 1 : 2)));
+    // nch_ready > 0: pool_ws already holds that many records per image (pw_proj_bwd_kernel phase 0 took the sums)
+    const int nch = nch_ready > 0 ? nch_ready : std::max(1, std::min(chan_pool_chunks(HW), std::max(HW / 512, imgs >= 512 ? 1 : 2)));
     const dim3 grid(nch, imgs), blk(QT * P);
-    if (dt == DT_F32)
+    if (nch_ready > 0) {}
+    else if (dt == DT_F32)
         hipLaunchKernelGGL((chan_pool5_kernel<float>), grid, blk, 0, s, cp<float>(dout), cp<float>(y), pool_ws, HW, C, QT, P, scale,
                            shift, mean, istd, ipg);
     else

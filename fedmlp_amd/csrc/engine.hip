@@ -1377,28 +1377,61 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         guard(0, par);
         { OP("bnact_bwd"); bnact_bwd(e, m.bn2, go, cp.y, T_small, dc, groups, B * HWo, HWo, 0); }
         Bn& b1 = e->bns[m.bn1];
-        side_begin(0, par);
-        if (fuse_for(e, m)) {      // the project conv's operand a_s was never stored: re-formed from y_d on load
-            const Prologue pro{b1.scale, b1.shift, m.gate};
-            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.y_d, T_small, imgs, &pro, B * HWo); }
-        } else
-            { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.a_s, T_small, imgs); }
-        side_end(0, par);
-        guard(1, par);
-        { OP("proj_dgrad"); conv_dgrad(e, m.c_proj, S, T_small, T_mid, imgs, nullptr, false); }          // d a_s
-        // a_s = a_d * gate(a_d)
-        // ONE pass over (d a_s, y_d) yields the squeeze-excite backward's pooled sums and the BN1-backward sums
         float* dgp = (sw && par) ? e->se_dgp2 : e->se_dgp;       // the squeeze-excite gradient vectors alternate too
         float* drp = (sw && par) ? e->se_drp2 : e->se_drp;
-        guard(3, par);
-        { OP("k_se_bwd"); k_se_bwd_bn1(T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
-                     S + m.w1_off, S + m.w2_off, dgp, drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
-        side_begin(3, par);
-        { OP("k_se_wgrad"); k_se_wgrad(dgp, drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
-        side_end(3, par);
-        // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
-        { OP("bnact_bwd"); bnact_bwd(e, m.bn1, T_mid, m.y_d, T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
-                                     se_bwd_bn1_splits(B)); }   // d y_d
+        // early blocks (half of the depthwise-resolution bytes): d a_s is never stored -- pw_proj_bwd_kernel forms it twice on the
+        // matrix pipe, once for the five per-image sums + the weight gradient, once for the BN1-backward apply (7 passes -> 3)
+        const int nch5 = e->precision ? pw_proj_bwd_nch(m.ce_p, cp.cout_p, imgs, HWo) : 0;
+        bool pfused = false;
+        if (nch5) {
+            PwProjBwdParams q{};
+            q.dYp = reinterpret_cast<const bf16*>(T_small); q.Yd = reinterpret_cast<const bf16*>(m.y_d);
+            q.Wt = shadow_of(e, S) + cp.wbt_off; q.dYd = reinterpret_cast<bf16*>(T_mid);
+            q.slab = e->ws_slab; q.pool5 = e->se_pool;
+            q.sc = b1.scale; q.sh = b1.shift; q.mean = b1.mean; q.istd = b1.istd; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc;
+            q.gate = m.gate; q.ds = e->se_ds;
+            q.L = m.ce_p; q.S = cp.cout_p; q.imgs = imgs; q.HW = HWo; q.ipg = B; q.nch = nch5;
+            int sk;
+            { OP("proj_bwd_sums"); sk = launch_pw_proj_bwd(q, 0, e->slab_floats, e->st);
+              if (sk > 0) k_reduce_slabs(e->ws_slab, G + cp.w_off, sk, (int64_t)cp.w_numel, e->st); }
+            if (sk > 0) {
+                guard(3, par);
+                { OP("k_se_bwd"); k_se_bwd_bn1(nullptr, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
+                             S + m.w1_off, S + m.w2_off, dgp, drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st, nch5); }
+                side_begin(3, par);
+                { OP("k_se_wgrad"); k_se_wgrad(dgp, drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
+                side_end(3, par);
+                guard(1, par);
+                { OP("proj_bwd_apply");
+                  k_bn_bwd_finalize(e->ws_part, groups, se_bwd_bn1_splits(B), b1.C, B * HWo, e->state + e->off_gamma + b1.ch_off, b1.mean,
+                                    b1.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b1.ch_off, e->grad + e->off_beta + b1.ch_off,
+                                    e->st);
+                  if (launch_pw_proj_bwd(q, 1, e->slab_floats, e->st) != 1) soft(e, hipErrorInvalidValue); }      // d y_d
+                pfused = true;
+            }
+        }
+        if (!pfused) {
+            side_begin(0, par);
+            if (fuse_for(e, m)) {      // the project conv's operand a_s was never stored: re-formed from y_d on load
+                const Prologue pro{b1.scale, b1.shift, m.gate};
+                { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.y_d, T_small, imgs, &pro, B * HWo); }
+            } else
+                { OP("proj_wgrad"); conv_wgrad(e, m.c_proj, m.a_s, T_small, imgs); }
+            side_end(0, par);
+            guard(1, par);
+            { OP("proj_dgrad"); conv_dgrad(e, m.c_proj, S, T_small, T_mid, imgs, nullptr, false); }          // d a_s
+            // a_s = a_d * gate(a_d)
+            // ONE pass over (d a_s, y_d) yields the squeeze-excite backward's pooled sums and the BN1-backward sums
+            guard(3, par);
+            { OP("k_se_bwd"); k_se_bwd_bn1(T_mid, m.y_d, e->dt, b1.scale, b1.shift, b1.mean, b1.istd, B, e->se_pool, m.gate, m.rpre,
+                         S + m.w1_off, S + m.w2_off, dgp, drp, e->se_ds, e->ws_part, imgs, HWo, m.ce_p, m.cs, e->st); }
+            side_begin(3, par);
+            { OP("k_se_wgrad"); k_se_wgrad(dgp, drp, m.rpre, m.sq, e->ws_slab, G + m.w1_off, imgs, m.ce_p, m.cs, e->st); }
+            side_end(3, par);
+            // d a_d = d a_s * gate + ds/HW is formed on load inside the BN backward's apply pass
+            { OP("bnact_bwd"); bnact_bwd(e, m.bn1, T_mid, m.y_d, T_mid, nullptr, groups, B * HWo, HWo, 2, m.gate, e->se_ds, -1,
+                                         se_bwd_bn1_splits(B)); }   // d y_d
+        }
         const float* a_e = m.c_exp >= 0 ? m.a_e : in;
         side_begin(1, par);
         { OP("k_dw_wgrad"); k_dw_wgrad(T_mid, a_e, e->dt, e->ws_slab, G + m.dw_off, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,

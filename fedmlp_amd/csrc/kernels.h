@@ -129,7 +129,7 @@ int se_bwd_bn1_splits(int ipg);       // per-group partials k_se_bwd_bn1 leaves 
 void k_se_bwd_bn1(const void* dout, const void* y, int dt, const float* scale, const float* shift, const float* mean,
                   const float* istd, int ipg, float* pool_ws, const float* gate, const float* rpre, const float* W1,
                   const float* W2, float* dgp, float* drp, float* ds, float* bn_part, int imgs, int HW, int C, int Cs,
-                  hipStream_t s);
+                  hipStream_t s, int nch_ready = 0);
 // dW1 = start of the contiguous [dW1 | db1 (padded to 4) | dW2 | db2] gradient range; part = workspace (16 slabs of it)
 void k_se_wgrad(const float* dgp, const float* drp, const float* rpre, const float* sq, float* part, float* dW1, int imgs, int C,
                 int Cs, hipStream_t s);

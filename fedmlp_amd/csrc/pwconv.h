@@ -55,6 +55,21 @@ struct PwExpBwdParams {
 // returns the number of slabs written (reduce with k_reduce_slabs), 0 = shape not handled
 int launch_pw_exp_bwd(const PwExpBwdParams& p, size_t slab_floats, hipStream_t s);
 
+// Fused backward of a project conv with the squeeze-excite gate and BN1 + Swish in front of it (early MBConv blocks), two
+// launches around the squeeze-excite backward: phase 0 = chan_pool5's per-image sums + the weight gradient's slabs from ONE
+// read of y_d, phase 1 = d y_d (BN1-backward apply of the re-formed d a_s) from one more read.  d a_s is never stored.
+struct PwProjBwdParams {
+    const bf16 *dYp, *Yd, *Wt;               // [npix][S], [npix][L], W^T [L][S]
+    bf16* dYd;                               // phase 1 result [npix][L]
+    float *slab, *pool5;                     // phase 0 results: [slabs][S][L], [imgs][nch][5][L]
+    const float *sc, *sh, *mean, *istd, *ca, *cb, *cc;   // [groups][L]
+    const float *gate, *ds;                  // [imgs][L]
+    int L, S, imgs, HW, ipg, nch;            // ipg = images per statistics group, nch = pw_proj_bwd_nch(...)
+};
+int pw_proj_bwd_nch(int L, int S, int imgs, int HW);      // pooling records per image; 0 = shape not handled
+// phase 0: returns the number of slabs written (0 = not handled); phase 1: 1 = launched, 0 = not handled
+int launch_pw_proj_bwd(const PwProjBwdParams& p, int phase, size_t slab_floats, hipStream_t s);
+
 // fp32 master weights -> bf16 shadows, all 1x1 convolutions in one launch:
 // wb[w_off ...] = bf16(W[m][k]) row-major and wbt[t_off ...] = its transpose [K][M]
 struct CastJob { long long src_off, w_off, t_off; int M, K, blk0; };
