@@ -2152,6 +2152,46 @@ int fm_debug_pw(fm_engine* e, int32_t op, int32_t conv, const void* x_dev, const
     return FM_OK;
 }
 
+int fm_debug_proj_bwd(fm_engine* e, int32_t conv, int32_t phase, const void* dyp_dev, const void* yd_dev, const float* bn_dev,
+                      const float* gate_dev, const float* ds_dev, int32_t imgs, int32_t groups, void* out_dev, float* pool5_dev)
+{
+    ARGCHK(e && out_dev && conv >= 0 && conv < (int)e->convs.size(), "conv index");
+    ARGCHK(e->precision == 1 && e->convs[conv].k == 1, "bf16 engine and a 1x1 convolution");
+    ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs/groups");
+    ARGCHK(dyp_dev && yd_dev && bn_dev && gate_dev && (phase == 0 ? pool5_dev != nullptr : ds_dev != nullptr), "operands");
+    Conv& c = e->convs[conv];
+    ensure_packed(e);
+    const int L = c.cin_p, HW = c.hout * c.wout;
+    const int nch = pw_proj_bwd_nch(L, c.cout_p, imgs, HW);
+    ARGCHK(nch > 0, "shape not handled by pw_proj_bwd_kernel");
+    PwProjBwdParams q{};
+    q.dYp = reinterpret_cast<const bf16*>(dyp_dev); q.Yd = reinterpret_cast<const bf16*>(yd_dev);
+    q.Wt = e->wb + c.wbt_off; q.dYd = reinterpret_cast<bf16*>(out_dev);
+    q.slab = e->ws_slab; q.pool5 = e->se_pool;
+    const size_t gl = (size_t)groups * L;
+    q.sc = bn_dev; q.sh = bn_dev + gl; q.mean = bn_dev + 2 * gl; q.istd = bn_dev + 3 * gl;
+    q.ca = bn_dev + 4 * gl; q.cb = bn_dev + 5 * gl; q.cc = bn_dev + 6 * gl;
+    q.gate = gate_dev; q.ds = ds_dev;
+    q.L = L; q.S = c.cout_p; q.imgs = imgs; q.HW = HW; q.ipg = imgs / groups; q.nch = nch;
+    const int sk = launch_pw_proj_bwd(q, phase, e->slab_floats, e->st);
+    ARGCHK(sk > 0, "launch refused");
+    if (phase == 0) {
+        k_reduce_slabs(e->ws_slab, reinterpret_cast<float*>(out_dev), sk, (int64_t)c.w_numel, e->st);
+        std::vector<float> h((size_t)imgs * nch * 5 * L), o((size_t)imgs * 5 * L);
+        HIPCHK(hipMemcpyAsync(h.data(), e->se_pool, h.size() * 4, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipStreamSynchronize(e->st));
+        for (int i = 0; i < imgs; ++i)
+            for (int k = 0; k < 5 * L; ++k) {
+                double sum = 0;
+                for (int t = 0; t < nch; ++t) sum += h[((size_t)i * nch + t) * 5 * L + k];
+                o[(size_t)i * 5 * L + k] = (float)sum;
+            }
+        HIPCHK(hipMemcpy(pool5_dev, o.data(), o.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipGetLastError());
+    return FM_OK;
+}
+
 int fm_debug_get_grads(fm_engine* e, float* host_f32)
 {
     ARGCHK(e && host_f32, "null");

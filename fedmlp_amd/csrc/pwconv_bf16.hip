@@ -744,55 +744,62 @@ __global__ __launch_bounds__(256, 2) void pw_exp_bwd_kernel(const ExpBwdArgs p)
 
 // =====================================================================================================
 // Fused backward of a project (1x1) convolution with the squeeze-excite gate and BatchNorm1 + Swish in front of it, for the
-// early high-resolution MBConv blocks (HW % 32 == 0: blocks 0-2, half of the network's depthwise-output bytes).  The unfused
-// order moves the block's depthwise-resolution tensors seven times: weight gradient (reads y_d, re-forms a_s on load), data
-// gradient (writes d a_s), the five-sum pooling pass (reads d a_s, y_d), the BN1-backward apply (reads d a_s, y_d, writes
-// d y_d).  d a_s = d y_p W is a K = 16-32 product of a tensor six times smaller, so it is cheaper to form it twice on the
+// early high-resolution MBConv blocks (blocks 0-4: S <= 48 project channels, 3/4 of the network's depthwise-output bytes).  The
+// unfused order moves the block's depthwise-resolution tensors seven times: weight gradient (reads y_d, re-forms a_s on load),
+// data gradient (writes d a_s), the five-sum pooling pass (reads d a_s, y_d), the BN1-backward apply (reads d a_s, y_d, writes
+// d y_d).  d a_s = d y_p W is a K = 16-48 product of a tensor six times smaller, so it is cheaper to form it twice on the
 // matrix pipe than to store it once:
 //   phase 0 (before the squeeze-excite backward): d a_s tile by MFMA -> bf16 (the value the unfused path stores) -> the five
 //            per-image sums of chan_pool5_kernel and a_s = swish(bn1(y_d)) * gate from the SAME registers -> dW_p += d y_p^T a_s;
 //            reads y_d once, writes only partial sums and slabs;
 //   phase 1 (after the BN1-backward finalize): the same d a_s tile again (same instructions, same bits) -> d y_d with
 //            bnact_bwd_apply_kernel's arithmetic; reads y_d once, writes d y_d once.
-// A wave owns runs of consecutive 32-pixel tiles of one image (a run = one pooling record); elementwise work is laid out as
-// lane = (16-B channel piece, pixel sub-lane): the per-channel parameters and the five running sums stay in registers for the
-// whole run, and a tile of y_d / d y_d moves as contiguous rows.
+// The expanded channels are cut into slices of 16 NLT (48, or 32 for block 0); a WAVE owns one slice of runs of consecutive
+// 32-pixel tiles of one image (a run = one pooling record; the waves of a block take the slices of the same runs, so the block
+// reads whole rows).  Elementwise work is laid out as lane = (16-B channel piece, pixel sub-lane): the per-channel parameters
+// and the five running sums stay in registers for the whole run; per-slice registers are what lets 3-4 waves per SIMD overlap
+// the phases (the elementwise phase is VALU-bound: two transcendentals and ~25 other operations per element).
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 struct ProjBwdArgs {
     const bf16 *dYp, *Yd, *Wt;               // [npix][S], [npix][L], W^T [L][S] (the conv's transposed shadow)
     bf16* dYd;                               // phase 1: [npix][L]
-    float* slab;                             // phase 0: [waves][S][L] fp32 partial dW (conv weight layout [M = S][K = L])
+    float* slab;                             // phase 0: [blocks x run lanes][S][L] fp32 partial dW (conv weight layout [M = S][K = L])
     float* pool5;                            // phase 0: [imgs][nch][5][L]
     const float *sc, *sh, *mean, *istd;      // BN1 forward affine and statistics [groups][L]
     const float *ca, *cb, *cc;               // BN1-backward coefficients [groups][L] (phase 1)
     const float *gate, *ds;                  // [imgs][L]
-    int imgs, HW, ipg, nch;
+    int L, nsl, imgs, HW, ipg, nch;          // nsl = L / (16 NLT) slices = waves per run lane
     float inv_hw;
     int strideB, strideS, strideW;           // LDS row strides in bytes (32 x odd)
 };
 template <int NLT, int CS, int PHASE>
-__global__ __launch_bounds__(256, 2) void pw_proj_bwd_kernel(const ProjBwdArgs p)
+#ifndef FM_PROJ_WPE
+#define FM_PROJ_WPE 2
+#endif
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(FM_PROJ_WPE, 4))) void pw_proj_bwd_kernel(const ProjBwdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int L = 16 * NLT, S = 16 * CS;
-    constexpr int NOCT = 2 * NLT, NJ = 64 / NOCT, R = (32 + NJ - 1) / NJ, EVL = NJ * NOCT;
-    constexpr int CPS = 2 * CS, NSM = CPS / 2;              // a 32-pixel d y_p tile = 32 CPS 16-B chunks = NSM per lane
+    constexpr int LS = 16 * NLT, S = 16 * CS;
+    constexpr int NOCT = 4 * NLT, NJ = 64 / NOCT, R = (32 + NJ - 1) / NJ, EVL = NJ * NOCT;    // pieces of 4 channels (8 B)
+    constexpr int CPS = 2 * CS;                             // 16-B chunks per d y_p row; a 32-pixel tile = CS chunks per lane
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform loop control
     const int li = lane & 15, lg = lane >> 4;
+    const int L = p.L, L4 = L >> 2, nsl = p.nsl;
+    const int rw = wave / nsl, slice = wave - rw * nsl, nrw = (int)(blockDim.x >> 6) / nsl;
+    const int l0 = slice * LS;
     const int strideB = p.strideB, strideS = p.strideS, strideW = p.strideW;
     unsigned char* wt = smem;                                           // [L][strideW]
     unsigned char* base = smem + L * strideW + (size_t)wave * 32 * (strideB + strideS);
     unsigned char* sbase = base + 32 * strideB;
-    for (int c = tid; c < L * CPS; c += 256) {
+    for (int c = tid; c < L * CPS; c += blockDim.x) {
         const int row = c / CPS, cb = c - row * CPS;
         *reinterpret_cast<uint4*>(wt + row * strideW + cb * 16) = *reinterpret_cast<const uint4*>(p.Wt + (size_t)row * S + 8 * cb);
     }
     __syncthreads();
-    const int ws = blockIdx.x * 4 + wave, nws = gridDim.x * 4;
-    const int oc = lane % NOCT;
+    const int oc = lane % NOCT, jr = lane / NOCT;
     const bool ev = lane < EVL;                             // lanes of the elementwise phase: lane = jr * NOCT + oc
-    const int jr = lane / NOCT;
-    const int tpi = p.HW >> 5, nruns = p.imgs * p.nch;
+    const int tpi = (p.HW + 31) >> 5, nruns = p.imgs * p.nch;
     const int trow = 4 * lg + (li >> 2), tcol = 4 * (li & 3);
     f32x4 acc[PHASE == 0 ? CS : 1][PHASE == 0 ? NLT : 1];
     if constexpr (PHASE == 0) {
@@ -801,68 +808,74 @@ __global__ __launch_bounds__(256, 2) void pw_proj_bwd_kernel(const ProjBwdArgs p
 #pragma unroll
             for (int r = 0; r < NLT; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    uint4 vy[R], vs0, vs1;
-    for (int run = ws; run < nruns; run += nws) {
+    uint2 vy[R];
+    uint4 vs0, vs1, vs2;
+    for (int run = blockIdx.x * nrw + rw; run < nruns; run += gridDim.x * nrw) {
         const int img = run / p.nch, ch = run - img * p.nch;
         const int t0 = (int)((long long)ch * tpi / p.nch), t1 = (int)((long long)(ch + 1) * tpi / p.nch);
         const int g = img / p.ipg;
-        const uint4* yimg = reinterpret_cast<const uint4*>(p.Yd + (size_t)img * p.HW * L);
+        const uint2* yimg = reinterpret_cast<const uint2*>(p.Yd + (size_t)img * p.HW * L) + (l0 >> 2) + oc;
         const uint4* simg = reinterpret_cast<const uint4*>(p.dYp + (size_t)img * p.HW * S);
-        uint4* dimg = reinterpret_cast<uint4*>(p.dYd + (size_t)img * p.HW * L);
-        // per-lane parameters of this lane's 8 channels: pa / pb = mean / istd (phase 0) or ca / cb (phase 1)
-        f32x4 sc[2], sh[2], pa[2], pb[2], pc[2], gt[2], dv[2], sm[PHASE == 0 ? 5 : 1][2];
+        uint2* dimg = reinterpret_cast<uint2*>(p.dYd + (size_t)img * p.HW * L) + (l0 >> 2) + oc;
+        // per-lane parameters of this lane's 4 channels: pa / pb = mean / istd (phase 0) or ca / cb (phase 1)
+        f32x4 sc, sh, pa, pb, pc, gt, dv, sm[PHASE == 0 ? 5 : 1];
         {
-            const int po = g * L + 8 * oc, io = img * L + 8 * oc;
+            const int po = g * L + l0 + 4 * oc, io = img * L + l0 + 4 * oc;
+            sc = ld4(p.sc + po); sh = ld4(p.sh + po);
+            gt = ld4(p.gate + io);
+            if constexpr (PHASE == 0) {
+                pa = ld4(p.mean + po); pb = ld4(p.istd + po);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                sc[h] = ld4(p.sc + po + 4 * h); sh[h] = ld4(p.sh + po + 4 * h);
-                gt[h] = ld4(p.gate + io + 4 * h);
-                if constexpr (PHASE == 0) {
-                    pa[h] = ld4(p.mean + po + 4 * h); pb[h] = ld4(p.istd + po + 4 * h);
-#pragma unroll
-                    for (int t = 0; t < 5; ++t) sm[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    pa[h] = ld4(p.ca + po + 4 * h); pb[h] = ld4(p.cb + po + 4 * h); pc[h] = ld4(p.cc + po + 4 * h);
-                    dv[h] = ld4(p.ds + io + 4 * h);
-                }
+                for (int t = 0; t < 5; ++t) sm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                pa = ld4(p.ca + po); pb = ld4(p.cb + po); pc = ld4(p.cc + po);
+                dv = ld4(p.ds + io) * p.inv_hw;
             }
         }
+        // rows at and beyond nv = HW - 32 t (the ragged last tile of a 28 x 28 image) load zeros and store nothing
         auto gload = [&](int t) {
-            const uint4* ty = yimg + (size_t)t * 32 * NOCT + lane;         // rows jr + NJ i: chunk lane + EVL i of the tile
+            const int nv = p.HW - 32 * t;
+            const uint2* ty = yimg + (size_t)t * 32 * L4;
 #pragma unroll
-            for (int i = 0; i < R; ++i)
-                vy[i] = (ev && jr + NJ * i < 32) ? ty[EVL * i] : make_uint4(0u, 0u, 0u, 0u);
+            for (int i = 0; i < R; ++i) {
+                const int row = jr + NJ * i;
+                vy[i] = (ev && row < 32 && row < nv) ? ty[(size_t)row * L4] : make_uint2(0u, 0u);
+            }
             const uint4* tx = simg + (size_t)t * 32 * CPS + lane;
-            vs0 = tx[0];
-            if constexpr (NSM == 2) vs1 = tx[64];
+            vs0 = lane / CPS < nv ? tx[0] : zero4();
+            if constexpr (CS >= 2) vs1 = (lane + 64) / CPS < nv ? tx[64] : zero4();
+            if constexpr (CS >= 3) vs2 = (lane + 128) / CPS < nv ? tx[128] : zero4();
         };
         gload(t0);
         for (int t = t0; t < t1; ++t) {
+            const int nv = p.HW - 32 * t;
             // ---- d y_p tile -> LDS ----
             *reinterpret_cast<uint4*>(sbase + (lane / CPS) * strideS + (lane % CPS) * 16) = vs0;
-            if constexpr (NSM == 2) *reinterpret_cast<uint4*>(sbase + ((lane + 64) / CPS) * strideS + (lane % CPS) * 16) = vs1;
+            if constexpr (CS >= 2) *reinterpret_cast<uint4*>(sbase + ((lane + 64) / CPS) * strideS + ((lane + 64) % CPS) * 16) = vs1;
+            if constexpr (CS >= 3) *reinterpret_cast<uint4*>(sbase + ((lane + 128) / CPS) * strideS + ((lane + 128) % CPS) * 16) = vs2;
             __builtin_amdgcn_wave_barrier();
             // ---- data gradient: D[l][pix] = sum_s W^T[l][s] d y_p[pix][s]; lane (li, lg): 4 consecutive l of pixel li -> bf16 tile ----
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 const unsigned char* xrow = sbase + (16 * pt + li) * strideS;
                 unsigned char* drow = base + (16 * pt + li) * strideB + 8 * lg;
-                if constexpr (CS == 2) {
-                    const uint4 bf = *reinterpret_cast<const uint4*>(xrow + 16 * lg);
+                // K = S in chunks of 32; the last chunk of S = 16 / 48 is half a chunk: lane groups 2, 3 feed zeros on both sides
+                // (one opcode for the whole chain: a dependent 16x16x32 -> 16x16x16 pair gave wrong low accumulator halves)
+                constexpr int NKC = (S + 31) / 32, HALF = (S & 16) != 0;
+                uint4 bf[NKC];
 #pragma unroll
-                    for (int r = 0; r < NLT; ++r) {
-                        const f32x4 d = mfma32(*reinterpret_cast<const uint4*>(wt + (16 * r + li) * strideW + 16 * lg), bf,
-                                               f32x4{0.f, 0.f, 0.f, 0.f});
-                        *reinterpret_cast<uint2*>(drow + 32 * r) = pack4(d);
-                    }
-                } else {
-                    const uint2 bf = *reinterpret_cast<const uint2*>(xrow + 8 * lg);
+                for (int kc = 0; kc < NKC; ++kc)
+                    bf[kc] = (HALF && kc == NKC - 1 && lg >= 2) ? zero4() : *reinterpret_cast<const uint4*>(xrow + 64 * kc + 16 * lg);
 #pragma unroll
-                    for (int r = 0; r < NLT; ++r) {
-                        const f32x4 d = mfma16(*reinterpret_cast<const uint2*>(wt + (16 * r + li) * strideW + 8 * lg), bf,
-                                               f32x4{0.f, 0.f, 0.f, 0.f});
-                        *reinterpret_cast<uint2*>(drow + 32 * r) = pack4(d);
+                for (int r = 0; r < NLT; ++r) {
+                    const unsigned char* wrow = wt + (l0 + 16 * r + li) * strideW;
+                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const uint4 af = (HALF && kc == NKC - 1 && lg >= 2) ? zero4() : *reinterpret_cast<const uint4*>(wrow + 64 * kc + 16 * lg);
+                        d = mfma32(af, bf[kc], d);
                     }
+                    *reinterpret_cast<uint2*>(drow + 32 * r) = pack4(d);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -870,49 +883,46 @@ __global__ __launch_bounds__(256, 2) void pw_proj_bwd_kernel(const ProjBwdArgs p
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const int row = jr + NJ * i;
-                if (ev && row < 32) {
-                    unsigned char* dp = base + row * strideB + oc * 16;
-                    const uint4 dd = *reinterpret_cast<const uint4*>(dp);
-                    f32x4 o[2];
+                if (ev && row < 32 && row < nv) {
+                    unsigned char* dp = base + row * strideB + oc * 8;
+                    f32x4 d = cvt4(*reinterpret_cast<const uint2*>(dp));
+                    const f32x4 y = cvt4(vy[i]);
+                    const f32x4 v = y * sc + sh;
+                    f32x4 o;
+                    if constexpr (PHASE == 0) {
+                        const f32x4 xh = (y - pa) * pb;
+                        f32x4 ad, sg;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        f32x4 d = h ? hi4(dd) : lo4(dd);
-                        const f32x4 y = h ? hi4(vy[i]) : lo4(vy[i]);
-                        const f32x4 v = y * sc[h] + sh[h];
-                        if constexpr (PHASE == 0) {
-                            const f32x4 xh = (y - pa[h]) * pb[h];
-                            f32x4 ad, sg;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-v[k]));
-                                ad[k] = v[k] * sgm;
-                                sg[k] = sgm * (1.f + v[k] * (1.f - sgm));
-                            }
-                            const f32x4 dsg = d * sg;
-                            sm[0][h] += d * ad;
-                            sm[1][h] += dsg;
-                            sm[2][h] += dsg * xh;
-                            sm[3][h] += sg;
-                            sm[4][h] += sg * xh;
-                            o[h] = ad * gt[h];
-                        } else {
-                            d = d * gt[h] + dv[h] * p.inv_hw;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-v[k]));
-                                d[k] *= sgm * (1.f + v[k] * (1.f - sgm));
-                            }
-                            o[h] = pa[h] * d + pb[h] * y + pc[h];
+                        for (int k = 0; k < 4; ++k) {
+                            const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-v[k]));
+                            ad[k] = v[k] * sgm;
+                            sg[k] = sgm * (1.f + v[k] * (1.f - sgm));
                         }
+                        const f32x4 dsg = d * sg;
+                        sm[0] += d * ad;
+                        sm[1] += dsg;
+                        sm[2] += dsg * xh;
+                        sm[3] += sg;
+                        sm[4] += sg * xh;
+                        o = ad * gt;
+                        *reinterpret_cast<uint2*>(dp) = pack4(o);
+                    } else {
+                        d = d * gt + dv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-v[k]));
+                            d[k] *= sgm * (1.f + v[k] * (1.f - sgm));
+                        }
+                        o = pa * d + pb * y + pc;
+                        dimg[((size_t)t * 32 + row) * L4] = pack4(o);
                     }
-                    if constexpr (PHASE == 0) *reinterpret_cast<uint4*>(dp) = pack8(o[0], o[1]);
-                    else dimg[(size_t)t * 32 * NOCT + lane + EVL * i] = pack8(o[0], o[1]);
                 }
             }
             if (t + 1 < t1) gload(t + 1);
             if constexpr (PHASE == 0) {
                 __builtin_amdgcn_wave_barrier();
-                // ---- weight gradient: dW[s][l] += sum_pix d y_p[pix][s] a_s[pix][l] (transposed fragments of both tiles) ----
+                // ---- weight gradient: dW[s][l] += sum_pix d y_p[pix][s] a_s[pix][l] (transposed fragments of both tiles; the rows
+                //      of a ragged tile beyond nv hold d y_p = 0 against finite a_s) ----
                 uint4 a[CS];
 #pragma unroll
                 for (int c = 0; c < CS; ++c) {
@@ -934,25 +944,24 @@ __global__ __launch_bounds__(256, 2) void pw_proj_bwd_kernel(const ProjBwdArgs p
         if constexpr (PHASE == 0) {
             // the NJ pixel sub-lanes of a channel piece are folded through LDS in a fixed order: one record per run
             float* scr = reinterpret_cast<float*>(base);
-            float* rec = p.pool5 + ((size_t)img * p.nch + ch) * 5 * L;
+            float* rec = p.pool5 + ((size_t)img * p.nch + ch) * 5 * L + l0;
 #pragma unroll
-            for (int t = 0; t < 5; ++t)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (ev) *reinterpret_cast<f32x4*>(scr + lane * 4) = sm[t][h];
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < NOCT) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(scr + lane * 4);
-                        for (int j = 1; j < NJ; ++j) v += *reinterpret_cast<const f32x4*>(scr + (j * NOCT + lane) * 4);
-                        *reinterpret_cast<f32x4*>(rec + t * L + 8 * lane + 4 * h) = v;
-                    }
-                    __builtin_amdgcn_wave_barrier();
+            for (int t = 0; t < 5; ++t) {
+                if (ev) *reinterpret_cast<f32x4*>(scr + lane * 4) = sm[t];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NOCT) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(scr + lane * 4);
+                    for (int j = 1; j < NJ; ++j) v += *reinterpret_cast<const f32x4*>(scr + (j * NOCT + lane) * 4);
+                    *reinterpret_cast<f32x4*>(rec + t * L + 4 * lane) = v;
                 }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     if constexpr (PHASE == 0) {
-        // acc[c][r][q] = dW[s = 16 c + 4 lg + q][l = 16 r + li]; this wave's slab (zeros when it had no run)
-        float* slab = p.slab + (size_t)ws * L * S;
+        // acc[c][r][q] = dW[s = 16 c + 4 lg + q][l = l0 + 16 r + li]; the run lane's slab (zeros when it had no run), this
+        // wave's columns of it
+        float* slab = p.slab + (size_t)(blockIdx.x * nrw + rw) * L * S + l0;
 #pragma unroll
         for (int c = 0; c < CS; ++c)
 #pragma unroll
@@ -1185,45 +1194,56 @@ int launch_pw_exp_bwd(const PwExpBwdParams& w, size_t slab_floats, hipStream_t s
 
 // Fused project-conv backward (pw_proj_bwd_kernel).  pw_proj_bwd_nch: pooling records per image (0 = shape not handled: the
 // caller runs the separate passes).  Phase 0 returns the number of [S][L] slabs written (reduce with k_reduce_slabs).
+static int proj_bwd_slice(int L) { return L == 32 ? 32 : (L % 48 == 0 ? 48 : 0); }
 int pw_proj_bwd_nch(int L, int S, int imgs, int HW)
 {
-    static const int on = fm_tune("FM_PW_PROJ_BWD", 1);
-    const int nlt = L / 16, cs = S / 16;
-    const bool shape = (nlt == 2 && cs == 1) || (nlt == 6 && cs == 2) || (nlt == 9 && cs == 2);
-    if (!on || !shape || (L & 15) || (S & 15) || HW % 32 != 0 || imgs < 1) return 0;
-    const int tpi = HW / 32;
+    static const int on = fm_tune("FM_PW_PROJ_BWD", 1), ragged = fm_tune("FM_PW_PROJ_RAGGED", 1);
+    const int ls = proj_bwd_slice(L);
+    if (!on || !ls || L / ls > 5 || (S != 16 && S != 32 && S != 48) || imgs < 1) return 0;
+    if (HW % 32 != 0 && (!ragged || HW % 16 != 0)) return 0;
+    static const int dbg_l = fm_tune("FM_PW_PROJ_DBGL", 0);
+    if (HW % 32 != 0 && dbg_l && L != dbg_l) return 0;
+    const int tpi = (HW + 31) / 32;
     return std::max(1, std::min(std::min(16, tpi), (2048 + imgs - 1) / imgs));
 }
 int launch_pw_proj_bwd(const PwProjBwdParams& w, int phase, size_t slab_floats, hipStream_t s)
 {
     const int nch = pw_proj_bwd_nch(w.L, w.S, w.imgs, w.HW);
     if (!nch || nch != w.nch || w.imgs % w.ipg != 0) return 0;
+    const int ls = proj_bwd_slice(w.L), nsl = w.L / ls;
     ProjBwdArgs a{};
     a.dYp = w.dYp; a.Yd = w.Yd; a.Wt = w.Wt; a.dYd = w.dYd; a.slab = w.slab; a.pool5 = w.pool5;
     a.sc = w.sc; a.sh = w.sh; a.mean = w.mean; a.istd = w.istd; a.ca = w.ca; a.cb = w.cb; a.cc = w.cc;
     a.gate = w.gate; a.ds = w.ds;
-    a.imgs = w.imgs; a.HW = w.HW; a.ipg = w.ipg; a.nch = nch; a.inv_hw = 1.f / (float)w.HW;
-    a.strideB = odd32(2 * w.L); a.strideS = odd32(2 * w.S); a.strideW = odd32(2 * w.S);
+    a.L = w.L; a.nsl = nsl; a.imgs = w.imgs; a.HW = w.HW; a.ipg = w.ipg; a.nch = nch; a.inv_hw = 1.f / (float)w.HW;
+    a.strideB = odd32(2 * ls); a.strideS = odd32(2 * w.S); a.strideW = odd32(2 * w.S);
+    const int nrw = nsl == 1 ? 4 : (nsl == 2 ? 2 : 1);               // run lanes per block: 4 x 1, 2 x 2, 1 x 3..5 waves
+    const int nwaves = nsl * nrw;
     const int nruns = w.imgs * nch;
-    int nblk = std::max(1, std::min(512, nruns / 4));
-    if (phase == 0) nblk = (int)std::min<size_t>(nblk, std::max<size_t>(1, slab_floats / ((size_t)4 * w.L * w.S)));
-    const size_t lds = (size_t)w.L * a.strideW + (size_t)4 * 32 * (a.strideB + a.strideS);
-    const int nlt = w.L / 16;
+    static const int cap = fm_tune("FM_PW_PROJ_BLOCKS", 1024);
+    int nblk = std::max(1, std::min(cap, (nruns + nrw - 1) / nrw));
+    if (phase == 0) nblk = (int)std::min<size_t>(nblk, std::max<size_t>(1, slab_floats / ((size_t)nrw * w.L * w.S)));
+    const size_t lds = (size_t)w.L * a.strideW + (size_t)nwaves * 32 * (a.strideB + a.strideS);
 #define PROJ_BWD(N, C, PH)                                                                                              \
     do {                                                                                                                \
         static bool done_ = false;                                                                                      \
         if (!done_) { set_max_dyn_lds(reinterpret_cast<const void*>(&pw_proj_bwd_kernel<N, C, PH>), 96 * 1024, "pw_proj_bwd"); done_ = true; } \
-        hipLaunchKernelGGL((pw_proj_bwd_kernel<N, C, PH>), dim3(nblk), dim3(256), lds, s, a);                           \
+        hipLaunchKernelGGL((pw_proj_bwd_kernel<N, C, PH>), dim3(nblk), dim3(64 * nwaves), lds, s, a);                   \
+    } while (0)
+#define PROJ_BWD_S(N, PH)                                                                                               \
+    do {                                                                                                                \
+        if (w.S == 16) PROJ_BWD(N, 1, PH);                                                                              \
+        else if (w.S == 32) PROJ_BWD(N, 2, PH);                                                                         \
+        else PROJ_BWD(N, 3, PH);                                                                                        \
     } while (0)
     if (phase == 0) {
-        if (nlt == 2) PROJ_BWD(2, 1, 0);
-        else if (nlt == 6) PROJ_BWD(6, 2, 0);
-        else PROJ_BWD(9, 2, 0);
-        return 4 * nblk;
+        if (ls == 32) PROJ_BWD_S(2, 0);
+        else PROJ_BWD_S(3, 0);
+        return nrw * nblk;
     }
-    if (nlt == 2) PROJ_BWD(2, 1, 1);
-    else if (nlt == 6) PROJ_BWD(6, 2, 1);
-    else PROJ_BWD(9, 2, 1);
+    if (ls == 32) PROJ_BWD_S(2, 1);
+    else PROJ_BWD_S(3, 1);
+#undef PROJ_BWD_S
 #undef PROJ_BWD
     return 1;
 }

@@ -321,6 +321,10 @@ class Engine:
         _lib.check(self.lib.fm_debug_pw(self.h, op, conv, _ptr(x), _ptr(dy), _ptr(out), imgs, groups, _ptr(psc),
                                         _ptr(psh), _ptr(gate), _ptr(stats)))
 
+    def debug_proj_bwd(self, conv, phase, dyp, yd, bn, gate, ds, imgs, groups, out, pool5=None):
+        _lib.check(self.lib.fm_debug_proj_bwd(self.h, conv, phase, _ptr(dyp), _ptr(yd), _ptr(bn), _ptr(gate), _ptr(ds), imgs,
+                                              groups, _ptr(out), _ptr(pool5)))
+
     def debug_activation(self, kind, block, imgs):
         """post-ReLU activation kept by the last train-mode forward, as an NCHW numpy array"""
         dims = (C.c_int32 * 4)()

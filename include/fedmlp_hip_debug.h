@@ -39,6 +39,16 @@ int fm_debug_pw(fm_engine* e, int32_t op, int32_t conv, const void* x_dev, const
                 int32_t imgs, int32_t groups, const float* psc_dev, const float* psh_dev, const float* gate_dev,
                 float* stats_dev);
 
+/* Fused backward of a project convolution (pw_proj_bwd_kernel; conv = a project conv of blocks 0-4 of a precision-1 engine):
+ * dyp bf16 [imgs,h,w,cout_p] (= d y_p), yd bf16 [imgs,h,w,cin_p] (the depthwise output y_d), bn [7][groups][cin_p] fp32 =
+ * BN1's scale, shift, mean, istd and the BN1-backward coefficients ca, cb, cc; gate / ds fp32 [imgs][cin_p].
+ * phase 0: out = fp32 dW [cout_p][cin_p] with a_s = swish(yd*scale+shift)*gate, pool5 = fp32 [imgs][5][cin_p], the five
+ *          per-image sums of (d a_s, y_d) that the squeeze-excite and BN1 backward need (d a_s = bf16(dyp W));
+ * phase 1: out = bf16 d y_d [imgs,h,w,cin_p] = ca*((d a_s*gate + ds/HW)*swish'(v)) + cb*yd + cc. */
+int fm_debug_proj_bwd(fm_engine* e, int32_t conv, int32_t phase, const void* dyp_dev, const void* yd_dev, const float* bn_dev,
+                      const float* gate_dev, const float* ds_dev, int32_t imgs, int32_t groups, void* out_dev,
+                      float* pool5_dev);
+
 /* Post-ReLU activations the last train-mode forward kept (ResNet-18): kind 0 = relu(bn1(conv1)) of
  * basic block `block`, kind 1 = the block's output relu(bn2(conv2) + identity); NHWC fp32 for the first
  * `imgs` images, dims4 = {imgs, H, W, C}.  host_nhwc may be NULL to query the dims only.  Parity tests

@@ -162,6 +162,71 @@ def test_pw_prologue_gate_matches_materialised_operand(eng):
         assert err < 5e-3, (affine, err)
 
 
+@pytest.mark.parametrize("shape", [(32, 16), (96, 32), (144, 32), (144, 48), (240, 48)])
+def test_fused_project_backward_vs_fp32_on_rounded_operands(shape):
+    """pw_proj_bwd_kernel (blocks 0-4): d a_s = bf16(d y_p W) formed on the matrix pipe in both phases; phase 0 = the five
+    per-image sums of (d a_s, y_d) + the project conv's weight gradient with a_s = swish(bn1(y_d))*gate re-formed in
+    registers, phase 1 = the BN1-backward apply.  Against the same arithmetic in torch on the same bf16 operands; a 96 x 96
+    input gives 48 x 48 / 24 x 24 maps (whole 32-pixel tiles) and 12 x 12 maps (144 pixels: the ragged last tile)."""
+    from fedmlp_amd.engine import Engine
+    e = Engine("Efficient_b0", C_, 96, 96, 8, precision="bf16")
+    try:
+        e.stochastic = False
+        _load(e)
+        L, S = shape
+        ci, info = next((c, i) for c, i in _pw_convs(e) if i["cin_p"] == L and i["cout_p"] == S and i["cin"] > i["cout"])
+        h, w = info["hout"], info["wout"]
+        HWo = h * w
+        imgs, groups = 6, 2
+        npix = imgs * HWo
+        g = torch.Generator().manual_seed(11 + L)
+        dyp = (torch.randn((npix, S), generator=g) * 0.5).to(torch.bfloat16)
+        dyp[:, info["cout"]:] = 0                                   # padded channels carry zeros
+        yd = torch.randn((npix, L), generator=g).to(torch.bfloat16)
+        bn = torch.empty((7, groups, L))
+        bn[0] = torch.rand((groups, L), generator=g) + 0.5          # scale
+        bn[1] = torch.randn((groups, L), generator=g) * 0.3         # shift
+        bn[2] = torch.randn((groups, L), generator=g) * 0.2         # mean
+        bn[3] = torch.rand((groups, L), generator=g) + 0.5          # istd
+        bn[4] = torch.rand((groups, L), generator=g) + 0.5          # ca
+        bn[5] = torch.randn((groups, L), generator=g) * 0.1         # cb
+        bn[6] = torch.randn((groups, L), generator=g) * 0.1         # cc
+        gate = torch.rand((imgs, L), generator=g)
+        ds = torch.randn((imgs, L), generator=g)
+        W = torch.from_numpy(_engine_weight(e, ci, info)).to(torch.bfloat16).float()        # [S][L]
+        dev = e.device
+        # torch yardstick
+        d = (dyp.float() @ W).to(torch.bfloat16).float().view(imgs, HWo, L)
+        y = yd.float().view(imgs, HWo, L)
+        per_img = lambda t: t.repeat_interleave(imgs // groups, dim=0)[:, None, :]          # [groups][L] -> [imgs][1][L]
+        v = y * per_img(bn[0]) + per_img(bn[1])
+        sgm = torch.sigmoid(v)
+        ad, sg = v * sgm, sgm * (1 + v * (1 - sgm))
+        xh = (y - per_img(bn[2])) * per_img(bn[3])
+        want5 = torch.stack([(d * ad).sum(1), (d * sg).sum(1), (d * sg * xh).sum(1), sg.sum(1), (sg * xh).sum(1)], dim=1)
+        a_s = (ad * gate[:, None, :]).to(torch.bfloat16).float().view(npix, L)
+        want_dw = dyp.float().t() @ a_s
+        dd = (d * gate[:, None, :] + ds[:, None, :] / HWo) * sg
+        want_dy = per_img(bn[4]) * dd + per_img(bn[5]) * y + per_img(bn[6])
+        # engine
+        dw = torch.empty((S, L), device=dev)
+        pool5 = torch.empty((imgs, 5, L), device=dev)
+        e.debug_proj_bwd(ci, 0, dyp.to(dev), yd.to(dev), bn.to(dev), gate.to(dev), None, imgs, groups, dw, pool5)
+        dy = torch.empty((npix, L), dtype=torch.bfloat16, device=dev)
+        e.debug_proj_bwd(ci, 1, dyp.to(dev), yd.to(dev), bn.to(dev), gate.to(dev), ds.to(dev), imgs, groups, dy)
+        torch.cuda.synchronize()
+        e5 = [float((pool5[:, t].cpu() - want5[:, t]).abs().max() / want5[:, t].abs().max()) for t in range(5)]
+        edw = float((dw.cpu() - want_dw).abs().max() / want_dw.abs().max())
+        edy = float((dy.float().cpu().view(imgs, HWo, L) - want_dy).abs().max() / want_dy.abs().max())
+        REPORT[f"fused_project_backward_L{L}_S{S}_hw{h}"] = {"pool5_rel_to_max": e5, "dw_rel_to_max": edw, "dyd_rel_to_max": edy}
+        _dump()
+        assert max(e5) < 2e-3, e5                # fp32 sums of ~150-2300 products; d a_s may round the other way on a tie
+        assert edw < 5e-3, edw
+        assert edy < 1.2e-2, edy                 # bf16 output rounding (2^-9) after a fast exp / rcp
+    finally:
+        e.close()
+
+
 # ---- model level ---------------------------------------------------------------------------------------
 def test_forward_eval_bf16_vs_fp32_oracle(eng):
     net = _load(eng)
