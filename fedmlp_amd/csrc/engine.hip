@@ -1381,18 +1381,30 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
         float* drp = (sw && par) ? e->se_drp2 : e->se_drp;
         // early blocks (half of the depthwise-resolution bytes): d a_s is never stored -- pw_proj_bwd_kernel forms it twice on the
         // matrix pipe, once for the five per-image sums + the weight gradient, once for the BN1-backward apply (7 passes -> 3)
-        const int nch5 = e->precision ? pw_proj_bwd_nch(m.ce_p, cp.cout_p, imgs, HWo) : 0;
+        const int nch5 = e->precision ? pw_proj_bwd_nch(m.ce_p, cp.cout_p, imgs, HWo) : pw_proj_bwd_f32_nch(m.ce_p, cp.cout_p, imgs, HWo);
         bool pfused = false;
         if (nch5) {
             PwProjBwdParams q{};
-            q.dYp = reinterpret_cast<const bf16*>(T_small); q.Yd = reinterpret_cast<const bf16*>(m.y_d);
-            q.Wt = shadow_of(e, S) + cp.wbt_off; q.dYd = reinterpret_cast<bf16*>(T_mid);
-            q.slab = e->ws_slab; q.pool5 = e->se_pool;
-            q.sc = b1.scale; q.sh = b1.shift; q.mean = b1.mean; q.istd = b1.istd; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc;
-            q.gate = m.gate; q.ds = e->se_ds;
-            q.L = m.ce_p; q.S = cp.cout_p; q.imgs = imgs; q.HW = HWo; q.ipg = B; q.nch = nch5;
+            PwProjBwdF32Params qf{};
+            if (e->precision) {
+                q.dYp = reinterpret_cast<const bf16*>(T_small); q.Yd = reinterpret_cast<const bf16*>(m.y_d);
+                q.Wt = shadow_of(e, S) + cp.wbt_off; q.dYd = reinterpret_cast<bf16*>(T_mid);
+                q.slab = e->ws_slab; q.pool5 = e->se_pool;
+                q.sc = b1.scale; q.sh = b1.shift; q.mean = b1.mean; q.istd = b1.istd; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc;
+                q.gate = m.gate; q.ds = e->se_ds;
+                q.L = m.ce_p; q.S = cp.cout_p; q.imgs = imgs; q.HW = HWo; q.ipg = B; q.nch = nch5;
+            } else {
+                qf.dYp = T_small; qf.Yd = m.y_d; qf.W = S + cp.w_off; qf.dYd = T_mid;
+                qf.slab = e->ws_slab; qf.pool5 = e->se_pool;
+                qf.sc = b1.scale; qf.sh = b1.shift; qf.mean = b1.mean; qf.istd = b1.istd; qf.ca = e->ca; qf.cb = e->cb; qf.cc = e->cc;
+                qf.gate = m.gate; qf.ds = e->se_ds;
+                qf.L = m.ce_p; qf.S = cp.cout_p; qf.imgs = imgs; qf.HW = HWo; qf.ipg = B; qf.nch = nch5;
+            }
+            auto launch = [&](int phase) {
+                return e->precision ? launch_pw_proj_bwd(q, phase, e->slab_floats, e->st) : launch_pw_proj_bwd_f32(qf, phase, e->slab_floats, e->st);
+            };
             int sk;
-            { OP("proj_bwd_sums"); sk = launch_pw_proj_bwd(q, 0, e->slab_floats, e->st);
+            { OP("proj_bwd_sums"); sk = launch(0);
               if (sk > 0) k_reduce_slabs(e->ws_slab, G + cp.w_off, sk, (int64_t)cp.w_numel, e->st); }
             if (sk > 0) {
                 guard(3, par);
@@ -1406,7 +1418,7 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
                   k_bn_bwd_finalize(e->ws_part, groups, se_bwd_bn1_splits(B), b1.C, B * HWo, e->state + e->off_gamma + b1.ch_off, b1.mean,
                                     b1.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b1.ch_off, e->grad + e->off_beta + b1.ch_off,
                                     e->st);
-                  if (launch_pw_proj_bwd(q, 1, e->slab_floats, e->st) != 1) soft(e, hipErrorInvalidValue); }      // d y_d
+                  if (launch(1) != 1) soft(e, hipErrorInvalidValue); }      // d y_d
                 pfused = true;
             }
         }
@@ -2156,24 +2168,37 @@ int fm_debug_proj_bwd(fm_engine* e, int32_t conv, int32_t phase, const void* dyp
                       const float* gate_dev, const float* ds_dev, int32_t imgs, int32_t groups, void* out_dev, float* pool5_dev)
 {
     ARGCHK(e && out_dev && conv >= 0 && conv < (int)e->convs.size(), "conv index");
-    ARGCHK(e->precision == 1 && e->convs[conv].k == 1, "bf16 engine and a 1x1 convolution");
+    ARGCHK(e->model == 1 && e->convs[conv].k == 1, "an EfficientNet engine and a 1x1 convolution");
     ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs/groups");
     ARGCHK(dyp_dev && yd_dev && bn_dev && gate_dev && (phase == 0 ? pool5_dev != nullptr : ds_dev != nullptr), "operands");
     Conv& c = e->convs[conv];
     ensure_packed(e);
     const int L = c.cin_p, HW = c.hout * c.wout;
-    const int nch = pw_proj_bwd_nch(L, c.cout_p, imgs, HW);
-    ARGCHK(nch > 0, "shape not handled by pw_proj_bwd_kernel");
-    PwProjBwdParams q{};
-    q.dYp = reinterpret_cast<const bf16*>(dyp_dev); q.Yd = reinterpret_cast<const bf16*>(yd_dev);
-    q.Wt = e->wb + c.wbt_off; q.dYd = reinterpret_cast<bf16*>(out_dev);
-    q.slab = e->ws_slab; q.pool5 = e->se_pool;
+    const int nch = e->precision ? pw_proj_bwd_nch(L, c.cout_p, imgs, HW) : pw_proj_bwd_f32_nch(L, c.cout_p, imgs, HW);
+    ARGCHK(nch > 0, "shape not handled by the fused project backward");
     const size_t gl = (size_t)groups * L;
-    q.sc = bn_dev; q.sh = bn_dev + gl; q.mean = bn_dev + 2 * gl; q.istd = bn_dev + 3 * gl;
-    q.ca = bn_dev + 4 * gl; q.cb = bn_dev + 5 * gl; q.cc = bn_dev + 6 * gl;
-    q.gate = gate_dev; q.ds = ds_dev;
-    q.L = L; q.S = c.cout_p; q.imgs = imgs; q.HW = HW; q.ipg = imgs / groups; q.nch = nch;
-    const int sk = launch_pw_proj_bwd(q, phase, e->slab_floats, e->st);
+    int sk;
+    if (e->precision) {
+        PwProjBwdParams q{};
+        q.dYp = reinterpret_cast<const bf16*>(dyp_dev); q.Yd = reinterpret_cast<const bf16*>(yd_dev);
+        q.Wt = e->wb + c.wbt_off; q.dYd = reinterpret_cast<bf16*>(out_dev);
+        q.slab = e->ws_slab; q.pool5 = e->se_pool;
+        q.sc = bn_dev; q.sh = bn_dev + gl; q.mean = bn_dev + 2 * gl; q.istd = bn_dev + 3 * gl;
+        q.ca = bn_dev + 4 * gl; q.cb = bn_dev + 5 * gl; q.cc = bn_dev + 6 * gl;
+        q.gate = gate_dev; q.ds = ds_dev;
+        q.L = L; q.S = c.cout_p; q.imgs = imgs; q.HW = HW; q.ipg = imgs / groups; q.nch = nch;
+        sk = launch_pw_proj_bwd(q, phase, e->slab_floats, e->st);
+    } else {
+        PwProjBwdF32Params q{};
+        q.dYp = reinterpret_cast<const float*>(dyp_dev); q.Yd = reinterpret_cast<const float*>(yd_dev);
+        q.W = e->state + c.w_off; q.dYd = reinterpret_cast<float*>(out_dev);
+        q.slab = e->ws_slab; q.pool5 = e->se_pool;
+        q.sc = bn_dev; q.sh = bn_dev + gl; q.mean = bn_dev + 2 * gl; q.istd = bn_dev + 3 * gl;
+        q.ca = bn_dev + 4 * gl; q.cb = bn_dev + 5 * gl; q.cc = bn_dev + 6 * gl;
+        q.gate = gate_dev; q.ds = ds_dev;
+        q.L = L; q.S = c.cout_p; q.imgs = imgs; q.HW = HW; q.ipg = imgs / groups; q.nch = nch;
+        sk = launch_pw_proj_bwd_f32(q, phase, e->slab_floats, e->st);
+    }
     ARGCHK(sk > 0, "launch refused");
     if (phase == 0) {
         k_reduce_slabs(e->ws_slab, reinterpret_cast<float*>(out_dev), sk, (int64_t)c.w_numel, e->st);

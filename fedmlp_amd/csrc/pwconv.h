@@ -70,6 +70,18 @@ int pw_proj_bwd_nch(int L, int S, int imgs, int HW);      // pooling records per
 // phase 0: returns the number of slabs written (0 = not handled); phase 1: 1 = launched, 0 = not handled
 int launch_pw_proj_bwd(const PwProjBwdParams& p, int phase, size_t slab_floats, hipStream_t s);
 
+// the fp32-storage twin (projbwd_f32.hip; blocks 0-2): same two phases on the fp32 matrix pipe, W = the conv weight [S][L]
+struct PwProjBwdF32Params {
+    const float *dYp, *Yd, *W;
+    float* dYd;
+    float *slab, *pool5;
+    const float *sc, *sh, *mean, *istd, *ca, *cb, *cc;
+    const float *gate, *ds;
+    int L, S, imgs, HW, ipg, nch;
+};
+int pw_proj_bwd_f32_nch(int L, int S, int imgs, int HW);
+int launch_pw_proj_bwd_f32(const PwProjBwdF32Params& p, int phase, size_t slab_floats, hipStream_t s);
+
 // fp32 master weights -> bf16 shadows, all 1x1 convolutions in one launch:
 // wb[w_off ...] = bf16(W[m][k]) row-major and wbt[t_off ...] = its transpose [K][M]
 struct CastJob { long long src_off, w_off, t_off; int M, K, blk0; };

@@ -39,7 +39,8 @@ int fm_debug_pw(fm_engine* e, int32_t op, int32_t conv, const void* x_dev, const
                 int32_t imgs, int32_t groups, const float* psc_dev, const float* psh_dev, const float* gate_dev,
                 float* stats_dev);
 
-/* Fused backward of a project convolution (pw_proj_bwd_kernel; conv = a project conv of blocks 0-4 of a precision-1 engine):
+/* Fused backward of a project convolution (pw_proj_bwd_kernel: blocks 0-4 of a precision-1 EfficientNet engine, tensors bf16;
+ * pw_proj_bwd_f32_kernel: blocks 0-2 of a precision-0 one, every "bf16" below is then fp32):
  * dyp bf16 [imgs,h,w,cout_p] (= d y_p), yd bf16 [imgs,h,w,cin_p] (the depthwise output y_d), bn [7][groups][cin_p] fp32 =
  * BN1's scale, shift, mean, istd and the BN1-backward coefficients ca, cb, cc; gate / ds fp32 [imgs][cin_p].
  * phase 0: out = fp32 dW [cout_p][cin_p] with a_s = swish(yd*scale+shift)*gate, pool5 = fp32 [imgs][5][cin_p], the five

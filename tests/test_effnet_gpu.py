@@ -559,3 +559,72 @@ def test_row_blocked_bn_act_passes_are_bit_identical(monkeypatch, precision):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("shape", [(32, 16), (96, 32), (144, 32)])
+def test_fused_project_backward_fp32_kernel(shape):
+    """pw_proj_bwd_f32_kernel (fp32 storage, blocks 0-2): d a_s = d y_p W formed on the fp32 matrix pipe in both phases;
+    phase 0 = the five per-image sums of (d a_s, y_d) + the project conv's weight gradient with a_s = swish(bn1(y_d)) * gate,
+    phase 1 = the BN1-backward apply.  Against the same arithmetic in float64 torch (fp32 summation order and the hardware
+    exp / rcp of the fp32 build are the only differences)."""
+    from fedmlp_amd.engine import Engine
+    e = Engine(M, C_, 96, 96, 8)
+    try:
+        e.stochastic = False
+        _load(e)
+        L, S = shape
+        ci, info = None, None
+        for c in range(e.debug_num_convs()):
+            i = e.debug_conv_info(c)
+            if i["k"] == 1 and i["cin_p"] == L and i["cout_p"] == S and i["cin"] > i["cout"]:
+                ci, info = c, i
+                break
+        assert ci is not None
+        flat, cnt = e.get_state()
+        sd = spec.flat_to_state_dict(M, C_, flat, cnt)
+        ckeys = [k for k, shp, _ in spec.entries(M, C_) if len(shp) == 4 and "_depthwise" not in k and "_se_" not in k]
+        W = torch.zeros((S, L), dtype=torch.float64)
+        W[:info["cout"], :info["cin"]] = torch.from_numpy(sd[ckeys[ci]].reshape(info["cout"], info["cin"])).double()
+        HWo = info["hout"] * info["wout"]
+        imgs, groups = 6, 2
+        npix = imgs * HWo
+        g = torch.Generator().manual_seed(23 + L)
+        dyp = torch.randn((npix, S), generator=g) * 0.5
+        dyp[:, info["cout"]:] = 0
+        yd = torch.randn((npix, L), generator=g)
+        bn = torch.empty((7, groups, L))
+        bn[0] = torch.rand((groups, L), generator=g) + 0.5
+        bn[1] = torch.randn((groups, L), generator=g) * 0.3
+        bn[2] = torch.randn((groups, L), generator=g) * 0.2
+        bn[3] = torch.rand((groups, L), generator=g) + 0.5
+        bn[4] = torch.rand((groups, L), generator=g) + 0.5
+        bn[5] = torch.randn((groups, L), generator=g) * 0.1
+        bn[6] = torch.randn((groups, L), generator=g) * 0.1
+        gate = torch.rand((imgs, L), generator=g)
+        ds = torch.randn((imgs, L), generator=g)
+        d = (dyp.double() @ W).view(imgs, HWo, L)
+        y = yd.double().view(imgs, HWo, L)
+        per_img = lambda t: t.double().repeat_interleave(imgs // groups, dim=0)[:, None, :]
+        v = y * per_img(bn[0]) + per_img(bn[1])
+        sgm = torch.sigmoid(v)
+        ad, sg = v * sgm, sgm * (1 + v * (1 - sgm))
+        xh = (y - per_img(bn[2])) * per_img(bn[3])
+        want5 = torch.stack([(d * ad).sum(1), (d * sg).sum(1), (d * sg * xh).sum(1), sg.sum(1), (sg * xh).sum(1)], dim=1)
+        want_dw = dyp.double().t() @ (ad * gate.double()[:, None, :]).view(npix, L)
+        want_dy = per_img(bn[4]) * ((d * gate.double()[:, None, :] + ds.double()[:, None, :] / HWo) * sg) + per_img(bn[5]) * y \
+            + per_img(bn[6])
+        dev = e.device
+        dw = torch.empty((S, L), device=dev)
+        pool5 = torch.empty((imgs, 5, L), device=dev)
+        e.debug_proj_bwd(ci, 0, dyp.to(dev), yd.to(dev), bn.to(dev), gate.to(dev), None, imgs, groups, dw, pool5)
+        dy = torch.empty((npix, L), device=dev)
+        e.debug_proj_bwd(ci, 1, dyp.to(dev), yd.to(dev), bn.to(dev), gate.to(dev), ds.to(dev), imgs, groups, dy)
+        torch.cuda.synchronize()
+        e5 = [float((pool5[:, t].cpu().double() - want5[:, t]).abs().max() / want5[:, t].abs().max()) for t in range(5)]
+        edw = float((dw.cpu().double() - want_dw).abs().max() / want_dw.abs().max())
+        edy = float((dy.cpu().double().view(imgs, HWo, L) - want_dy).abs().max() / want_dy.abs().max())
+        assert max(e5) < 2e-5, e5                # fp32 sums of 576-2304 terms, fast exp / rcp (~2 ulp)
+        assert edw < 2e-5, edw
+        assert edy < 5e-6, edy
+    finally:
+        e.close()
