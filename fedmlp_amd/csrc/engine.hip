@@ -1457,9 +1457,10 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
             { OP("k_dw_dgrad"); sums = k_dw_dgrad(T_mid, S + m.dw_off, T_big, e->dt, imgs, m.hin, m.win, m.hout, m.wout, m.ce_p, m.k, m.s,
                        m.pad_t, m.pad_l, e->st, ce.y, b0.mean, b0.istd, b0.scale, b0.shift, e->ws_slab, e->ws_part, groups); }
             bool fused = false;
-            if (e->precision && (ce.cout_p == 96 || ce.cout_p == 144) && ce.cin_p <= 32) {
+            if ((ce.cout_p == 96 || ce.cout_p == 144) && ce.cin_p <= 32) {
                 // early blocks (62 % of the expanded-tensor bytes): BN0-backward apply + weight gradient + data gradient of the
-                // expand conv in ONE kernel that reads d a_e and y_e once (pw_exp_bwd_kernel) instead of five passes over them
+                // expand conv in ONE kernel that reads d a_e and y_e once (pw_exp_bwd_kernel / pw_exp_bwd_f32_kernel) instead of
+                // five passes over them
                 OP("exp_bwd_fused");
                 const int pix = B * HWi;
                 if (!sums)
@@ -1468,13 +1469,22 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
                 k_bn_bwd_finalize(e->ws_part, groups, sums ? dw_stats_tiles() : bn_bwd_blocks(pix), b0.C, pix,
                                   e->state + e->off_gamma + b0.ch_off, b0.mean, b0.istd, e->ca, e->cb, e->cc,
                                   e->grad + e->off_gamma + b0.ch_off, e->grad + e->off_beta + b0.ch_off, e->st);
-                PwExpBwdParams q{};
-                q.dA = reinterpret_cast<const bf16*>(T_big); q.Ye = reinterpret_cast<const bf16*>(ce.y);
-                q.X = reinterpret_cast<const bf16*>(in); q.Wt = shadow_of(e, S) + ce.wbt_off;
-                q.res = reinterpret_cast<const bf16*>(m.skip ? go : nullptr); q.dX = reinterpret_cast<bf16*>(gi);
-                q.slab = e->ws_slab; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc; q.sc = b0.scale; q.sh = b0.shift;
-                q.L = ce.cout_p; q.S = ce.cin_p; q.npix = imgs * HWi; q.pix_per_group = pix; q.groups = groups;
-                const int sk = launch_pw_exp_bwd(q, e->slab_floats, e->st);
+                int sk;
+                if (e->precision) {
+                    PwExpBwdParams q{};
+                    q.dA = reinterpret_cast<const bf16*>(T_big); q.Ye = reinterpret_cast<const bf16*>(ce.y);
+                    q.X = reinterpret_cast<const bf16*>(in); q.Wt = shadow_of(e, S) + ce.wbt_off;
+                    q.res = reinterpret_cast<const bf16*>(m.skip ? go : nullptr); q.dX = reinterpret_cast<bf16*>(gi);
+                    q.slab = e->ws_slab; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc; q.sc = b0.scale; q.sh = b0.shift;
+                    q.L = ce.cout_p; q.S = ce.cin_p; q.npix = imgs * HWi; q.pix_per_group = pix; q.groups = groups;
+                    sk = launch_pw_exp_bwd(q, e->slab_floats, e->st);
+                } else {
+                    PwExpBwdF32Params q{};
+                    q.dA = T_big; q.Ye = ce.y; q.X = in; q.W = S + ce.w_off; q.res = m.skip ? go : nullptr; q.dX = gi;
+                    q.slab = e->ws_slab; q.ca = e->ca; q.cb = e->cb; q.cc = e->cc; q.sc = b0.scale; q.sh = b0.shift;
+                    q.L = ce.cout_p; q.S = ce.cin_p; q.npix = imgs * HWi; q.pix_per_group = pix; q.groups = groups;
+                    sk = launch_pw_exp_bwd_f32(q, e->slab_floats, e->st);
+                }
                 if (sk > 0) {
                     k_reduce_slabs(e->ws_slab, G + ce.w_off, sk, (int64_t)ce.w_numel, e->st);
                     fused = true;
@@ -2213,6 +2223,40 @@ int fm_debug_proj_bwd(fm_engine* e, int32_t conv, int32_t phase, const void* dyp
             }
         HIPCHK(hipMemcpy(pool5_dev, o.data(), o.size() * 4, hipMemcpyHostToDevice));
     }
+    HIPCHK(hipGetLastError());
+    return FM_OK;
+}
+
+int fm_debug_exp_bwd(fm_engine* e, int32_t conv, const void* da_dev, const void* ye_dev, const void* x_dev, const void* res_dev,
+                     const float* bn_dev, int32_t imgs, int32_t groups, void* dx_dev, float* dw_dev)
+{
+    ARGCHK(e && da_dev && ye_dev && x_dev && bn_dev && dx_dev && dw_dev && conv >= 0 && conv < (int)e->convs.size(), "operands");
+    ARGCHK(e->model == 1 && e->convs[conv].k == 1, "an EfficientNet engine and a 1x1 convolution");
+    ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && groups <= 2 && imgs % groups == 0, "imgs/groups");
+    Conv& c = e->convs[conv];
+    ensure_packed(e);
+    const int L = c.cout_p, S = c.cin_p, HW = c.hout * c.wout;
+    const size_t gl = (size_t)groups * L;
+    int sk;
+    if (e->precision) {
+        PwExpBwdParams q{};
+        q.dA = reinterpret_cast<const bf16*>(da_dev); q.Ye = reinterpret_cast<const bf16*>(ye_dev);
+        q.X = reinterpret_cast<const bf16*>(x_dev); q.Wt = e->wb + c.wbt_off; q.res = reinterpret_cast<const bf16*>(res_dev);
+        q.dX = reinterpret_cast<bf16*>(dx_dev); q.slab = e->ws_slab;
+        q.ca = bn_dev; q.cb = bn_dev + gl; q.cc = bn_dev + 2 * gl; q.sc = bn_dev + 3 * gl; q.sh = bn_dev + 4 * gl;
+        q.L = L; q.S = S; q.npix = imgs * HW; q.pix_per_group = (imgs / groups) * HW; q.groups = groups;
+        sk = launch_pw_exp_bwd(q, e->slab_floats, e->st);
+    } else {
+        PwExpBwdF32Params q{};
+        q.dA = reinterpret_cast<const float*>(da_dev); q.Ye = reinterpret_cast<const float*>(ye_dev);
+        q.X = reinterpret_cast<const float*>(x_dev); q.W = e->state + c.w_off; q.res = reinterpret_cast<const float*>(res_dev);
+        q.dX = reinterpret_cast<float*>(dx_dev); q.slab = e->ws_slab;
+        q.ca = bn_dev; q.cb = bn_dev + gl; q.cc = bn_dev + 2 * gl; q.sc = bn_dev + 3 * gl; q.sh = bn_dev + 4 * gl;
+        q.L = L; q.S = S; q.npix = imgs * HW; q.pix_per_group = (imgs / groups) * HW; q.groups = groups;
+        sk = launch_pw_exp_bwd_f32(q, e->slab_floats, e->st);
+    }
+    ARGCHK(sk > 0, "shape not handled by the fused expand backward");
+    k_reduce_slabs(e->ws_slab, dw_dev, sk, (int64_t)c.w_numel, e->st);
     HIPCHK(hipGetLastError());
     return FM_OK;
 }

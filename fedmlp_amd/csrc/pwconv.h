@@ -82,6 +82,16 @@ struct PwProjBwdF32Params {
 int pw_proj_bwd_f32_nch(int L, int S, int imgs, int HW);
 int launch_pw_proj_bwd_f32(const PwProjBwdF32Params& p, int phase, size_t slab_floats, hipStream_t s);
 
+// the fp32-storage twin of launch_pw_exp_bwd (expbwd_f32.hip): W = the expand conv's weight [L][S]
+struct PwExpBwdF32Params {
+    const float *dA, *Ye, *X, *W, *res;
+    float* dX;
+    float* slab;
+    const float *ca, *cb, *cc, *sc, *sh;
+    int L, S, npix, pix_per_group, groups;
+};
+int launch_pw_exp_bwd_f32(const PwExpBwdF32Params& p, size_t slab_floats, hipStream_t s);
+
 // fp32 master weights -> bf16 shadows, all 1x1 convolutions in one launch:
 // wb[w_off ...] = bf16(W[m][k]) row-major and wbt[t_off ...] = its transpose [K][M]
 struct CastJob { long long src_off, w_off, t_off; int M, K, blk0; };

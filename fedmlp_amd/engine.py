@@ -325,6 +325,10 @@ class Engine:
         _lib.check(self.lib.fm_debug_proj_bwd(self.h, conv, phase, _ptr(dyp), _ptr(yd), _ptr(bn), _ptr(gate), _ptr(ds), imgs,
                                               groups, _ptr(out), _ptr(pool5)))
 
+    def debug_exp_bwd(self, conv, da, ye, x, res, bn, imgs, groups, dx, dw):
+        _lib.check(self.lib.fm_debug_exp_bwd(self.h, conv, _ptr(da), _ptr(ye), _ptr(x), _ptr(res), _ptr(bn), imgs, groups,
+                                             _ptr(dx), _ptr(dw)))
+
     def debug_activation(self, kind, block, imgs):
         """post-ReLU activation kept by the last train-mode forward, as an NCHW numpy array"""
         dims = (C.c_int32 * 4)()

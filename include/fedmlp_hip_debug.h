@@ -50,6 +50,14 @@ int fm_debug_proj_bwd(fm_engine* e, int32_t conv, int32_t phase, const void* dyp
                       const float* gate_dev, const float* ds_dev, int32_t imgs, int32_t groups, void* out_dev,
                       float* pool5_dev);
 
+/* Fused backward of an expand convolution with its BatchNorm + Swish (pw_exp_bwd_kernel, precision 1: tensors bf16;
+ * pw_exp_bwd_f32_kernel, precision 0: fp32; conv = an expand conv of blocks 1-3):  da = d a_e and ye = y_e [imgs,h,w,cout_p],
+ * x = the block input [imgs,h,w,cin_p], res (optional) = the skip connection's gradient [imgs,h,w,cin_p], bn [5][groups][cout_p]
+ * fp32 = the BN0-backward coefficients ca, cb, cc and the forward's scale, shift.
+ * dx = d y_e W (+ res) [imgs,h,w,cin_p] with d y_e = ca*(da*swish'(ye*scale+shift)) + cb*ye + cc; dw = fp32 [cout_p][cin_p]. */
+int fm_debug_exp_bwd(fm_engine* e, int32_t conv, const void* da_dev, const void* ye_dev, const void* x_dev, const void* res_dev,
+                     const float* bn_dev, int32_t imgs, int32_t groups, void* dx_dev, float* dw_dev);
+
 /* Post-ReLU activations the last train-mode forward kept (ResNet-18): kind 0 = relu(bn1(conv1)) of
  * basic block `block`, kind 1 = the block's output relu(bn2(conv2) + identity); NHWC fp32 for the first
  * `imgs` images, dims4 = {imgs, H, W, C}.  host_nhwc may be NULL to query the dims only.  Parity tests

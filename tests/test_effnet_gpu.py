@@ -628,3 +628,69 @@ def test_fused_project_backward_fp32_kernel(shape):
         assert edy < 5e-6, edy
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(96, 16), (144, 32)])
+def test_fused_expand_backward_kernel(shape, precision):
+    """pw_exp_bwd_f32_kernel / pw_exp_bwd_kernel (blocks 1-3): BN0-backward apply + the expand conv's weight gradient + its data
+    gradient (+ skip gradient) from one read of (d a_e, y_e).  Against the same arithmetic in float64 torch on the operands as
+    stored (bf16: d y_e is rounded to bf16 before the two products, as the unfused passes store it)."""
+    from fedmlp_amd.engine import Engine
+    e = Engine(M, C_, 64, 64, 8, precision=precision)
+    try:
+        e.stochastic = False
+        _load(e)
+        L, S = shape
+        bf = precision == "bf16"
+        ci, info = None, None
+        for c in range(e.debug_num_convs()):
+            i = e.debug_conv_info(c)
+            if i["k"] == 1 and i["cout_p"] == L and i["cin_p"] == S and i["cout"] > i["cin"]:
+                ci, info = c, i
+                break
+        assert ci is not None
+        flat, cnt = e.get_state()
+        sd = spec.flat_to_state_dict(M, C_, flat, cnt)
+        ckeys = [k for k, shp, _ in spec.entries(M, C_) if len(shp) == 4 and "_depthwise" not in k and "_se_" not in k]
+        W = torch.zeros((L, S), dtype=torch.float64)
+        W[:info["cout"], :info["cin"]] = torch.from_numpy(sd[ckeys[ci]].reshape(info["cout"], info["cin"])).double()
+        if bf:
+            W = W.float().to(torch.bfloat16).double()
+        HWi = info["hout"] * info["wout"]
+        imgs, groups = 4, 2
+        npix = imgs * HWi
+        st = torch.bfloat16 if bf else torch.float32
+        g = torch.Generator().manual_seed(5 + L)
+        da = (torch.randn((npix, L), generator=g) * 0.5).to(st)
+        ye = torch.randn((npix, L), generator=g).to(st)
+        x = torch.randn((npix, S), generator=g).to(st)
+        x[:, info["cin"]:] = 0
+        res = (torch.randn((npix, S), generator=g) * 0.3).to(st)
+        bn = torch.empty((5, groups, L))
+        bn[0] = torch.rand((groups, L), generator=g) + 0.5          # ca
+        bn[1] = torch.randn((groups, L), generator=g) * 0.1         # cb
+        bn[2] = torch.randn((groups, L), generator=g) * 0.1         # cc
+        bn[3] = torch.rand((groups, L), generator=g) + 0.5          # scale
+        bn[4] = torch.randn((groups, L), generator=g) * 0.3         # shift
+        per_pix = lambda t: t.double().repeat_interleave(npix // groups, dim=0)
+        y = ye.double()
+        u = y * per_pix(bn[3]) + per_pix(bn[4])
+        sg = torch.sigmoid(u)
+        dy = per_pix(bn[0]) * (da.double() * (sg * (1 + u * (1 - sg)))) + per_pix(bn[1]) * y + per_pix(bn[2])
+        if bf:
+            dy = dy.float().to(torch.bfloat16).double()
+        want_dw = dy.t() @ x.double()
+        want_dx = dy @ W + res.double()
+        dev = e.device
+        dx = torch.empty((npix, S), dtype=st, device=dev)
+        dw = torch.empty((L, S), device=dev)
+        e.debug_exp_bwd(ci, da.to(dev), ye.to(dev), x.to(dev), res.to(dev), bn.to(dev), imgs, groups, dx, dw)
+        torch.cuda.synchronize()
+        edw = float((dw.cpu().double() - want_dw).abs().max() / want_dw.abs().max())
+        edx = float((dx.cpu().double() - want_dx).abs().max() / want_dx.abs().max())
+        # bf16: d y_e may round the other way after the fast exp / rcp (one 2^-9 step in a 96-144-term sum), dX is stored in bf16
+        assert edw < (3e-3 if bf else 2e-5), edw
+        assert edx < (1e-2 if bf else 2e-5), edx
+    finally:
+        e.close()
