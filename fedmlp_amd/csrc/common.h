@@ -130,6 +130,10 @@ struct IgemmParams {
     // gate of an eval-mode project conv: the gated activation is never written); null = no prologue
     const float* gate = nullptr;
     int gate_HW = 1;
+    // + BN1 + Swish in front of the gate (train-mode project conv of the blocks whose backward is fused):
+    // Xe = swish(X * psc[group][k] + psh[group][k]) * gate; null = gate only
+    const float* psc = nullptr;
+    const float* psh = nullptr;
 };
 
 // Weight-gradient GEMM: dW[m][n] = sum_p dY[p][m] * Xg[p][n], split over p.

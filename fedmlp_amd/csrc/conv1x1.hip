@@ -28,8 +28,9 @@ constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
 // the shipped instantiation is <4,2> = 64 channels x 32 pixels
 // STATS: train forward (BN partial sums kept in registers across the pixel loop) -- a template parameter so that the eval /
 // data-gradient launches do not carry the 32 sum registers (3 -> 4 waves per SIMD)
-// GATE: the operand is multiplied by a per-image, per-channel gate on load (IgemmParams::gate)
-template <int RT, int P, bool STATS, bool GATE = false>
+// GATE: 1 = the operand is multiplied by a per-image, per-channel gate on load (IgemmParams::gate); 2 = BN affine + Swish of
+// the operand first (IgemmParams::psc / psh, per statistics group): a_s = swish(bn1(y_d)) * gate is never written (train forward)
+template <int RT, int P, bool STATS, int GATE = 0>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p, int vt_per_block, int blocks_per_group)
 {
     constexpr int MT = 16 * RT;
@@ -79,7 +80,16 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 b[g][k] = (v && kb + k < nkk) ? *reinterpret_cast<const f32x4*>(xp + (kb + k) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (GATE) { if (v && kb + k < nkk) b[g][k] *= *reinterpret_cast<const f32x4*>(gp + (kb + k) * 16); }
+                if constexpr (GATE == 2) {
+                    if (v && kb + k < nkk) {
+                        const int ko = grp * K + 4 * lg + (kb + k) * 16;
+                        f32x4 u = b[g][k] * *reinterpret_cast<const f32x4*>(p.psc + ko) + *reinterpret_cast<const f32x4*>(p.psh + ko);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) u[j] = u[j] * __builtin_amdgcn_rcpf(1.f + __expf(-u[j]));     // act_fwd's fast form (effnet.hip)
+                        b[g][k] = u;
+                    }
+                }
+                if constexpr (GATE != 0) { if (v && kb + k < nkk) b[g][k] *= *reinterpret_cast<const f32x4*>(gp + (kb + k) * 16); }
             }
         }
     };
@@ -209,10 +219,15 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;
     const size_t lds = std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
-    if (p.gate) {
+    if (p.gate && p.psc) {
+        if (!p.stats) return false;                          // the affine prologue exists for the train forward only
         static bool g_done = false;
-        if (!g_done) { set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, false, true>), 64 * 256 * 4, "conv1x1_stream_kernel<gate>"); g_done = true; }
-        hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false, true>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+        if (!g_done) { set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, true, 2>), 64 * 256 * 4, "conv1x1_stream_kernel<affine gate>"); g_done = true; }
+        hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, true, 2>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+    } else if (p.gate) {
+        static bool g_done = false;
+        if (!g_done) { set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, false, 1>), 64 * 256 * 4, "conv1x1_stream_kernel<gate>"); g_done = true; }
+        hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false, 1>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
     } else if (p.stats) hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, true>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
     else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
     return true;

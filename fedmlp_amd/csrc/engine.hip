@@ -819,9 +819,9 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
     }
     p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
-    if (pro && pro->gate && !pro->psc) {         // fp32 eval project conv: only the streaming kernel (conv1x1.hip) applies the gate
-        p.gate = pro->gate; p.gate_HW = c.hout * c.wout;
-        if (!conv1x1_stream_takes(c.cin_p, c.cout_p, c.cout_p) || c.k != 1 || c.stride != 1) soft(e, hipErrorInvalidValue);
+    if (pro && pro->gate) {       // fp32 project conv: only the streaming kernel (conv1x1.hip) applies the gate (eval) or BN1 + Swish + gate (train)
+        p.gate = pro->gate; p.gate_HW = c.hout * c.wout; p.psc = pro->psc; p.psh = pro->psh;
+        if (!conv1x1_stream_takes(c.cin_p, c.cout_p, c.cout_p) || c.k != 1 || c.stride != 1 || (pro->psc && !stats)) soft(e, hipErrorInvalidValue);
     }
     p.M = c.cout_p; p.nsteps = c.nsteps;
     p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
@@ -1172,7 +1172,14 @@ void backward_and_step(fm_engine* e, int groups, int B)
 // Squeeze-excite gate on the project conv's operand load: only where the conv reads its input once or twice
 // (<= 2 M-tiles).  The late blocks (K = 672, 1152: 32-row M-tiles, 6-10 of them) would redo the BN + Swish
 // prologue per M-tile on tensors that are tiny anyway: they keep the materialised a_s.
-bool fuse_for(fm_engine* e, const MBConv& m) { return e->fuse_gate && pw_tiles_m(m.cout_p, m.ce_p) <= 2; }
+// fp32 storage: where the project conv's backward is fused (pw_proj_bwd_f32_kernel needs no a_s) and the train forward streams
+// through conv1x1.hip, which then applies BN1 + Swish + gate on its operand load.
+bool fuse_for(fm_engine* e, const MBConv& m)
+{
+    if (e->precision) return e->fuse_gate && pw_tiles_m(m.cout_p, m.ce_p) <= 2;
+    static const int on = fm_tune("FM_F32_TRAIN_GATE", 1);
+    return on && pw_proj_bwd_f32_nch(m.ce_p, m.cout_p, 1, m.hout * m.wout) > 0 && conv1x1_stream_takes(m.ce_p, m.cout_p, m.cout_p);
+}
 
 // BN over an arbitrary NHWC tensor (depthwise output): statistics by chan_reduce, then the same finalize
 // sums_ready: ws_part already holds dw_stats_tiles() partials per group (left by the depthwise forward)
@@ -1423,6 +1430,8 @@ void eff_backward_and_step(fm_engine* e, int groups, int B)
             }
         }
         if (!pfused) {
+            if (!e->precision && fuse_for(e, m)) soft(e, hipErrorInvalidValue);     // fp32: a_s was not stored for this block and only
+                                                                                    // the fused backward can do without it
             side_begin(0, par);
             if (fuse_for(e, m)) {      // the project conv's operand a_s was never stored: re-formed from y_d on load
                 const Prologue pro{b1.scale, b1.shift, m.gate};
