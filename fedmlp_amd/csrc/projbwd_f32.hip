@@ -1,6 +1,7 @@
 // Fused backward of a project (1x1) convolution with the squeeze-excite gate and BatchNorm1 + Swish in front of it, fp32
 // storage (BASELINE configs[3]: EfficientNet-B0 as the reference runs it), gfx950.  The fp32 twin of pw_proj_bwd_kernel
-// (pwconv_bf16.hip), for the early high-resolution MBConv blocks 0-2.
+// (pwconv_bf16.hip), for the early high-resolution MBConv blocks 0-3 (block 4's 240 x 48 weight and five wave tiles exceed the
+// LDS of a block).
 //
 // Reference ops replaced: inside loss.backward() (utils/local_training.py:674, 965, 1191 through efficientnet_pytorch 0.7.1's
 // MBConvBlock, model/efficientnet.py:28-33) the backward of  y_p = project_conv(swish(bn1(y_d)) * se_gate):  the conv's weight
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void pw_proj_bwd_f32_kernel(const ProjBwdF32Ar
     __syncthreads();
     const int oc = lane % NOCT, jr = lane / NOCT;
     const bool ev = lane < EVL;
-    const int tpi = p.HW >> 5, nruns = p.imgs * p.nch;      // HW % 32 == 0 (launcher)
+    const int tpi = (p.HW + 31) >> 5, nruns = p.imgs * p.nch;
     f32x4 acc[PHASE == 0 ? CS : 1][PHASE == 0 ? NLT : 1];
     if constexpr (PHASE == 0) {
 #pragma unroll
@@ -95,19 +96,22 @@ __global__ __launch_bounds__(256) void pw_proj_bwd_f32_kernel(const ProjBwdF32Ar
                 dv = ld4(p.ds + io) * p.inv_hw;
             }
         }
+        // rows at and beyond nv = HW - 32 t (the ragged last tile of a 28 x 28 image) load zeros and store nothing
         auto gload = [&](int t) {
+            const int nv = p.HW - 32 * t;
             const f32x4* ty = yimg + (size_t)t * 32 * L4;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const int row = jr + NJ * i;
-                vy[i] = (ev && row < 32) ? ty[(size_t)row * L4] : f32x4{0.f, 0.f, 0.f, 0.f};
+                vy[i] = (ev && row < 32 && row < nv) ? ty[(size_t)row * L4] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const f32x4* tx = simg + (size_t)t * 32 * CPR + lane;
 #pragma unroll
-            for (int q = 0; q < NVS; ++q) vs[q] = tx[64 * q];
+            for (int q = 0; q < NVS; ++q) vs[q] = (lane + 64 * q) / CPR < nv ? tx[64 * q] : f32x4{0.f, 0.f, 0.f, 0.f};
         };
         gload(t0);
         for (int t = t0; t < t1; ++t) {
+            const int nv = p.HW - 32 * t;
             // ---- d y_p tile -> LDS ----
 #pragma unroll
             for (int q = 0; q < NVS; ++q) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void pw_proj_bwd_f32_kernel(const ProjBwdF32Ar
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const int row = jr + NJ * i;
-                if (ev && row < 32) {
+                if (ev && row < 32 && row < nv) {
                     float* dp = dt + row * SB + 4 * oc;
                     f32x4 d = *reinterpret_cast<const f32x4*>(dp);
                     const f32x4 y = vy[i];
@@ -223,8 +227,8 @@ int pw_proj_bwd_f32_nch(int L, int S, int imgs, int HW)
 {
     static const int on = fm_tune("FM_PW_PROJ_BWD_F32", 1);
     const int ls = proj_bwd_f32_slice(L);
-    if (!on || !ls || L / ls > 3 || (S != 16 && S != 32) || imgs < 1 || HW % 32 != 0) return 0;
-    const int tpi = HW / 32;
+    if (!on || !ls || L / ls > 3 || (S != 16 && S != 32 && S != 48) || imgs < 1 || HW % 16 != 0) return 0;
+    const int tpi = (HW + 31) / 32;
     return std::max(1, std::min(std::min(16, tpi), (2048 + imgs - 1) / imgs));
 }
 
@@ -251,12 +255,12 @@ int launch_pw_proj_bwd_f32(const PwProjBwdF32Params& w, int phase, size_t slab_f
         hipLaunchKernelGGL((pw_proj_bwd_f32_kernel<N, C, PH>), dim3(nblk), dim3(64 * nwaves), lds, s, a);               \
     } while (0)
     if (phase == 0) {
-        if (ls == 32) { if (w.S == 16) PROJ_F32(2, 1, 0); else PROJ_F32(2, 2, 0); }
-        else { if (w.S == 16) PROJ_F32(3, 1, 0); else PROJ_F32(3, 2, 0); }
+        if (ls == 32) { if (w.S == 16) PROJ_F32(2, 1, 0); else if (w.S == 32) PROJ_F32(2, 2, 0); else PROJ_F32(2, 3, 0); }
+        else { if (w.S == 16) PROJ_F32(3, 1, 0); else if (w.S == 32) PROJ_F32(3, 2, 0); else PROJ_F32(3, 3, 0); }
         return nrw * nblk;
     }
-    if (ls == 32) { if (w.S == 16) PROJ_F32(2, 1, 1); else PROJ_F32(2, 2, 1); }
-    else { if (w.S == 16) PROJ_F32(3, 1, 1); else PROJ_F32(3, 2, 1); }
+    if (ls == 32) { if (w.S == 16) PROJ_F32(2, 1, 1); else if (w.S == 32) PROJ_F32(2, 2, 1); else PROJ_F32(2, 3, 1); }
+    else { if (w.S == 16) PROJ_F32(3, 1, 1); else if (w.S == 32) PROJ_F32(3, 2, 1); else PROJ_F32(3, 3, 1); }
 #undef PROJ_F32
     return 1;
 }

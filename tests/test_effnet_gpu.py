@@ -561,9 +561,9 @@ def test_row_blocked_bn_act_passes_are_bit_identical(monkeypatch, precision):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
 
 
-@pytest.mark.parametrize("shape", [(32, 16), (96, 32), (144, 32)])
+@pytest.mark.parametrize("shape", [(32, 16), (96, 32), (144, 32), (144, 48)])
 def test_fused_project_backward_fp32_kernel(shape):
-    """pw_proj_bwd_f32_kernel (fp32 storage, blocks 0-2): d a_s = d y_p W formed on the fp32 matrix pipe in both phases;
+    """pw_proj_bwd_f32_kernel (fp32 storage, blocks 0-3; the 12 x 12 map of the last shape ends with a ragged 16-pixel tile): d a_s = d y_p W formed on the fp32 matrix pipe in both phases;
     phase 0 = the five per-image sums of (d a_s, y_d) + the project conv's weight gradient with a_s = swish(bn1(y_d)) * gate,
     phase 1 = the BN1-backward apply.  Against the same arithmetic in float64 torch (fp32 summation order and the hardware
     exp / rcp of the fp32 build are the only differences)."""
