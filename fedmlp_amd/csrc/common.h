@@ -7,6 +7,22 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Swish in the fp32 configuration's streaming kernels and conv epilogues: 1 = hardware v_exp_f32 / v_rcp_f32 (both within ~2 ulp
+// of the IEEE sequences; the step parity against the fp32 oracle is unchanged at its 2e-5 / 5e-4 bounds), 0 = expf and 1/x.
+#ifndef FM_F32_FAST_SWISH
+#define FM_F32_FAST_SWISH 1
+#endif
+#ifdef __HIPCC__
+__device__ __forceinline__ float fm_swish_f32(float v)
+{
+#if FM_F32_FAST_SWISH
+    return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+#else
+    return v / (1.f + expf(-v));
+#endif
+}
+#endif
+
 // Tuning knobs of the kernels (tile orders, split counts, variant choices that were measured and settled): the shipped
 // library uses the defaults; a `make TUNING=1` build (-DFM_TUNING) reads them from the environment for measurements.
 // The few RUNTIME switches the shipped library does read are listed in DESIGN.md section 9, each with the test that

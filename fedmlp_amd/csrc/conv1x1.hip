@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 } else if (p.relu == 2) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + expf(-v[q]));
+                    for (int q = 0; q < 4; ++q) v[q] = fm_swish_f32(v[q]);
                 }
                 *reinterpret_cast<f32x4*>(p.Y + o) = v;
             }

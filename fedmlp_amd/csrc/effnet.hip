@@ -22,9 +22,6 @@ __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); 
 // FM_F32_FAST_SWISH (default on): the fp32 configuration takes the hardware exp / rcp in the streaming kernels too
 // (both within ~2 ulp of the IEEE sequences: the step parity against the fp32 oracle is unchanged at its 2e-5 / 5e-4
 // bounds, and the BN / squeeze-excite passes stop being issue-bound).  -DFM_F32_FAST_SWISH=0 restores expf and 1/x.
-#ifndef FM_F32_FAST_SWISH
-#define FM_F32_FAST_SWISH 1
-#endif
 template <bool FAST> __device__ __forceinline__ float sigm_t(float v)
 {
     if constexpr (FAST || FM_F32_FAST_SWISH) return __builtin_amdgcn_rcpf(1.f + __expf(-v));

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                 } else if (p.relu == 2) {                           // swish (EfficientNet eval epilogue)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + expf(-v[q]));
+                    for (int q = 0; q < 4; ++q) v[q] = fm_swish_f32(v[q]);
                 }
                 *reinterpret_cast<f32x4*>(p.Y + o + m) = v;
             }
