@@ -1201,8 +1201,6 @@ int pw_proj_bwd_nch(int L, int S, int imgs, int HW)
     const int ls = proj_bwd_slice(L);
     if (!on || !ls || L / ls > 5 || (S != 16 && S != 32 && S != 48) || imgs < 1) return 0;
     if (HW % 32 != 0 && (!ragged || HW % 16 != 0)) return 0;
-    static const int dbg_l = fm_tune("FM_PW_PROJ_DBGL", 0);
-    if (HW % 32 != 0 && dbg_l && L != dbg_l) return 0;
     const int tpi = (HW + 31) / 32;
     return std::max(1, std::min(std::min(16, tpi), (2048 + imgs - 1) / imgs));
 }
