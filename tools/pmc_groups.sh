@@ -10,7 +10,7 @@ G[sq]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_C
 G[ta]="TA_TA_BUSY TA_BUFFER_TOTAL_CYCLES TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES"
 G[tcp]="TCP_PENDING_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES TCP_GATE_EN1"
 G[td]="TD_TD_BUSY TD_TC_STALL GRBM_GUI_ACTIVE"
-for g in sq ta tcp td; do
+for g in ${PMC_GROUPS:-sq tcp td}; do
   rm -rf $OUT/$TAG.$g
   timeout 240 rocprofv3 --pmc ${G[$g]} --kernel-trace --output-format csv -d $OUT/$TAG.$g -- python3 bench.py "$@" --one-stream --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $OUT/$TAG.$g.log 2>&1
   echo "group $g rc=$?"
