@@ -26,6 +26,10 @@
 //    row strides are 32 B x odd so that the 8 row segments a half-wave touches fall on distinct banks.
 //    Block tile = 64 channels of the larger channel count x ALL of the smaller one (<= 320): the large
 //    operand is read exactly once; split over pixels, fp32 slabs, fixed-order reduction (deterministic).
+//  * fused backward kernels of the high-resolution MBConv blocks (further down, each with its own header):
+//    pw_exp_bwd_kernel -- BN0-backward apply + expand weight gradient + data gradient from one read of (d a_e, y_e);
+//    pw_proj_bwd_kernel -- the project conv's backward with the squeeze-excite / BN1 backward around it, in two phases that
+//    re-form d a_s = d y_p W on the matrix pipe instead of storing it (7 passes over the depthwise-resolution tensors -> 3).
 #include <stdlib.h>
 
 #include <algorithm>
