@@ -12,4 +12,4 @@ bash tools/pmc_run.sh ebf "Efficient_b0/bf16/stage1/bs512/hw224/C5" 3 1 --model 
 bash tools/pmc_run.sh ef32 "Efficient_b0/fp32/stage1/bs256/hw224/C5" 3 1 --model Efficient_b0 --batch 256 > gpurun_out/$TAG/pmc_ef32.log 2>&1
 python tools/op_profile.py --precision bf16 --batch 512 --streams 1 > gpurun_out/$TAG/op_profile_one_stream_bf16_bs512.txt 2>/dev/null
 python tools/op_profile.py --precision fp32 --batch 256 --streams 1 > gpurun_out/$TAG/op_profile_one_stream_f32_bs256.txt 2>/dev/null
-tail -3 gpurun_out/$TAG/pmc_ebf.log gpurun_out/$TAG/pmc_ef32.log
+for f in gpurun_out/$TAG/pmc_ebf.log gpurun_out/$TAG/pmc_ef32.log; do tail -n 3 $f; done
