@@ -1475,7 +1475,7 @@ static void dw_rowu_wgrad_launch(const T* dy, const T* x, float* part, float* ou
     constexpr int RB = S == 1 ? 2 : 1;
     const int WB = (Wo + 3) / 4, HB = (Ho + RB - 1) / RB, Q = C / 4;
     const int nchunk = (WB * Q + 63) / 64, nsteps = imgs * HB;
-    static const int tgt = fm_tune("FM_DW_WG_BLOCKS", 1536);
+    static const int tgt = fm_tune("FM_DW_WG_BLOCKS", 2048);
     int spb = std::max(8, (int)(((int64_t)nsteps * nchunk + tgt - 1) / tgt));
     spb = (spb + 3) / 4 * 4;
     const int nrg = (nsteps + spb - 1) / spb;
