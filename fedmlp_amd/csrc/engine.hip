@@ -927,7 +927,11 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
     p.tilesM = (c.cout_p + bm - 1) / bm;
     p.tilesN = (c.Kw + bn - 1) / bn;
     const int tiles = p.tilesM * p.tilesN;
-    int splits = std::max(1, 1024 / tiles);           // tiles*splits <= 1024 = 2 full rounds of 512 block slots
+    // tiles * splits <= 512 = ONE round of the 512 block slots: with the weight gradients on the side stream next to the
+    // BN-backward / data-gradient chain, a second round of their blocks holds slots the main stream's next GEMM is waiting for
+    // (two-stream step 36.8 -> 36.3 ms; one stream: 38.5 either way; 384: 37.3, 640: 37.4, 1024 = round 2's choice)
+    static const int wg_slots = fm_tune("FM_WGRAD_SLOTS", 512);
+    int splits = std::max(1, wg_slots / tiles);
     const int max_by_pix = std::max(1, p.npix / 256);
     const int max_by_mem = (int)std::max<size_t>(1, e->slab_floats / c.w_numel);
     splits = std::max(1, std::min(splits, std::min(max_by_pix, max_by_mem)));
