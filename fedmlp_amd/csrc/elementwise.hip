@@ -221,6 +221,41 @@ void k_scale(float* x, float w, int64_t n, hipStream_t s)
     hipLaunchKernelGGL(scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, w, n);
 }
 
+// FedAvg of K client states that share this GPU (utils/FedAvg.py:7-14).  HBM-bound: (K + 1) x 4 B per element, 16 B per lane.
+// __fmul_rn / __fadd_rn / __fdiv_rn keep the reference's roundings (no contraction into FMAs, IEEE division).
+__global__ void __launch_bounds__(256) fedavg_fold_kernel(FoldArgs a, int K, float tot, float* __restrict__ out, int64_t n4)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(a.s[0])[i];
+        float4 acc = {__fmul_rn(v.x, a.n[0]), __fmul_rn(v.y, a.n[0]), __fmul_rn(v.z, a.n[0]), __fmul_rn(v.w, a.n[0])};
+        for (int k = 1; k < K; ++k) {
+            v = reinterpret_cast<const float4*>(a.s[k])[i];
+            acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, a.n[k]));
+            acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, a.n[k]));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, a.n[k]));
+            acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, a.n[k]));
+        }
+        acc.x = __fdiv_rn(acc.x, tot); acc.y = __fdiv_rn(acc.y, tot); acc.z = __fdiv_rn(acc.z, tot); acc.w = __fdiv_rn(acc.w, tot);
+        reinterpret_cast<float4*>(out)[i] = acc;
+    }
+}
+__global__ void fedavg_fold_tail_kernel(FoldArgs a, int K, float tot, float* __restrict__ out, int64_t i0, int64_t n)
+{
+    const int64_t i = i0 + threadIdx.x;
+    if (i >= n) return;
+    float acc = __fmul_rn(a.s[0][i], a.n[0]);
+    for (int k = 1; k < K; ++k) acc = __fadd_rn(acc, __fmul_rn(a.s[k][i], a.n[k]));
+    out[i] = __fdiv_rn(acc, tot);
+}
+void k_fedavg_fold(const FoldArgs& a, int K, float tot, float* out, int64_t n, hipStream_t s)
+{
+    const int64_t n4 = n / 4;
+    if (n4) hipLaunchKernelGGL(fedavg_fold_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 8192)), dim3(256), 0, s, a, K, tot, out, n4);
+    if (n4 * 4 < n) hipLaunchKernelGGL(fedavg_fold_tail_kernel, dim3(1), dim3(64), 0, s, a, K, tot, out, n4 * 4, n);
+}
+
 // ------------------------------------------------------------ augmentation -----
 // Replaces, for a uint8 cache of already-resized images kept in HBM, the per-sample CPU work of
 // the reference's train transform (dataset/dataset.py:40-53): RandomAffine(10 deg, 2 %) with

@@ -199,17 +199,17 @@ struct fm_engine {
     bool wb_dirty = true, twb_dirty = true;
     bool fuse_gate = false;           // squeeze-excite gate applied on the project conv's operand load (a_s never stored)
     // stage-1 steps of EfficientNet-B0: the frozen teacher's forward is independent of the student's until the loss, so it is
-    // enqueued on a side stream with its own activation / workspace set (FM_SIDE_TEACHER=0: one stream, shared buffers)
+    // enqueued on a side stream with its own activation / workspace set (stream_mode 1: one stream, shared buffers)
     hipStream_t st2 = nullptr;
     hipEvent_t ev_in = nullptr, ev_t = nullptr;
     bool side_ok = false;
     float *t_a0 = nullptr, *t_Tmid = nullptr, *t_se_pool = nullptr, *t_rec = nullptr;
     float *t_c0y = nullptr, *t_p0 = nullptr;                        // ResNet-18: stem output / pooled stem of the teacher
     // EfficientNet backward: the weight gradients of the 1x1 and depthwise convs run on the side stream next to the
-    // data-gradient chain; the gradient tensors they read are double-buffered by block parity (FM_SIDE_WGRAD=0: inline)
+    // data-gradient chain; the gradient tensors they read are double-buffered by block parity (stream_mode 1 or 2: inline)
     bool side_w = false;
     float *T_small2 = nullptr, *T_mid2 = nullptr, *T_big2 = nullptr, *ws_slab2 = nullptr;
-    float *GB2 = nullptr, *GC2 = nullptr, *GD2 = nullptr;           // ResNet-18 (FM_SIDE_TEACHER=2): the same for d y2 / d y_ds / d y1
+    float *GB2 = nullptr, *GC2 = nullptr, *GD2 = nullptr;           // ResNet-18 (stream_mode 0): the same for d y2 / d y_ds / d y1
     hipEvent_t ev_p[4][2] = {}, ev_c[4][2] = {}, ev_wdone = nullptr;    // [tensor: d y_p, d y_d, d y_e, SE vectors][block parity]
     float *se_dgp2 = nullptr, *se_drp2 = nullptr;
     float* sk_slab2 = nullptr;                                       // stream-K fix-up workspace of igemm launches on st2
@@ -695,7 +695,21 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->sk_counters, (size_t)1 << 20);
     HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
     {
-        const int side = e->stream_mode != 1;
+        int side = e->stream_mode != 1;
+        if (side && e->model == 0) {
+            // the teacher's activation set, the second gradient / slab buffers: keep one stream when they would not fit with
+            // 4 GB to spare (the EfficientNet branch above guards its own second set the same way); fm_stream_mode() reports
+            // the mode that was actually set up
+            const Conv& c0 = e->convs[0];
+            const size_t pooled = B * (c0.hout / 2) * (c0.wout / 2) * 64;
+            size_t need = (B * c0.hout * c0.wout * c0.cout_p + 4 * pooled + e->slab_floats) * 4, free_b = 0, total_b = 0;
+            for (auto& blk : e->blocks) {
+                const Conv& c = e->convs[blk.c1];
+                need += (size_t)(blk.ds >= 0 ? 3 : 2) * B * c.hout * c.wout * c.cout * 4;
+            }
+            need += (size_t)igemm_max_blocks() * 2 * 16384 * 4 + ((size_t)4 << 20);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)4 << 30)) side = 0;
+        }
         if (side) {
             DALLOC(e->sk_slab2, (size_t)igemm_max_blocks() * 2 * 16384);
             DALLOC(e->sk_counters2, (size_t)1 << 20);
@@ -821,7 +835,11 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
     if (pro && pro->gate) {       // fp32 project conv: only the streaming kernel (conv1x1.hip) applies the gate (eval) or BN1 + Swish + gate (train)
         p.gate = pro->gate; p.gate_HW = c.hout * c.wout; p.psc = pro->psc; p.psh = pro->psh;
-        if (!conv1x1_stream_takes(c.cin_p, c.cout_p, c.cout_p) || c.k != 1 || c.stride != 1 || (pro->psc && !stats)) soft(e, hipErrorInvalidValue);
+        // the streaming kernel has a gate-only eval form (no statistics) and a BN1 + Swish + gate train form (statistics): a
+        // gate-only prologue WITH statistics, or a full prologue without them, has no instantiation
+        if (!conv1x1_stream_takes(c.cin_p, c.cout_p, c.cout_p) || c.k != 1 || c.stride != 1 || (pro->psc && !stats) ||
+            (!pro->psc && stats))
+            soft(e, hipErrorInvalidValue);
     }
     p.M = c.cout_p; p.nsteps = c.nsteps;
     p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
@@ -1100,7 +1118,7 @@ void backward_and_step(fm_engine* e, int groups, int B)
     const int imgs = groups * B;
     const float* S = e->state;
     const Conv& cl = e->convs[e->blocks.back().c2];
-    // side_w (FM_SIDE_TEACHER=2): the weight gradients run on the side stream next to the BN-backward / data-gradient chain
+    // side_w (stream_mode 0): the weight gradients run on the side stream next to the BN-backward / data-gradient chain
     // (d y2, d y_ds, d y1 double-buffered by block parity, own slab workspace) -- same scheme as eff_backward_and_step
     const bool sw = e->side_w;
     float* GBp[2] = {e->GB, sw ? e->GB2 : e->GB};
@@ -1742,6 +1760,32 @@ int fm_state_scale(fm_engine* e, float w)
     k_scale(e->state, w, (int64_t)e->NS, e->st);
     e->ev_dirty = true;
     e->wpack_dirty = true;
+    return FM_OK;
+}
+
+int fm_stream_mode(fm_engine* e)
+{
+    if (!e) return -1;
+    return e->side_ok ? (e->side_w ? 0 : 2) : 1;
+}
+
+int fm_fedavg_fold(fm_engine* e, const float* const* states_dev, const float* n_host, int32_t K, float* out_dev)
+{
+    ARGCHK(e && states_dev && n_host && out_dev, "null argument");
+    ARGCHK(K >= 1 && K <= FM_FOLD_MAX, "fm_fedavg_fold: 1 <= K <= FM_FOLD_MAX");
+    FoldArgs a{};
+    float tot = 0.f;                                    // sum(dict_len) as the reference's Python int sum, exact below 2^24
+    double tot_d = 0.0;
+    for (int k = 0; k < K; ++k) {
+        ARGCHK(states_dev[k], "fm_fedavg_fold: null state pointer");
+        a.s[k] = states_dev[k];
+        a.n[k] = n_host[k];
+        tot_d += (double)n_host[k];
+    }
+    tot = (float)tot_d;
+    k_fedavg_fold(a, K, tot, out_dev, (int64_t)e->NS, e->st);
+    if (out_dev == e->state) { e->ev_dirty = true; e->wpack_dirty = true; e->wb_dirty = true; }
+    HIPCHK(hipGetLastError());
     return FM_OK;
 }
 

@@ -30,6 +30,11 @@ struct PackJob { long long w_off; float* out; int Co, T, Ci, ntaps; int taps[9];
 void k_pack_dgrad_all(const float* state, const PackJob* jobs, int njobs, int nblocks, hipStream_t s);
 int pack_job_blocks(int Co, int Ci, int ntaps);      // blocks of one job (32 x 32 tiles per tap); PackJob.blk0 = running sum
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
+// utils/FedAvg.py:7-14 over K engine-layout states on one GPU: out = ((s0*n0 + s1*n1) + ...) / tot, the reference's
+// left-to-right order with separately rounded products, sums and an IEEE division (bit-identical on fp32 entries)
+#define FM_FOLD_MAX 16
+struct FoldArgs { const float* s[FM_FOLD_MAX]; float n[FM_FOLD_MAX]; };
+void k_fedavg_fold(const FoldArgs& a, int K, float tot, float* out, int64_t n, hipStream_t s);
 void k_axpby(float* y, const float* x, float a, float b, int64_t n, hipStream_t s);   // y = a*y + b*x
 
 // ---- input pipeline: uint8 HBM cache -> augmented, normalised fp32 NCHW batch.

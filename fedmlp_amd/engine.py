@@ -58,6 +58,8 @@ class Engine:
         assert (self.nf, self.ni) == spec.sizes(model, self.n_classes), \
             "engine and fedmlp_amd.spec disagree on the state_dict layout"
         self.feature_dim = spec.FEATURE_DIM[model]
+        # what fm_create actually set up (it keeps one stream when the second buffer set does not fit in free memory)
+        self.stream_mode = int(self.lib.fm_stream_mode(self.h))
         # Efficient_b0: draw drop-connect / dropout multipliers before every train step, like the
         # reference's model does inside net(images) in train mode.  Parity tests switch it off and
         # install their own draws with set_stochastic().
@@ -124,6 +126,28 @@ class Engine:
     def state_scale(self, w):
         _lib.check(self.lib.fm_state_scale(self.h, C.c_float(w)))
 
+    def fedavg_fold(self, states, dict_len, out=None):
+        """FedAvg (utils/FedAvg.py:7-14) of K engine-layout device states on this GPU, reference order and roundings.
+        states: list of cuda fp32 tensors of state_tensor()'s length; out: destination (default: the engine's own state)."""
+        K = len(states)
+        assert K == len(dict_len) and K >= 1
+        for t in states:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == self.state_tensor().numel()
+        ptrs = (C.c_void_p * K)(*[t.data_ptr() for t in states])
+        dst = self.state_tensor() if out is None else out
+        self._check_stream()
+        _lib.check(self.lib.fm_fedavg_fold(self.h, ptrs, _lib.fvec(dict_len, K), K, _ptr(dst)))
+        return dst
+
+    def _check_stream(self):
+        """The engine enqueues on the stream that was torch's current one when it was built (fm_config.stream is fixed for
+        the handle's life: its workspaces are ordered on that stream).  A call made under another torch.cuda.stream(...)
+        would race with the producers of its inputs, so it is refused."""
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if cur != self.stream:
+            raise RuntimeError(f"fedmlp_amd.Engine was built on stream {self.stream:#x} but torch's current stream is "
+                               f"{cur:#x}: call the engine under the stream it was created on")
+
     def teacher_snapshot(self):
         _lib.check(self.lib.fm_teacher_snapshot(self.h))
 
@@ -143,6 +167,7 @@ class Engine:
 
     def forward_eval_into(self, x, feat, logits, teacher=False):
         """net(x) in eval mode into caller-owned [B,D] / [B,C] device buffers (no allocation)."""
+        self._check_stream()
         _lib.check(self.lib.fm_forward_eval(self.h, _ptr(x), x.shape[0], int(teacher), _ptr(feat), _ptr(logits)))
         return feat, logits
 
@@ -190,24 +215,28 @@ class Engine:
             self.draw_stochastic(imgs, self.stochastic_generator)
 
     def step_bce(self, x, y, pos_weight, bs_norm, loss_out):
+        self._check_stream()
         self._draw(x.shape[0])
         _lib.check(self.lib.fm_step_bce(self.h, _ptr(x), _ptr(y), x.shape[0],
                                         _lib.fvec(pos_weight, self.n_classes), int(bs_norm),
                                         _ptr(loss_out)))
 
     def step_stage1(self, x1, x2, y, active_mask, annotation_num, bs_norm, loss_out):
+        self._check_stream()
         self._draw(2 * x1.shape[0])
         _lib.check(self.lib.fm_step_stage1(self.h, _ptr(x1), _ptr(x2), _ptr(y), x1.shape[0],
                                            _lib.fvec(active_mask, self.n_classes),
                                            int(annotation_num), int(bs_norm), _ptr(loss_out)))
 
     def step_stage2(self, x, y, distill, loss_out):
+        self._check_stream()
         self._draw(x.shape[0])
         _lib.check(self.lib.fm_step_stage2(self.h, _ptr(x), _ptr(y), _ptr(distill), x.shape[0],
                                            _ptr(loss_out)))
 
     def step_fixmatch(self, xw, xs, y, pos_weight, pos_weight_unk, active_mask, annotation_num,
                       bs_norm, loss_out):
+        self._check_stream()
         n = self.n_classes
         self._draw(2 * xw.shape[0])
         _lib.check(self.lib.fm_step_fixmatch(
@@ -218,6 +247,7 @@ class Engine:
     # ---- prototypes / tagging ------------------------------------------------------
     # ---- generic split step (rank-4 baselines: loss head computed by the host mirror) -----------
     def forward_train(self, x1, x2=None):
+        self._check_stream()
         views = 1 if x2 is None else 2
         B = x1.shape[0]
         self._draw(views * B)
@@ -227,6 +257,7 @@ class Engine:
         return feat, logits
 
     def backward_step(self, dlogits):
+        self._check_stream()
         _lib.check(self.lib.fm_backward_step(self.h, _ptr(dlogits.contiguous().float())))
 
     def teacher_axpby(self, w_teacher, w_student):

@@ -91,6 +91,14 @@ int fm_state_device(fm_engine* e, float** dev_ptr, int64_t* numel);
 int fm_counters(fm_engine* e, int64_t* host_i64, int32_t set);
 /* state *= w  (the n_i / sum(n) pre-scale before the all-reduce SUM). */
 int fm_state_scale(fm_engine* e, float w);
+/* FedAvg (utils/FedAvg.py:7-14) of K client states that share ONE GPU (main.py:135-218 trains its clients in turn and
+ * aggregates their state_dicts in one process): out[j] = ((s_0[j]*n_0 + s_1[j]*n_1) + ...) / sum(n) in the reference's
+ * left-to-right order with its roundings (separate fp32 product and sum, IEEE division), so fp32 entries are bit-identical
+ * to utils/FedAvg.py.  states_dev: HOST array of K device pointers to engine-layout states (fm_state_device()'s layout and
+ * length, e.g. copies of it taken after each client's round); n_host: the K sample counts (dict_len); K <= 16; out_dev may
+ * be fm_state_device()'s buffer itself or any of the inputs.  The num_batches_tracked counters stay with the caller
+ * (fm_counters). */
+int fm_fedavg_fold(fm_engine* e, const float* const* states_dev, const float* n_host, int32_t K, float* out_dev);
 /* ---- FedAvg across ranks as RCCL calls inside the library (one client per GPU) --------------
  * utils/FedAvg.py:7-14 (FedAvg), :51-70 (FedAvg_tao), :72-93 (FedAvg_proto) walk a Python list of
  * client results in one process.  With one process per GPU the same weighted sums are
@@ -239,6 +247,10 @@ int fm_teacher_swap(fm_engine* e);
 int fm_set_stochastic(fm_engine* e, const float* drop_connect_dev, const float* dropout_dev);
 /* feature width of the model: 512 (ResNet-18) or 1280 (EfficientNet-B0) */
 int fm_feature_dim(fm_engine* e);
+/* The stream mode that was actually set up (fm_config.reserved[1] asks; fm_create falls back to one stream when the
+ * second activation / workspace set would not fit in free device memory): 0 teacher + weight gradients on the side
+ * stream, 2 teacher only, 1 one stream. */
+int fm_stream_mode(fm_engine* e);
 
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the

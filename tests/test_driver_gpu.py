@@ -26,6 +26,20 @@ def test_driver_fedmlp_two_stage_smoke():
     assert log[1]["mean_loss"] < log[0]["mean_loss"] * 1.5
 
 
+def test_driver_two_stage_with_tail_batches():
+    """--n_local 97 at --batch_size 32: every pass of every client ends with a batch of ONE sample (two views), the
+    prototype pass (batches of 4 * 32) is a single short batch, the stage-2 feature pass ends with one image.  The
+    reference keeps such tails (DataLoader drop_last=False, utils/local_training.py:47-48) and normalises by
+    args.batch_size (:956-959)."""
+    log = _run(["--exp", "FedMLP", "--n_clients", "2", "--n_classes", "4", "--rounds_warmup", "4",
+                "--rounds_FedMLP_stage1", "2", "--batch_size", "32", "--n_local", "97", "--hw", "64", "--pretrained", "0",
+                "--clean_threshold", "0.05", "--noise_threshold", "0.1"])
+    assert len(log) == 4 and all(np.isfinite(r["mean_loss"]) for r in log)
+    log2 = _run(["--exp", "FedAVG+FixMatch", "--n_clients", "2", "--n_classes", "4", "--rounds_warmup", "2",
+                 "--batch_size", "32", "--n_local", "100", "--hw", "64", "--pretrained", "0"])
+    assert len(log2) == 2 and all(np.isfinite(r["mean_loss"]) for r in log2)
+
+
 def test_driver_fedavg_smoke():
     log = _run(["--exp", "FedAVG", "--n_clients", "2", "--n_classes", "4", "--rounds_warmup", "2",
                 "--batch_size", "32", "--n_local", "96", "--hw", "64", "--pretrained", "0"])

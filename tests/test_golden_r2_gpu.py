@@ -172,7 +172,8 @@ def _replay_two_stage(name, tol, tol_after_split, delta=(2.5e-2, 6e-2), model="R
     P = np.load(os.path.join(GOLDEN, name + "_protos.npz"))
     C, n_cl, N, S1 = g["C"], g["n_clients"], g["N"], g["S1"]
     args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=S1, seed=g["init_seed"], pretrained=0, model=model,
-                     feature_dim=spec.FEATURE_DIM[model], precision=precision)
+                     feature_dim=spec.FEATURE_DIM[model], precision=precision,
+                     clean_threshold=g.get("clean_threshold", 0.005), noise_threshold=g.get("noise_threshold", 0.01))
     ds = SynthDataset(n_cl * N, C, g["hw"], g["data_seed"], True, g.get("p_pos", 0.3))
     pos, neg = class_lists(ds.targets, C)
     netglob = _init_net(args, g.get("bn_seed"))

@@ -165,3 +165,57 @@ def test_library_rccl_world_of_one(eng):
     out = eng.fedavg_proto(p, 300, [1, 0, 0, 0, 0])
     np.testing.assert_allclose(out[:2], p[:2], rtol=1e-6)
     assert np.isnan(out[2:]).all()
+
+
+def test_fedavg_fold_is_bit_exact_with_the_reference(eng, kat):
+    """fm_fedavg_fold (several clients' states on ONE GPU) reproduces utils/FedAvg.py:7-14 bit for bit on fp32 entries: the
+    reference's own known-answer vector embedded at the head of arena-sized states, and the rest of the arena against the
+    same left-to-right float32 arithmetic in numpy (what the host drop-in FedAvg, pinned on that KAT, computes)."""
+    g = kat["fedavg"]
+    n = eng.state_tensor().numel()
+    lens = g["lens"]
+    K = len(g["w"])
+    rs = np.random.RandomState(5)
+    host = [rs.standard_normal(n).astype(np.float32) for _ in range(K)]
+    fkeys = [k for k in g["w"][0] if "num_batches" not in k]
+    want_head = np.concatenate([np.asarray(g["out"][k], np.float32).reshape(-1) for k in fkeys])
+    for i in range(K):
+        head = np.concatenate([np.asarray(g["w"][i][k], np.float32).reshape(-1) for k in fkeys])
+        host[i][:head.size] = head
+    states = [torch.from_numpy(h).to(eng.device) for h in host]
+    out = torch.empty_like(states[0])
+    eng.fedavg_fold(states, lens, out)
+    got = out.cpu().numpy()
+    np.testing.assert_array_equal(got[:want_head.size], want_head)
+    acc = host[0] * np.float32(lens[0])
+    for i in range(1, K):
+        acc = acc + host[i] * np.float32(lens[i])
+    np.testing.assert_array_equal(got, acc / np.float32(sum(lens)))
+
+
+def test_fedavg_fold_of_eight_clients_into_the_engine_state(eng):
+    """K = 8 (BASELINE configs[1]: 8 clients), uneven sample counts, the engine's own state as the destination: the folded
+    state is what the next forward uses (derived buffers are rebuilt)."""
+    from fedmlp_amd import spec
+    flat, cnt = spec.init_state("Resnet18", C_, 1037)
+    eng.set_state(flat, cnt)
+    base = eng.state_tensor().clone()
+    g = torch.Generator(device=eng.device).manual_seed(2)
+    lens = [5000, 4999, 37, 5000, 1, 2500, 5000, 123]
+    states = [(base * (1.0 + 0.01 * torch.randn(base.shape, device=eng.device, generator=g))).contiguous() for _ in lens]
+    hs = [s.cpu().numpy() for s in states]
+    acc = hs[0] * np.float32(lens[0])
+    for i in range(1, len(lens)):
+        acc = acc + hs[i] * np.float32(lens[i])
+    want = acc / np.float32(sum(lens))
+    x = torch.randn((4, 3, HW, HW), device=eng.device, generator=g)
+    eng.forward_eval(x)                                   # derived buffers (BN folds, packs) built for the old state
+    eng.fedavg_fold(states, lens)                         # out = the engine's state
+    np.testing.assert_array_equal(eng.state_tensor().cpu().numpy(), want)
+    f1, z1 = eng.forward_eval(x)
+    folded_flat, _ = eng.get_state()
+    eng.set_state(folded_flat, cnt)
+    f2, z2 = eng.forward_eval(x)
+    assert torch.equal(z1, z2) and torch.equal(f1, f2)
+    with pytest.raises(Exception):
+        eng.fedavg_fold(states * 3, lens * 3)             # K > 16

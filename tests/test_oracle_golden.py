@@ -143,15 +143,31 @@ def test_traj_fixmatch():
     assert_norms_close(norms_of(sd), g["norms"], 1e-5)
 
 
-def test_traj_fedmlp_two_stage():
-    """Full two-stage FedMLP flow incl. prototype pass, tagging, selection, FedAvg*."""
-    g = load_golden("traj_fedmlp.json")
-    P = np.load(GOLDEN + "/traj_fedmlp_protos.npz")
+def _perturb_bn(net, seed):
+    """the conditioned goldens' initial BatchNorm affine (tests/synth.perturbed_bn, as make_golden.py applies it)"""
+    if seed is None:
+        return net
+    from tests.synth import perturbed_bn
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, v in perturbed_bn([(k, tuple(t.shape)) for k, t in sd.items()], seed):
+            sd[k].copy_(torch.from_numpy(v))
+    return net
+
+
+@pytest.mark.parametrize("name", ["traj_fedmlp", "traj_fedmlp_tail4", "traj_fedmlp_tail1"])
+def test_traj_fedmlp_two_stage(name):
+    """Full two-stage FedMLP flow incl. prototype pass, tagging, selection, FedAvg*.  The tail goldens (N = 100 / 97 at
+    bs 32) end every pass with a batch of 4 / of ONE image per view, normalised by args.batch_size
+    (utils/local_training.py:47-48, 956-959)."""
+    g = load_golden(name + ".json")
+    P = np.load(GOLDEN + f"/{name}_protos.npz")
     C, n_cl, N, S1 = g["C"], g["n_clients"], g["N"], g["S1"]
-    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=S1)
+    args = make_args(n_classes=C, n_clients=n_cl, rounds_FedMLP_stage1=S1,
+                     clean_threshold=g.get("clean_threshold", 0.005), noise_threshold=g.get("noise_threshold", 0.01))
     data = data_dict(n_cl * N, C, g["hw"], g["data_seed"], True)
     _, neg = class_lists(data["targets"], C)
-    glob = oracle_net(C, g["init_seed"])
+    glob = _perturb_bn(oracle_net(C, g["init_seed"]), g.get("bn_seed"))
     clients = [R.RefClient(args, i, data, g["users"][i], neg, [i]) for i in range(n_cl)]
     assert [c.negative for c in clients] == g["neg_lists"]
     prototype, lens = None, [N] * n_cl
@@ -183,6 +199,24 @@ def test_traj_fedmlp_two_stage():
             np.testing.assert_allclose(prototype.numpy(), P[f"r{rnd}_glob_proto"],
                                        rtol=1e-5, atol=1e-6, equal_nan=True)
         assert_norms_close(norms_of(glob.state_dict()), r["glob_norms"], 1e-5)
+
+
+@pytest.mark.parametrize("tail", [4, 1])
+def test_traj_fixmatch_tails(tail):
+    """train_FixMatch with a last batch of 4 / of ONE image (two views), bs_norm = 32"""
+    g = load_golden("traj_fixmatch_tails.json")[f"tail{tail}"]
+    C, N = g["C"], g["N"]
+    args = make_args(n_classes=C, n_clients=1)
+    data = data_dict(N, C, g["hw"], g["data_seed"], True)
+    _, neg = class_lists(data["targets"], C)
+    net = _perturb_bn(oracle_net(C, g["init_seed"]), g["bn_seed"])
+    with torch.no_grad():
+        net.fc.weight.mul_(g["fc_scale"])
+    cl = R.RefClient(args, 0, data, list(range(N)), neg, [0])
+    np.testing.assert_allclose(cl.loss_w_unknown, g["loss_w_unknown"], rtol=0)
+    sd, loss, _ = cl.train_fixmatch(net, g["order"])
+    assert abs(loss - g["loss"]) <= 1e-5 * abs(g["loss"])
+    assert_norms_close(norms_of(sd), g["norms"], 1e-5)
 
 
 def test_step224():
