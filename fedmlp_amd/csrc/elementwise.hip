@@ -222,32 +222,38 @@ void k_scale(float* x, float w, int64_t n, hipStream_t s)
 }
 
 // FedAvg of K client states that share this GPU (utils/FedAvg.py:7-14).  HBM-bound: (K + 1) x 4 B per element, 16 B per lane.
-// __fmul_rn / __fadd_rn / __fdiv_rn keep the reference's roundings (no contraction into FMAs, IEEE division).
+// The reference rounds every product and every sum separately (numpy / torch CPU fp32) and divides with an IEEE division:
+// contraction into FMAs is switched off for these two kernels (hipcc's default is -ffp-contract=fast; HIP's __fmul_rn /
+// __fadd_rn are header functions compiled under that default and are contracted all the same, so the operators are written
+// out inside the pragma's scope); fp32 division is correctly rounded by default.
 __global__ void __launch_bounds__(256) fedavg_fold_kernel(FoldArgs a, int K, float tot, float* __restrict__ out, int64_t n4)
 {
+#pragma clang fp contract(off)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
         float4 v = reinterpret_cast<const float4*>(a.s[0])[i];
-        float4 acc = {__fmul_rn(v.x, a.n[0]), __fmul_rn(v.y, a.n[0]), __fmul_rn(v.z, a.n[0]), __fmul_rn(v.w, a.n[0])};
+        float4 acc = {v.x * a.n[0], v.y * a.n[0], v.z * a.n[0], v.w * a.n[0]};
         for (int k = 1; k < K; ++k) {
             v = reinterpret_cast<const float4*>(a.s[k])[i];
-            acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, a.n[k]));
-            acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, a.n[k]));
-            acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, a.n[k]));
-            acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, a.n[k]));
+            const float px = v.x * a.n[k], py = v.y * a.n[k], pz = v.z * a.n[k], pw = v.w * a.n[k];
+            acc.x = acc.x + px; acc.y = acc.y + py; acc.z = acc.z + pz; acc.w = acc.w + pw;
         }
-        acc.x = __fdiv_rn(acc.x, tot); acc.y = __fdiv_rn(acc.y, tot); acc.z = __fdiv_rn(acc.z, tot); acc.w = __fdiv_rn(acc.w, tot);
+        acc.x = acc.x / tot; acc.y = acc.y / tot; acc.z = acc.z / tot; acc.w = acc.w / tot;
         reinterpret_cast<float4*>(out)[i] = acc;
     }
 }
 __global__ void fedavg_fold_tail_kernel(FoldArgs a, int K, float tot, float* __restrict__ out, int64_t i0, int64_t n)
 {
+#pragma clang fp contract(off)
     const int64_t i = i0 + threadIdx.x;
     if (i >= n) return;
-    float acc = __fmul_rn(a.s[0][i], a.n[0]);
-    for (int k = 1; k < K; ++k) acc = __fadd_rn(acc, __fmul_rn(a.s[k][i], a.n[k]));
-    out[i] = __fdiv_rn(acc, tot);
+    float acc = a.s[0][i] * a.n[0];
+    for (int k = 1; k < K; ++k) {
+        const float p = a.s[k][i] * a.n[k];
+        acc = acc + p;
+    }
+    out[i] = acc / tot;
 }
 void k_fedavg_fold(const FoldArgs& a, int K, float tot, float* out, int64_t n, hipStream_t s)
 {

@@ -85,11 +85,14 @@ def test_effnet_stage1_step_full_size_training_batch_bf16():
 
 def test_stage1_step_at_the_benchmarked_size_against_the_oracle_with_shared_relu_masks():
     """bs 128 x 2 views x 224x224, C = 5 (what bench.py times).  The stored-golden tests hold 3-6e-3 per gradient tensor
-    there and explain it by ReLU masks: of 6.4e8 ReLU inputs a few hundred lie within fp32 rounding distance of zero and
+    there and explain it by ReLU masks: of 5.9e8 ReLU inputs a few hundred lie within fp32 rounding distance of zero and
     fall differently under the two summation orders.  Here the oracle runs on this host with the ENGINE's masks in its
     backward (tests/helpers.relu_masks_from_engine; its forward and the loss are untouched), the differing positions are
     counted, and what is left -- the backward arithmetic itself at full size -- must agree to 2e-4 of each tensor's max,
-    the bound the 64x64 shared-mask tests hold (tests/test_engine_gpu.py)."""
+    the bound the 64x64 shared-mask tests hold (tests/test_engine_gpu.py).  One tensor is outside that statement by
+    construction: conv1.weight sits below the stem's ReLU and 3x3 max-pool, whose mask / argmax are each side's own (the
+    engine keeps no dense stem activation to hand over), and every one of its 9 408 elements is a 3.2e6-term fp32 sum.  For
+    it the yardstick is the same oracle step in FLOAT64: the engine must be as close to that as the fp32 oracle is."""
     from fedmlp_amd.engine import Engine
     C, B, hw = 5, 128, 224
     torch.set_num_threads(min(32, os.cpu_count() or 8))
@@ -99,8 +102,8 @@ def test_stage1_step_at_the_benchmarked_size_against_the_oracle_with_shared_relu
     y = (torch.rand((B, C), generator=g) < 0.3).float()
     act, neg = [0], [1, 2, 3, 4]
     y[:, 1:] = 0.0
-    net = oracle_net(C, 1037)
-    flat, cnt = spec.state_dict_to_flat("Resnet18", C, net.state_dict())
+    net0 = oracle_net(C, 1037)
+    flat, cnt = spec.state_dict_to_flat("Resnet18", C, net0.state_dict())
     eng = Engine("Resnet18", C, hw, hw, 2 * B)
     try:
         eng.set_state(flat, cnt)
@@ -110,33 +113,61 @@ def test_stage1_step_at_the_benchmarked_size_against_the_oracle_with_shared_relu
         eng.step_stage1(x1.to(eng.device), x2.to(eng.device), y.to(eng.device), [1.0, 0, 0, 0, 0], 1, B, lo)
         got_loss = lo.item()
         gsd = spec.flat_to_state_dict("Resnet18", C, eng.debug_get_grads(), np.zeros(eng.ni, np.int64))
-        t0 = time.perf_counter()
-        glob = copy.deepcopy(net).eval()
-        net.train()
-        with relu_masks_from_engine(eng, 2, B) as rm:
-            _, z1 = net(x1); _, z2 = net(x2)
-            with torch.no_grad():
-                _, g1 = glob(x1); _, g2 = glob(x2)
-            loss, _, _ = R.loss_stage1(z1, z2, g1, g2, y, act, neg, B, 1)
-            loss.backward()
-        oracle_s = time.perf_counter() - t0
+        rm = relu_masks_from_engine(eng, 2, B)
     finally:
         eng.close()
-    worst, errs = ("", 0.0), {}
-    for k, p in net.named_parameters():
-        want = p.grad.numpy()
-        err = float(np.abs(gsd[k] - want).max() / (np.abs(want).max() + 1e-12))
-        errs[k] = err
-        if err > worst[1]:
-            worst = (k, err)
+
+    def oracle_step(dtype):
+        net = copy.deepcopy(net0).to(dtype)
+        glob = copy.deepcopy(net).eval()
+        net.train()
+        a, b, yy = x1.to(dtype), x2.to(dtype), y.to(dtype)
+        rm.calls = rm.flips = 0
+        with rm:
+            _, z1 = net(a); _, z2 = net(b)
+            with torch.no_grad():
+                _, g1 = glob(a); _, g2 = glob(b)
+            loss, _, _ = R.loss_stage1(z1, z2, g1, g2, yy, act, neg, B, 1)
+            loss.backward()
+        return loss.item(), {k: p.grad.double().numpy() for k, p in net.named_parameters()}, int(rm.flips), rm.calls
+
+    t0 = time.perf_counter()
+    loss32, g32, flips, calls = oracle_step(torch.float32)
+    oracle_s = time.perf_counter() - t0
+    errs = {k: float(np.abs(gsd[k] - w).max() / (np.abs(w).max() + 1e-12)) for k, w in g32.items()}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    rest = {k: v for k, v in errs.items() if k != "conv1.weight"}
+    worst_rest = max(rest.items(), key=lambda kv: kv[1])
     n_relu = 2 * B * (64 * 112 * 112 + 4 * 64 * 56 * 56 + 4 * 128 * 28 * 28 + 4 * 256 * 14 * 14 + 4 * 512 * 7 * 7)
-    rep = {"loss": got_loss, "loss_oracle": loss.item(), "loss_rel_err": abs(got_loss - loss.item()) / abs(loss.item()),
-           "relu_inputs": n_relu, "mask_flips": int(rm.flips), "relu_calls": rm.calls,
+    rep = {"loss": got_loss, "loss_oracle": loss32, "loss_rel_err": abs(got_loss - loss32) / abs(loss32),
+           "relu_inputs": n_relu, "mask_flips": flips, "relu_calls": calls,
            "worst_grad_tensor": worst[0], "worst_grad_rel_to_max": worst[1],
-           "median_grad_rel_to_max": float(np.median(list(errs.values()))), "oracle_seconds": round(oracle_s, 1),
+           "worst_below_the_stem": list(worst_rest), "median_grad_rel_to_max": float(np.median(list(errs.values()))),
+           "top5": sorted(errs.items(), key=lambda kv: -kv[1])[:5], "oracle_seconds": round(oracle_s, 1),
            "threads": torch.get_num_threads()}
+    # float64 oracle (same masks handed over): where do the two fp32 implementations stand against it?
+    try:
+        import psutil
+        room = psutil.virtual_memory().available > (110 << 30)
+    except Exception:
+        room = False
+    if room:
+        t0 = time.perf_counter()
+        loss64, g64, _, _ = oracle_step(torch.float64)
+        e_eng = {k: float(np.abs(gsd[k] - w).max() / (np.abs(w).max() + 1e-300)) for k, w in g64.items()}
+        e_o32 = {k: float(np.abs(g32[k] - w).max() / (np.abs(w).max() + 1e-300)) for k, w in g64.items()}
+        rep["float64"] = {"loss": loss64, "seconds": round(time.perf_counter() - t0, 1),
+                          "conv1.weight": {"engine_vs_f64": e_eng["conv1.weight"], "oracle_f32_vs_f64": e_o32["conv1.weight"]},
+                          "worst_engine_vs_f64": list(max(e_eng.items(), key=lambda kv: kv[1])),
+                          "worst_oracle_f32_vs_f64": list(max(e_o32.items(), key=lambda kv: kv[1])),
+                          "median_engine_vs_f64": float(np.median(list(e_eng.values()))),
+                          "median_oracle_f32_vs_f64": float(np.median(list(e_o32.values())))}
     _dump(rep, "parity_step_full_shared_masks.json")
     assert rep["loss_rel_err"] < 1e-5, rep
-    assert rm.calls == 2 * 17
-    assert rep["mask_flips"] <= 2e-5 * n_relu, rep          # a few thousand of 6.4e8 (measured: see profiles/r04)
-    assert worst[1] < 2e-4, rep
+    assert calls == 2 * 17
+    assert flips <= 2e-6 * n_relu, rep                      # measured: 266 of 5.9e8
+    assert worst_rest[1] < 2e-4, rep                        # measured: 1.7e-5 (bn1.bias), median 3.6e-6
+    assert errs["conv1.weight"] < 3e-3, rep                 # measured: 1.1e-3 (own stem mask / pool argmax on each side)
+    if room:
+        f = rep["float64"]["conv1.weight"]
+        assert f["engine_vs_f64"] < 3.0 * f["oracle_f32_vs_f64"] + 2e-4, rep
