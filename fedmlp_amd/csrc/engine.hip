@@ -71,6 +71,7 @@ struct Conv {
     DgradClass cls[4];
     int bn;                   // index of the BatchNorm that follows
     long long wb_off = -1, wbt_off = -1;   // bf16 shadow of a 1x1 conv's weights [cout_p][cin_p] / transposed (bf16 mode)
+    bool last_pro = false;    // the last conv_fwd of this conv carried an operand prologue (decides the bf16 statistics layout)
     double macs_per_img;      // algorithmic MACs (real k, real cin)
     float* y = nullptr;       // raw conv output (train) [max_images][hout][wout][cout]
 };
@@ -808,10 +809,12 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
               const float* scale, const float* shift, const float* res, int relu, float* stats,
               const Prologue* pro = nullptr)
 {
-    const Conv& c = e->convs[ci];
+    Conv& c = e->convs[ci];
     const bool stem16 = e->precision && c.cin == 3;     // `x` is ignored: the operand is the im2col matrix
     if (e->precision && (c.k == 1 || stem16)) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
         PwParams q{};
+        q.zeros = e->zeros;
+        c.last_pro = pro && pro->gate;
         q.W = shadow_of(e, S) + c.wb_off;
         q.X = reinterpret_cast<const bf16*>(stem16 ? e->stem_col : x); q.Y = reinterpret_cast<bf16*>(y);
         q.M = c.cout_p; q.K = stem16 ? c.Kw : c.cin_p;
@@ -860,7 +863,7 @@ int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
 {
     const Conv& c = e->convs[ci];
     if (e->precision && (c.k == 1 || c.cin == 3))
-        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p);
+        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro);
     const int bn = igemm_tile_n(c.cout_p);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
@@ -873,6 +876,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
     Conv& c = e->convs[ci];
     if (e->precision && c.k == 1) {          // dX = dY W: the same streaming kernel with the transposed bf16 shadow
         PwParams q{};
+        q.zeros = e->zeros;
         q.W = shadow_of(e, S) + c.wbt_off;
         q.X = reinterpret_cast<const bf16*>(dy); q.Y = reinterpret_cast<bf16*>(dx);
         q.M = c.cin_p; q.K = c.cout_p;

@@ -221,10 +221,11 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
                 const uint4* A = As + (size_t)(kb + k) * RT * 64 + lane;
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    if (r >= nrt) break;                     // row tiles past M
-                    const uint4 a = A[r * 64];
+                    if (r < nrt) {                           // row tiles past M (no `break`: a loop with an early exit is fully
+                        const uint4 a = A[r * 64];           // unrolled only up to 8 trips, beyond that acc[] lands in scratch)
 #pragma unroll
-                    for (int g = 0; g < P; ++g) acc[r][g] = mfma32(a, b[g][k], acc[r][g]);
+                        for (int g = 0; g < P; ++g) acc[r][g] = mfma32(a, b[g][k], acc[r][g]);
+                    }
                 }
             }
         }
@@ -242,10 +243,11 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
             }
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                if (r >= nrt) break;
-                const uint2 a = At[r * 64 + lane];
+                if (r < nrt) {
+                    const uint2 a = At[r * 64 + lane];
 #pragma unroll
-                for (int g = 0; g < P; ++g) acc[r][g] = mfma16(a, b4[g], acc[r][g]);
+                    for (int g = 0; g < P; ++g) acc[r][g] = mfma16(a, b4[g], acc[r][g]);
+                }
             }
         }
         // ---- epilogue of the iteration: acc[r][g][q] = D[channel(r, 4 lg + q)][pixel pix0 + 16 g + li] -----
@@ -271,9 +273,10 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
             };
 #pragma unroll
             for (int u = 0; u < RT / 2; ++u) {
-                if (u >= npairs) break;
-                const int m = m0 + 32 * u + 8 * lg;
-                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m, 2 * u), finish(acc[2 * u + 1][g], m + 4, 2 * u + 1));
+                if (u < npairs) {
+                    const int m = m0 + 32 * u + 8 * lg;
+                    *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][g], m, 2 * u), finish(acc[2 * u + 1][g], m + 4, 2 * u + 1));
+                }
             }
             if (nrt & 1) {
                 const int r = nrt - 1;
@@ -320,6 +323,201 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
             st[p.M + m0 + tid] = v;
         }
     }
+}
+
+// =====================================================================================================
+// LDS-tiled GEMM form of the same convolution, used for the DATA GRADIENTS with K >= 64 (expand / project / head convs of the
+// low-resolution blocks: few pixels, long K; launch_pw_gemm says what was measured for the forward forms).  The streaming kernel
+// above keeps a whole 64-channel weight slice in LDS (86-147 KB, one block per CU) and every wave waits out the full load
+// latency of each of its pixel groups.  Here a block owns a tile of
+// BP pixels x BM channels and walks K in 64-k stages: both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4,
+// a whole 128-B line per row and stage, no registers), NS stages deep, counted s_waitcnt vmcnt + one raw s_barrier per
+// stage (the structure of igemm.hip).  The LDS image is lane-linear; the bank swizzle slot = chunk ^ ((row >> 1) & 7) is
+// applied on the DMA's SOURCE address and on the fragment reads (conflict-free ds_read_b128, brute-force checked).  The four
+// waves split the PIXELS (each reads its own pixel rows once, all of them read every weight row), so the accumulators
+// come out exactly as in the streaming kernel: lane (li, lg) holds 4 (paired tiles: 8) consecutive channels of pixel li,
+// one 8- / 16-B NHWC store, BN partial sums from the fp32 accumulators.  Chunks past K and rows past M / past the group's
+// pixels are DMA'd from a zero page.
+template <int BM, int BP, int NS, int MODE>
+__global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwParams p)
+{
+#if __HIP_DEVICE_COMPILE__
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int FR = BM / 16, FC = BP / 64;               // MFMA tiles per wave: all channel tiles x its pixel tiles
+    constexpr int STG_W = BM * 128, STG_X = BP * 128;       // bytes per stage (64 k x 2 B per row)
+    constexpr int GW = BM / 32, GX = BP / 32;               // DMA instructions per wave and stage (8 rows each)
+    constexpr int PER = GW + GX, D = NS - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ws = smem;
+    unsigned char* Xs = smem + NS * STG_W;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int K = p.K;
+    int bx, by;                                             // M-tile, (group, pixel tile): the M-tiles of one pixel tile on ONE XCD
+    {
+        const int id = blockIdx.x, nby = p.nblk * p.groups, tm = p.tiles_m;
+        const int full = p.xcd ? (nby >> 3) << 3 : 0;
+        if (id < full * tm) {
+            const int q = id / (8 * tm), r = id - q * 8 * tm;
+            bx = r >> 3;
+            by = q * 8 + (r & 7);
+        } else {
+            const int r = id - full * tm;
+            by = full + r / tm;
+            bx = r - (r / tm) * tm;
+        }
+    }
+    const int m0 = bx * BM;
+    const int grp = by / p.nblk, tn = by - grp * p.nblk;
+    const int n0 = tn * BP;
+    const size_t gbase = (size_t)grp * p.npix;
+    const int nrt = min(FR, (p.M - m0) >> 4);
+    const int npairs = nrt >> 1;
+    const int nst = (K + 63) >> 6;
+
+    // ---- LDS-DMA source state: lane = (row of an 8-row group, 16-B slot); slot s of row rho holds chunk s ^ ((rho >> 1) & 7)
+    const int drow = lane >> 3, dslot = lane & 7;
+    const bf16* wsrc[GW];
+    const bf16* xsrc[GX];
+    int wk[GW], xk[GX];                                     // element offset of this lane's chunk inside a stage, or -1 (zero page)
+#pragma unroll
+    for (int q = 0; q < GW; ++q) {
+        const int rho = 8 * (wave * GW + q) + drow, r = rho >> 4;
+        const bool ok = r < nrt;
+        wsrc[q] = p.W + (size_t)(ok ? m0 + tile_row_to_channel(r, rho & 15, npairs) : 0) * K;
+        wk[q] = ok ? (dslot ^ ((rho >> 1) & 7)) * 8 : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < GX; ++q) {
+        const int rho = 8 * (wave * GX + q) + drow;
+        const bool ok = n0 + rho < p.npix;
+        xsrc[q] = p.X + (gbase + (ok ? n0 + rho : 0)) * (size_t)K;
+        xk[q] = ok ? (dslot ^ ((rho >> 1) & 7)) * 8 : -1;
+    }
+    const bf16* zeros = reinterpret_cast<const bf16*>(p.zeros);
+    auto issue = [&](int s) {
+        const int slot = s % NS, k0 = s * 64;
+#pragma unroll
+        for (int q = 0; q < GW; ++q) {
+            const int k = k0 + wk[q];
+            __builtin_amdgcn_global_load_lds((wk[q] >= 0 && k < K) ? wsrc[q] + k : zeros,
+                                             (lds_void*)(Ws + slot * STG_W + (wave * GW + q) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < GX; ++q) {
+            const int k = k0 + xk[q];
+            __builtin_amdgcn_global_load_lds((xk[q] >= 0 && k < K) ? xsrc[q] + k : zeros,
+                                             (lds_void*)(Xs + slot * STG_X + (wave * GX + q) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FR][FC];
+#pragma unroll
+    for (int r = 0; r < FR; ++r)
+#pragma unroll
+        for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+#pragma unroll
+    for (int d = 1; d < D; ++d)
+        if (d < nst) issue(d);
+    const int fsw = (li >> 1) & 7;
+    const unsigned char* arow = Ws + li * 128;
+    const unsigned char* brow = Xs + (wave * (BP / 4) + li) * 128;
+    for (int s = 0; s < nst; ++s) {
+        const int younger = min(D - 1, nst - 1 - s);        // my DMA of stage s has landed once only younger stages are outstanding
+        if (D >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (D >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // everyone's stage-s rows landed; everyone finished reading stage s - 1
+        asm volatile("" ::: "memory");
+        if (s + D < nst) issue(s + D);                      // refill the slot stage s - 1 just vacated
+        const int slot = s % NS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (s * 64 + 32 * h >= K) break;                // K % 64 <= 32: the stage's second half is all zero page
+            const int so = ((4 * h + lg) ^ fsw) * 16;
+            uint4 b[FC];
+#pragma unroll
+            for (int c = 0; c < FC; ++c) b[c] = *reinterpret_cast<const uint4*>(brow + slot * STG_X + c * 16 * 128 + so);
+#pragma unroll
+            for (int r = 0; r < FR; ++r) {
+                if (r < nrt) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(arow + slot * STG_W + r * 16 * 128 + so);
+#pragma unroll
+                    for (int c = 0; c < FC; ++c) acc[r][c] = mfma32(a, b[c], acc[r][c]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: acc[r][c][q] = D[channel(r, 4 lg + q)][pixel n0 + wave BP/4 + 16 c + li] --------------------------------
+    if constexpr (MODE == 1) {
+        __syncthreads();                                    // every wave is done with the stages: reuse the LDS
+        float* red = reinterpret_cast<float*>(smem);       // [4 waves][BM][2]
+#pragma unroll
+        for (int r = 0; r < FR; ++r) {
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < FC; ++c) { s1 += acc[r][c]; s2 += acc[r][c] * acc[r][c]; }     // padded pixels are exact zeros
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u = s1[q], v = s2[q];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    u += __shfl_xor(u, d);
+                    v += __shfl_xor(v, d);
+                }
+                if (li == 0 && r < nrt) {
+                    const int ml = tile_row_to_channel(r, 4 * lg + q, npairs);
+                    red[(wave * BM + ml) * 2 + 0] = u;
+                    red[(wave * BM + ml) * 2 + 1] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * nrt) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                u += red[(w * BM + tid) * 2 + 0];
+                v += red[(w * BM + tid) * 2 + 1];
+            }
+            float* st = p.stats + (size_t)(grp * p.nblk + tn) * 2 * p.M;
+            st[m0 + tid] = u;
+            st[p.M + m0 + tid] = v;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < FC; ++c) {
+        const int px = n0 + wave * (BP / 4) + 16 * c + li;
+        if (px >= p.npix) continue;
+        const size_t o = (gbase + px) * (size_t)p.M;
+        auto finish = [&](f32x4 v, int m) {
+            if constexpr (MODE == 2) v = v * ld4(p.scale + m) + ld4(p.shift + m);
+            if (p.res) v += ld4(p.res + o + m);
+            if constexpr (MODE == 2) { if (p.act == 2) v = swish4(v); }
+            return v;
+        };
+#pragma unroll
+        for (int u = 0; u < FR / 2; ++u) {
+            if (u < npairs) {
+                const int m = m0 + 32 * u + 8 * lg;
+                *reinterpret_cast<uint4*>(p.Y + o + m) = pack8(finish(acc[2 * u][c], m), finish(acc[2 * u + 1][c], m + 4));
+            }
+        }
+        if (nrt & 1) {
+            const int r = nrt - 1;
+            const int m = m0 + 16 * r + 4 * lg;
+            f32x4 v = acc[0][c];
+#pragma unroll
+            for (int rr = 1; rr < FR; ++rr)
+                if (rr == r) v = acc[rr][c];                // static register index
+            *reinterpret_cast<uint2*>(p.Y + o + m) = pack4(finish(v, m));
+        }
+    }
+#endif
 }
 
 // =====================================================================================================
@@ -1003,11 +1201,17 @@ __global__ void cast_weights_kernel(const float* __restrict__ state, bf16* __res
 // ---- launchers ------------------------------------------------------------------------------------------
 // row tiles per block: 4 (64 channels).  K > 640: the slice is 86-147 KB -- one 8-wave block per CU (FM_PW_W8=0: two
 // 4-wave blocks of 32-channel tiles, the round-2 first form)
+bool pw_gemm_takes(int M, int K, bool pro, bool plain);
+int pw_gemm_blocks(int npix_per_group);
 static int pw_w8() { static const int v = fm_tune("FM_PW_W8", 1); return v; }
-static int pw_rt(int K) { return (K <= 640 || (pw_w8() && K <= 1152)) ? 4 : 2; }     // K = 1280 (head dgrad): 164 KB, stays 32-channel
+static int pw_rt(int M, int K)
+{
+    (void)M;
+    return (K <= 640 || (pw_w8() && K <= 1152)) ? 4 : 2;          // K = 1280 (head dgrad): 164 KB, stays 32-channel
+}
 static int pw_ppb(int npix_per_group, int groups, int M, int K)
 {
-    const int MT = 16 * pw_rt(K);
+    const int MT = 16 * pw_rt(M, K);
     const long long tilesM = (M + MT - 1) / MT;
     const long long total = (long long)npix_per_group * groups * tilesM;
     long long ppb = total / 2048;                               // ~2048 blocks when there is enough work
@@ -1016,9 +1220,10 @@ static int pw_ppb(int npix_per_group, int groups, int M, int K)
     ppb = std::min<long long>(std::max<long long>(ppb, 128), 4096);
     return (int)((ppb + 31) / 32 * 32);
 }
-int pw_tiles_m(int M, int K) { return (M + 16 * pw_rt(K) - 1) / (16 * pw_rt(K)); }
-int pw_blocks(int npix_per_group, int groups, int M, int K)
+int pw_tiles_m(int M, int K) { return (M + 16 * pw_rt(M, K) - 1) / (16 * pw_rt(M, K)); }
+int pw_blocks(int npix_per_group, int groups, int M, int K, bool pro)
 {
+    (void)pro;                                   // (statistics come from the streaming kernel only)
     const int ppb = pw_ppb(npix_per_group, groups, M, K);
     return (npix_per_group + ppb - 1) / ppb;
 }
@@ -1043,9 +1248,54 @@ static void pw_launch_t(const PwParams& p, bool pro, dim3 grid, size_t lds, hipS
     else if (p.scale) pw_launch_m<RT, P, KB, NW, 2>(p, pro, grid, lds, s);     // eval forward: folded BN (+ Swish, residual)
     else pw_launch_m<RT, P, KB, NW, 0>(p, pro, grid, lds, s);                  // data gradient (+ residual)
 }
+// ---- LDS-tiled GEMM form (pw_gemm_bf16_kernel): K >= 64 without an operand prologue --------------------------------------
+static int pw_gemm_on() { static const int v = fm_tune("FM_PW_GEMM", 1); return v; }
+static int pw_gemm_bm(int M) { return M <= 64 ? 64 : 128; }
+// Taken for the plain-store form only (the data gradients: no statistics, no affine).  Measured inside the bf16 bs-512 step
+// (one stream, tools/op_profile.py): expand / project / head data gradients 2.24 -> 1.80 ms per step; the train (statistics) and
+// eval (affine + Swish) forwards of the K = 80 ... 192 expand convs were SLOWER in this form (2.69 -> 3.19 / 2.76 -> 2.96 ms: a
+// 128-pixel tile is two stages of K there, so the per-tile statistics fold and epilogue loads weigh as much as its main loop;
+// the streaming kernel folds its statistics once per ~1 000 pixels) and the K = 672 / 1152 project forwards did not move.
+bool pw_gemm_takes(int M, int K, bool pro, bool plain)
+{
+    return pw_gemm_on() && plain && !pro && K >= 64 && (M & 15) == 0 && (K & 15) == 0;
+}
+constexpr int PW_GEMM_BP = 128;
+int pw_gemm_blocks(int npix_per_group) { return (npix_per_group + PW_GEMM_BP - 1) / PW_GEMM_BP; }
+template <int BM, int NS, int MODE>
+static void pw_gemm_launch_m(const PwParams& p, dim3 grid, hipStream_t s)
+{
+    constexpr int lds = NS * (BM + PW_GEMM_BP) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<BM, PW_GEMM_BP, NS, MODE>), lds, "pw_gemm_bf16_kernel");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pw_gemm_bf16_kernel<BM, PW_GEMM_BP, NS, MODE>), grid, dim3(256), lds, s, p);
+}
+template <int BM, int NS>
+static void pw_gemm_launch_t(const PwParams& p, dim3 grid, hipStream_t s)
+{
+    pw_gemm_launch_m<BM, NS, 0>(p, grid, s);      // (MODE 1 / 2 of the template are the measured-and-not-used forward forms)
+}
+static void launch_pw_gemm(PwParams p, hipStream_t s)
+{
+    const int BM = pw_gemm_bm(p.M);
+    p.ppb = PW_GEMM_BP;
+    p.nblk = pw_gemm_blocks(p.npix);
+    p.tiles_m = (p.M + BM - 1) / BM;
+    static const int xcd = fm_tune("FM_PW_XCD", 1);
+    p.xcd = xcd;
+    const dim3 grid(p.tiles_m * p.nblk * p.groups);
+    // two stages (64 / 48 KB: two / three blocks per CU); three stages = one block per CU was 30-50 % slower on every layer
+    if (BM == 64) pw_gemm_launch_t<64, 2>(p, grid, s);
+    else pw_gemm_launch_t<128, 2>(p, grid, s);
+}
+
 void launch_pw_conv(PwParams p, hipStream_t s)
 {
-    const int RT = pw_rt(p.K);
+    if (pw_gemm_takes(p.M, p.K, p.gate != nullptr, !p.stats && !p.scale)) { launch_pw_gemm(p, s); return; }
+    const int RT = pw_rt(p.M, p.K);
     const int MT = 16 * RT;
     p.ppb = pw_ppb(p.npix, p.groups, p.M, p.K);
     p.nblk = (p.npix + p.ppb - 1) / p.ppb;

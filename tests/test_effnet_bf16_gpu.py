@@ -81,12 +81,20 @@ def _engine_weight(e, ci, info):
     return W
 
 
-@pytest.mark.parametrize("which", ["small_k", "tail_k", "big_k", "head"])
+@pytest.mark.parametrize("which", ["small_k", "tail_k", "big_k", "head", "k80_m480", "k112_m672", "k672_m112", "k480_m80",
+                                   "k240_m48", "k192_m1152", "k32_m144", "k48_m240"])
 def test_pw_conv_fwd_dgrad_wgrad_vs_fp32_on_rounded_operands(eng, which):
     _load(eng)
     convs = _pw_convs(eng)
     pick = {"small_k": lambda i: i["cin_p"] == 16, "tail_k": lambda i: i["cin_p"] == 144 and i["cout_p"] == 32,
-            "big_k": lambda i: i["cin_p"] == 1152 and i["cout_p"] == 320, "head": lambda i: i["cout_p"] == 1280}[which]
+            "big_k": lambda i: i["cin_p"] == 1152 and i["cout_p"] == 320, "head": lambda i: i["cout_p"] == 1280,
+            # the LDS-tiled form's K tails (64 k per stage: K % 64 = 16 / 48 / 32 / 0) and M tails (80 = 5, 48 = 3 row tiles)
+            "k80_m480": lambda i: i["cin_p"] == 80 and i["cout_p"] == 480, "k112_m672": lambda i: i["cin_p"] == 112 and i["cout_p"] == 672,
+            "k672_m112": lambda i: i["cin_p"] == 672 and i["cout_p"] == 112, "k480_m80": lambda i: i["cin_p"] == 480 and i["cout_p"] == 80,
+            # one M-tile of all 9 row tiles / two tiles of 8 + 7 (the early expand convs write whole NHWC rows per wave)
+            "k32_m144": lambda i: i["cin_p"] == 32 and i["cout_p"] == 144, "k48_m240": lambda i: i["cin_p"] == 48 and i["cout_p"] == 240,
+            "k240_m48": lambda i: i["cin_p"] == 240 and i["cout_p"] == 48, "k192_m1152": lambda i: i["cin_p"] == 192 and i["cout_p"] == 1152,
+            }[which]
     ci, info = next((c, i) for c, i in convs if pick(i))
     M, K, h, w = info["cout_p"], info["cin_p"], info["hout"], info["wout"]
     imgs, groups = 6, 2
