@@ -18,7 +18,13 @@ out = {"config": {k: getattr(F, k) for k in ("C", "N_CL", "N_LOCAL", "HW", "BS",
                                                "LABEL_NOISE")},
        "prevalence": float(test[2].mean()), "runs": {}}
 path = os.path.join(ROOT, "tests", "golden", "map_study_oracle.json")
+if os.path.exists(path):                          # resume: seeds already in the fixture are kept (same config only)
+    old = json.load(open(path))
+    if old.get("config") == out["config"]:
+        out["runs"] = old["runs"]
 for s in F.SEEDS[:n]:
+    if str(s) in out["runs"]:
+        continue
     t0 = time.time()
     m, a = F.run_oracle(s, test)
     out["runs"][str(s)] = {"mAP": m, "auc": a}
