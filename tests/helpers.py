@@ -205,6 +205,7 @@ def grad_errors(gsd, gold):
         worst[k] = float(max(e_norm, e_sum, e_head))
     k_bad = max(worst, key=worst.get)
     grad_errors.p90 = float(np.percentile(list(worst.values()), 90))          # (read by the bf16 tests: stated 90th percentile)
+    grad_errors.all = dict(worst)
     # the ten worst tensors with their size and their norm relative to the median tensor's (for the parity records)
     grad_errors.top = [[k, round(v, 5), int(np.asarray(gsd[k]).size), round(gold[k]["norm"] / med_norm, 5)]
                        for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:10]]

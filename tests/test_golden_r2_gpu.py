@@ -188,7 +188,7 @@ def _replay_two_stage(name, tol, tol_after_split, delta=(2.5e-2, 6e-2), model="R
         locs[0]._bind(netglob, "image_aug_1").stochastic = False
     tao, Prototype = [0] * C, []
     neg_lists, act_lists = g["neg_lists"], g["act_lists"]
-    keys = ("loss", "norm", "bn_bias_norm", "proto", "logits", "t_count")
+    keys = ("loss", "norm", "bn_bias_norm", "se_bias_norm", "proto", "logits", "t_count")
     rep = {"max": {k: 0.0 for k in keys}, "max_after_split": {k: 0.0 for k in keys}, "picks_differing": 0,
            "picks_total": 0, "split_round": None}
     rep["max"].update(sim=0.0, pick_behind=-1.0)
@@ -201,7 +201,9 @@ def _replay_two_stage(name, tol, tol_after_split, delta=(2.5e-2, 6e-2), model="R
             if "num_batches" in k:
                 assert abs(got[k] - w) < 0.5, k
                 continue
-            kind = "bn_bias_norm" if (k.endswith(".bias") and not k.startswith("fc.")) else "norm"
+            # EfficientNet's squeeze-excite conv biases start at ZERO (their norm after a few dozen Adam steps is a sum of +-lr
+            # steps whose signs follow gradient noise): their own kind, apart from the BatchNorm biases of a conditioned init
+            kind = ("se_bias_norm" if "_se_" in k else "bn_bias_norm") if (k.endswith(".bias") and not k.startswith("fc.")) else "norm"
             cur[kind] = max(cur[kind], abs(got[k] - w) / (abs(w) + 1e-12))
 
     for rnd, r in enumerate(g["rounds"]):

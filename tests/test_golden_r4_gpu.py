@@ -171,3 +171,85 @@ def test_stage1_step_at_the_benchmarked_size_against_the_oracle_with_shared_relu
     if room:
         f = rep["float64"]["conv1.weight"]
         assert f["engine_vs_f64"] < 3.0 * f["oracle_f32_vs_f64"] + 2e-4, rep
+
+
+def _grad_record(grads):
+    """{key: {norm, sum, head, absmax}} of a dict of numpy gradients (the record format of tests/golden/make_golden.py)"""
+    out = {}
+    for k, g in grads.items():
+        g = np.asarray(g, np.float64)
+        out[k] = {"norm": float(np.linalg.norm(g)), "sum": float(g.sum()), "head": [float(v) for v in g.ravel()[:3]],
+                  "absmax": float(np.abs(g).max())}
+    return out
+
+
+# ---- bf16 (BASELINE configs[4]): whose error is it? ------------------------------------------------------------------------
+# The reference never runs reduced precision, so the bf16 tolerance is this build's and has to be defended.  Yardstick: the fp32
+# oracle with a bf16 rounding inserted at exactly the engine's storage points (oracle/efficientnet_ref.py, storage="bf16":
+# activations and their gradients where the engine stores them, bf16 MFMA weight operands) -- an INDEPENDENT implementation of the
+# same storage rule, run on this host.  Three sides on the goldens' own inputs and initial state: the reference trainer's fp32 step
+# (R, the committed golden), the storage-emulating oracle (O) and the engine in bf16 mode (E).  Statement: E is no further from R
+# than O is -- per summary statistic, and on the engine's worst tensor O is off by a comparable amount (that tensor's gradient is
+# ill-conditioned under bf16 storage, whoever implements it).
+@pytest.mark.parametrize("gname", ["effnet_step_bs256.json", "effnet_step.json", "effnet_step_224x64.json"])
+def test_effnet_bf16_deviation_is_the_storage_rule_not_the_engine(gname):
+    from fedmlp_amd.engine import Engine
+    from fedmlp_amd.spec import state_dict_to_flat, flat_to_state_dict
+    from oracle.efficientnet_ref import EfficientNetB0Ref
+    from tests.helpers import grad_errors
+    from tests.synth import synth_arrays
+    g = load_golden(gname)
+    C, N, hw, M = g["C"], g["N"], g["hw"], "Efficient_b0"
+    args = make_args(n_classes=C, n_clients=1, batch_size=g["bs"], seed=g["init_seed"], pretrained=0, model=M, feature_dim=1280)
+    hnet = _init_net(args, g["bn_seed"])
+    targets, x1, x2 = synth_arrays(N, C, hw, g["data_seed"], True)
+    y = targets.copy(); y[:, 1:] = 0.0
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    net = EfficientNetB0Ref(C, storage="bf16")
+    net.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in hnet.state_dict().items()})
+    glob = copy.deepcopy(net).eval()
+    net.train()
+    X1, X2, Y = torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(y)
+    t0 = time.perf_counter()
+    _, z1 = net(X1); _, z2 = net(X2)
+    with torch.no_grad():
+        _, g1 = glob(X1); _, g2 = glob(X2)
+    loss, _, _ = R.loss_stage1(z1, z2, g1, g2, Y, [0], list(range(1, C)), g["bs"], 1)
+    loss.backward()
+    oracle_s = time.perf_counter() - t0
+    o16 = {k: p.grad.numpy() for k, p in net.named_parameters()}
+    ref = g["stage1"]["grads"]
+
+    def summary(got):
+        k_bad, worst, med = grad_errors(got, ref)
+        return {"worst_tensor": k_bad, "worst": worst, "median": med, "p90": grad_errors.p90}, dict(grad_errors.all)
+
+    s_o, e_o = summary(o16)
+    eng = Engine(M, C, hw, hw, 2 * N, precision="bf16")
+    try:
+        eng.stochastic = False
+        flat, cnt = state_dict_to_flat(M, C, hnet.state_dict())
+        eng.set_state(flat, cnt)
+        eng.adam_reset(3e-5)
+        eng.teacher_snapshot()
+        lo = torch.zeros(1, device=eng.device)
+        eng.step_stage1(X1.to(eng.device), X2.to(eng.device), Y.to(eng.device), [1.0] + [0.0] * (C - 1), 1, g["bs"], lo)
+        got = flat_to_state_dict(M, C, eng.debug_get_grads(), np.zeros(eng.ni, np.int64))
+    finally:
+        eng.close()
+    s_e, e_e = summary(got)
+    top = sorted(e_e.items(), key=lambda kv: -kv[1])[:8]
+    rep = {"loss": {"engine_bf16": lo.item(), "oracle_bf16_storage": loss.item(), "reference_fp32": g["stage1"]["loss"]},
+           "engine_vs_reference": s_e, "emulating_oracle_vs_reference": s_o,
+           "engine_worst_tensors": [[k, round(v, 5), round(e_o[k], 5)] for k, v in top],     # [tensor, engine err, oracle err]
+           "oracle_seconds": round(oracle_s, 1)}
+    lr, lref = abs(lo.item() - g["stage1"]["loss"]), abs(loss.item() - g["stage1"]["loss"])
+    rep["loss"]["engine_rel_dev"], rep["loss"]["oracle_rel_dev"] = lr / abs(g["stage1"]["loss"]), lref / abs(g["stage1"]["loss"])
+    _dump(rep, f"parity_effnet_bf16_three_sides_{gname[:-5]}.json")
+    assert lr < 2e-3 * abs(g["stage1"]["loss"]), rep
+    for k in ("median", "p90"):
+        assert s_e[k] <= 1.5 * s_o[k] + 5e-3, (k, rep)
+    # the worst tensor: the independent implementation is off by a comparable amount on it, or the engine is within the general bound
+    kw = s_e["worst_tensor"]
+    assert s_e["worst"] < 0.3 or e_o[kw] > 0.25 * s_e["worst"], rep
+    assert sum(1 for v in e_e.values() if v > 0.3) <= max(1, sum(1 for v in e_o.values() if v > 0.3)), rep
