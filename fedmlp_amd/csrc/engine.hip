@@ -863,7 +863,7 @@ int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
 {
     const Conv& c = e->convs[ci];
     if (e->precision && (c.k == 1 || c.cin == 3))
-        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro);
+        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro, c.hout * c.wout);
     const int bn = igemm_tile_n(c.cout_p);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }

@@ -26,8 +26,9 @@ struct PwParams {
     int tiles_m, xcd;     // set by the launcher: M-tiles of the launch; 1 = XCD-aware block order
     const void* zeros;    // >= 16 B of zeros on the device (DMA source of padded chunks in the LDS-tiled form)
 };
-// nblk the launcher will use (statistics layout); pro = the launch has an operand prologue (PwParams::gate != null)
-int pw_blocks(int npix_per_group, int groups, int M, int K, bool pro = false);
+// nblk the launcher will use (statistics layout); pro = the launch has an operand prologue (PwParams::gate != null),
+// HW = pixels per image (the prologue form of the LDS-tiled kernel needs HW >= 32)
+int pw_blocks(int npix_per_group, int groups, int M, int K, bool pro = false, int HW = 0);
 int pw_tiles_m(int M, int K);       // M-tiles of the launch: the pixel operand (and its prologue) is read once per M-tile
 void launch_pw_conv(PwParams p, hipStream_t s);
 

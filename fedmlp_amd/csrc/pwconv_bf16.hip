@@ -338,7 +338,11 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_bf16_kernel(const PwParams p)
 // come out exactly as in the streaming kernel: lane (li, lg) holds 4 (paired tiles: 8) consecutive channels of pixel li,
 // one 8- / 16-B NHWC store, BN partial sums from the fp32 accumulators.  Chunks past K and rows past M / past the group's
 // pixels are DMA'd from a zero page.
-template <int BM, int BP, int NS, int MODE>
+// PRO: operand prologue of the project convs (PwParams::gate): 1 = Xe = X * gate[img][k] (eval forward), 2 = Xe = swish(X * psc[k]
+// + psh[k]) * gate[img][k] (train forward: BN1 + Swish + squeeze-excite gate; a_s is never written).  The gate rows of the (at most
+// two: HW >= BP) images of the tile ride along as one more DMA per stage ([2][64 k] fp32); psc / psh are staged once per block.  The
+// waves split the pixels, so every operand element is transformed exactly ONCE (the streaming kernel redoes it per 64-channel tile).
+template <int BM, int BP, int NS, int MODE, int PRO = 0>
 __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwParams p)
 {
 #if __HIP_DEVICE_COMPILE__
@@ -346,10 +350,12 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwParams p)
     constexpr int FR = BM / 16, FC = BP / 64;               // MFMA tiles per wave: all channel tiles x its pixel tiles
     constexpr int STG_W = BM * 128, STG_X = BP * 128;       // bytes per stage (64 k x 2 B per row)
     constexpr int GW = BM / 32, GX = BP / 32;               // DMA instructions per wave and stage (8 rows each)
-    constexpr int PER = GW + GX, D = NS - 1;
+    constexpr int PER = GW + GX + (PRO ? 1 : 0), D = NS - 1;   // (+ wave 0..3 each issue the gate DMA: counted alike in every wave)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Ws = smem;
     unsigned char* Xs = smem + NS * STG_W;
+    float* Gs = reinterpret_cast<float*>(smem + NS * (STG_W + STG_X));                 // [NS][4 waves][1 KB: 2 images x 64 k fp32 + the DMA's unused upper half] (PRO)
+    float* Ps = reinterpret_cast<float*>(smem + NS * (STG_W + STG_X) + NS * 4 * 1024); // [2][K] psc, psh (PRO == 2)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -396,8 +402,30 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwParams p)
         xk[q] = ok ? (dslot ^ ((rho >> 1) & 7)) * 8 : -1;
     }
     const bf16* zeros = reinterpret_cast<const bf16*>(p.zeros);
+    // PRO: this WAVE's pixels span at most two images (HW >= BP / 4 is all that needs); lanes 0-31 stage [2][64 k] of their gate rows
+    const float* gsrc = nullptr;
+    int gk = -1, img0w = 0;
+    if constexpr (PRO != 0) {
+        const int pw0 = n0 + wave * (BP / 4);
+        const long long gp0 = (long long)gbase + min(pw0, p.npix - 1), gp1 = (long long)gbase + min(pw0 + BP / 4 - 1, p.npix - 1);
+        img0w = (int)(gp0 / p.HW);
+        const int img1w = (int)(gp1 / p.HW);
+        const int gi = (lane >> 4) & 1;
+        const bool ok = lane < 32 && img0w + gi <= img1w;
+        gsrc = p.gate + (size_t)(img0w + (ok ? gi : 0)) * K;
+        gk = ok ? 4 * (lane & 15) : -1;
+        if constexpr (PRO == 2) {
+            for (int k = tid; k < K; k += 256) { Ps[k] = p.psc[grp * K + k]; Ps[K + k] = p.psh[grp * K + k]; }
+            __syncthreads();
+        }
+    }
     auto issue = [&](int s) {
         const int slot = s % NS, k0 = s * 64;
+        if constexpr (PRO != 0) {
+            const int k = k0 + gk;
+            __builtin_amdgcn_global_load_lds((gk >= 0 && k < K) ? reinterpret_cast<const bf16*>(gsrc + k) : zeros,
+                                             (lds_void*)(Gs + (slot * 4 + wave) * 256), 16, 0, 0);
+        }
 #pragma unroll
         for (int q = 0; q < GW; ++q) {
             const int k = k0 + wk[q];
@@ -423,6 +451,14 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwParams p)
     for (int d = 1; d < D; ++d)
         if (d < nst) issue(d);
     const int fsw = (li >> 1) & 7;
+    int pimg[FC];                                           // PRO: image (0 / 1, relative to the wave's first) and validity of
+    bool pval[FC];                                          // this lane's pixel of each pixel tile
+#pragma unroll
+    for (int c = 0; c < FC; ++c) {
+        const int px = n0 + wave * (BP / 4) + 16 * c + li;
+        pval[c] = px < p.npix;
+        pimg[c] = PRO ? (int)(((long long)gbase + min(px, p.npix - 1)) / p.HW) - img0w : 0;
+    }
     const unsigned char* arow = Ws + li * 128;
     const unsigned char* brow = Xs + (wave * (BP / 4) + li) * 128;
     for (int s = 0; s < nst; ++s) {
@@ -441,6 +477,21 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16_kernel(const PwParams p)
             uint4 b[FC];
 #pragma unroll
             for (int c = 0; c < FC; ++c) b[c] = *reinterpret_cast<const uint4*>(brow + slot * STG_X + c * 16 * 128 + so);
+            if constexpr (PRO != 0) {
+                const int kk = 32 * h + 8 * lg;                                 // k inside the stage of this lane's 8 values
+#pragma unroll
+                for (int c = 0; c < FC; ++c) {
+                    const float* gr = Gs + (slot * 4 + wave) * 256 + pimg[c] * 64 + kk;
+                    f32x4 lo = lo4(b[c]), hi = hi4(b[c]);
+                    if constexpr (PRO == 2) {
+                        const float* ps = Ps + s * 64 + kk;
+                        const bool kv = s * 64 + kk < K;                        // (chunks past K: the zero page must stay zero)
+                        lo = swish4(lo * ld4(ps) + ld4(ps + K)); hi = swish4(hi * ld4(ps + 4) + ld4(ps + K + 4));
+                        if (!kv || !pval[c]) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+                    }
+                    b[c] = pack8(lo * ld4(gr), hi * ld4(gr + 4));
+                }
+            }
 #pragma unroll
             for (int r = 0; r < FR; ++r) {
                 if (r < nrt) {
@@ -1201,7 +1252,7 @@ __global__ void cast_weights_kernel(const float* __restrict__ state, bf16* __res
 // ---- launchers ------------------------------------------------------------------------------------------
 // row tiles per block: 4 (64 channels).  K > 640: the slice is 86-147 KB -- one 8-wave block per CU (FM_PW_W8=0: two
 // 4-wave blocks of 32-channel tiles, the round-2 first form)
-bool pw_gemm_takes(int M, int K, bool pro, bool plain);
+bool pw_gemm_takes(int M, int K, bool pro, bool plain, int HW);
 int pw_gemm_blocks(int npix_per_group);
 static int pw_w8() { static const int v = fm_tune("FM_PW_W8", 1); return v; }
 static int pw_rt(int M, int K)
@@ -1221,9 +1272,9 @@ static int pw_ppb(int npix_per_group, int groups, int M, int K)
     return (int)((ppb + 31) / 32 * 32);
 }
 int pw_tiles_m(int M, int K) { return (M + 16 * pw_rt(M, K) - 1) / (16 * pw_rt(M, K)); }
-int pw_blocks(int npix_per_group, int groups, int M, int K, bool pro)
+int pw_blocks(int npix_per_group, int groups, int M, int K, bool pro, int HW)
 {
-    (void)pro;                                   // (statistics come from the streaming kernel only)
+    if (pro && pw_gemm_takes(M, K, true, false, HW)) return pw_gemm_blocks(npix_per_group);   // train forward of a fused project conv
     const int ppb = pw_ppb(npix_per_group, groups, M, K);
     return (npix_per_group + ppb - 1) / ppb;
 }
@@ -1248,37 +1299,42 @@ static void pw_launch_t(const PwParams& p, bool pro, dim3 grid, size_t lds, hipS
     else if (p.scale) pw_launch_m<RT, P, KB, NW, 2>(p, pro, grid, lds, s);     // eval forward: folded BN (+ Swish, residual)
     else pw_launch_m<RT, P, KB, NW, 0>(p, pro, grid, lds, s);                  // data gradient (+ residual)
 }
-// ---- LDS-tiled GEMM form (pw_gemm_bf16_kernel): K >= 64 without an operand prologue --------------------------------------
+// ---- LDS-tiled GEMM form (pw_gemm_bf16_kernel) ----------------------------------------------------------------------------
 static int pw_gemm_on() { static const int v = fm_tune("FM_PW_GEMM", 1); return v; }
+static int pw_gemm_pro_on() { static const int v = fm_tune("FM_PW_GEMM_PRO", 1); return v; }
 static int pw_gemm_bm(int M) { return M <= 64 ? 64 : 128; }
-// Taken for the plain-store form only (the data gradients: no statistics, no affine).  Measured inside the bf16 bs-512 step
-// (one stream, tools/op_profile.py): expand / project / head data gradients 2.24 -> 1.80 ms per step; the train (statistics) and
-// eval (affine + Swish) forwards of the K = 80 ... 192 expand convs were SLOWER in this form (2.69 -> 3.19 / 2.76 -> 2.96 ms: a
+// Taken for (1) the plain-store form with K >= 64 (the data gradients: no statistics, no affine).  Measured inside the bf16 bs-512
+// step (one stream, tools/op_profile.py): expand / project / head data gradients 2.24 -> 1.80 ms per step; the train (statistics)
+// and eval (affine + Swish) forwards of the K = 80 ... 192 expand convs were SLOWER in this form (2.69 -> 3.19 / 2.76 -> 2.96 ms: a
 // 128-pixel tile is two stages of K there, so the per-tile statistics fold and epilogue loads weigh as much as its main loop;
-// the streaming kernel folds its statistics once per ~1 000 pixels) and the K = 672 / 1152 project forwards did not move.
-bool pw_gemm_takes(int M, int K, bool pro, bool plain)
+// the streaming kernel folds its statistics once per ~1 000 pixels) and the K = 672 / 1152 project forwards did not move;
+// (2) the project convs WITH an operand prologue and K >= 240 (blocks 4-10, M <= 128 = one M-tile): the prologue runs once per
+// element instead of once per 64-channel tile, and a tile is 4-11 stages long.
+static bool pw_gemm_pro_shape(int M, int K)
 {
-    return pw_gemm_on() && plain && !pro && K >= 64 && (M & 15) == 0 && (K & 15) == 0;
+    static const int mink = fm_tune("FM_PW_GEMM_PRO_MINK", 240);
+    return pw_gemm_pro_on() && K >= mink && M <= 128;
+}
+bool pw_gemm_takes(int M, int K, bool pro, bool plain, int HW)
+{
+    if ((M & 15) || (K & 15) || !pw_gemm_on()) return false;
+    return pro ? (pw_gemm_pro_shape(M, K) && HW >= 32) : (plain && K >= 64);     // (a wave's 32 pixels span at most two images)
 }
 constexpr int PW_GEMM_BP = 128;
 int pw_gemm_blocks(int npix_per_group) { return (npix_per_group + PW_GEMM_BP - 1) / PW_GEMM_BP; }
-template <int BM, int NS, int MODE>
+template <int BM, int MODE, int PRO>
 static void pw_gemm_launch_m(const PwParams& p, dim3 grid, hipStream_t s)
 {
-    constexpr int lds = NS * (BM + PW_GEMM_BP) * 128;
+    constexpr int NS = 2;       // two stages (64 / 48 KB: two / three blocks per CU); three = one block per CU was 30-50 % slower
+    const int lds = NS * (BM + PW_GEMM_BP) * 128 + (PRO ? NS * 4 * 1024 : 0) + (PRO == 2 ? 2 * p.K * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<BM, PW_GEMM_BP, NS, MODE>), lds, "pw_gemm_bf16_kernel");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<BM, PW_GEMM_BP, NS, MODE, PRO>), 96 * 1024, "pw_gemm_bf16_kernel");
         attr_done = true;
     }
-    hipLaunchKernelGGL((pw_gemm_bf16_kernel<BM, PW_GEMM_BP, NS, MODE>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((pw_gemm_bf16_kernel<BM, PW_GEMM_BP, NS, MODE, PRO>), grid, dim3(256), lds, s, p);
 }
-template <int BM, int NS>
-static void pw_gemm_launch_t(const PwParams& p, dim3 grid, hipStream_t s)
-{
-    pw_gemm_launch_m<BM, NS, 0>(p, grid, s);      // (MODE 1 / 2 of the template are the measured-and-not-used forward forms)
-}
-static void launch_pw_gemm(PwParams p, hipStream_t s)
+static bool launch_pw_gemm(PwParams p, hipStream_t s)
 {
     const int BM = pw_gemm_bm(p.M);
     p.ppb = PW_GEMM_BP;
@@ -1287,14 +1343,24 @@ static void launch_pw_gemm(PwParams p, hipStream_t s)
     static const int xcd = fm_tune("FM_PW_XCD", 1);
     p.xcd = xcd;
     const dim3 grid(p.tiles_m * p.nblk * p.groups);
-    // two stages (64 / 48 KB: two / three blocks per CU); three stages = one block per CU was 30-50 % slower on every layer
-    if (BM == 64) pw_gemm_launch_t<64, 2>(p, grid, s);
-    else pw_gemm_launch_t<128, 2>(p, grid, s);
+    if (!p.gate) {                                              // data gradients
+        if (BM == 64) pw_gemm_launch_m<64, 0, 0>(p, grid, s); else pw_gemm_launch_m<128, 0, 0>(p, grid, s);
+        return true;
+    }
+    // the engine uses <1, 2> (train forward of a fused project conv: statistics + BN1 / Swish / gate prologue) and <2, 1> (eval
+    // forward: folded BN2 + gate); the kernel-level tests also run the plain-store forms
+#define PW_GEMM_PRO(MODE, PRO)                                                                              \
+    do { if (BM == 64) pw_gemm_launch_m<64, MODE, PRO>(p, grid, s); else pw_gemm_launch_m<128, MODE, PRO>(p, grid, s); } while (0)
+    if (p.stats && p.scale) return false;
+    if (p.psc) { if (p.stats) PW_GEMM_PRO(1, 2); else if (p.scale) PW_GEMM_PRO(2, 2); else PW_GEMM_PRO(0, 2); }
+    else { if (p.stats) PW_GEMM_PRO(1, 1); else if (p.scale) PW_GEMM_PRO(2, 1); else PW_GEMM_PRO(0, 1); }
+#undef PW_GEMM_PRO
+    return true;
 }
 
 void launch_pw_conv(PwParams p, hipStream_t s)
 {
-    if (pw_gemm_takes(p.M, p.K, p.gate != nullptr, !p.stats && !p.scale)) { launch_pw_gemm(p, s); return; }
+    if (pw_gemm_takes(p.M, p.K, p.gate != nullptr, !p.stats && !p.scale, p.HW) && launch_pw_gemm(p, s)) return;
     const int RT = pw_rt(p.M, p.K);
     const int MT = 16 * RT;
     p.ppb = pw_ppb(p.npix, p.groups, p.M, p.K);

@@ -170,6 +170,48 @@ def test_pw_prologue_gate_matches_materialised_operand(eng):
         assert err < 5e-3, (affine, err)
 
 
+@pytest.mark.parametrize("shape", [(240, 48), (480, 80), (672, 112)])
+def test_pw_prologue_in_the_lds_tiled_form(shape):
+    """The project convs with K >= 240 (blocks 4-10) take their operand prologue inside pw_gemm_bf16_kernel: gate rows by
+    LDS-DMA per stage, BN1 + Swish on the fragments, every element transformed once.  A 128 x 128 input gives 16 x 16 /
+    8 x 8 maps (tiles that span two images, a partial last tile per group); output AND the train form's BN partial sums
+    against the same arithmetic in torch on the bf16 operand."""
+    from fedmlp_amd.engine import Engine
+    e = Engine("Efficient_b0", C_, 128, 128, 8, precision="bf16")
+    try:
+        e.stochastic = False
+        _load(e)
+        K, M = shape
+        ci, info = next((c, i) for c, i in _pw_convs(e) if i["cin_p"] == K and i["cout_p"] == M)
+        h, w = info["hout"], info["wout"]
+        imgs, groups = 6, 2
+        npix = imgs * h * w
+        g = torch.Generator().manual_seed(K)
+        x = torch.randn((npix, K), generator=g).to(torch.bfloat16)
+        sc = torch.rand((groups, K), generator=g) + 0.5
+        sh = torch.randn((groups, K), generator=g) * 0.3
+        gate = torch.rand((imgs, K), generator=g)
+        W = torch.from_numpy(_engine_weight(e, ci, info)).to(torch.bfloat16).float()
+        dev = e.device
+        v = x.float().view(groups, -1, K) * sc[:, None, :] + sh[:, None, :]
+        xa = ((v * torch.sigmoid(v)).view(imgs, h * w, K) * gate[:, None, :]).reshape(npix, K).to(torch.bfloat16).float()
+        xg = (x.float().view(imgs, h * w, K) * gate[:, None, :]).reshape(npix, K).to(torch.bfloat16).float()
+        for affine, xe in ((True, xa), (False, xg)):
+            out = torch.empty((npix, M), dtype=torch.bfloat16, device=dev)
+            stats = torch.zeros((groups, 2, M), device=dev)
+            e.debug_pw(0, ci, x.to(dev), None, out, imgs, groups, psc=sc.to(dev) if affine else None,
+                       psh=sh.to(dev) if affine else None, gate=gate.to(dev), stats=stats)
+            want = xe @ W.t()
+            err = (out.float().cpu() - want).abs().max() / want.abs().max()
+            assert err < 1.2e-2, (shape, affine, err)
+            wg = want.view(groups, -1, M)
+            tol = 2e-2 * float(wg.abs().sum(1).max()) / np.sqrt(wg.shape[1])       # operands re-rounded after a fast exp / rcp
+            np.testing.assert_allclose(stats[:, 0].cpu().numpy(), wg.sum(1).numpy(), rtol=2e-2, atol=tol)
+            np.testing.assert_allclose(stats[:, 1].cpu().numpy(), (wg * wg).sum(1).numpy(), rtol=2e-2)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("shape", [(32, 16), (96, 32), (144, 32), (144, 48), (240, 48)])
 def test_fused_project_backward_vs_fp32_on_rounded_operands(shape):
     """pw_proj_bwd_kernel (blocks 0-4): d a_s = bf16(d y_p W) formed on the matrix pipe in both phases; phase 0 = the five
