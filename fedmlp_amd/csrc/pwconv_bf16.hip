@@ -1271,7 +1271,13 @@ static int pw_ppb(int npix_per_group, int groups, int M, int K)
     ppb = std::min<long long>(std::max<long long>(ppb, 128), 4096);
     return (int)((ppb + 31) / 32 * 32);
 }
-int pw_tiles_m(int M, int K) { return (M + 16 * pw_rt(M, K) - 1) / (16 * pw_rt(M, K)); }
+static bool pw_gemm_pro_shape(int M, int K);
+// M-tiles of a launch WITH an operand prologue (what the engine asks before it fuses the squeeze-excite gate into a project conv)
+int pw_tiles_m(int M, int K)
+{
+    if (pw_gemm_pro_shape(M, K)) return (M + 127) / 128;
+    return (M + 16 * pw_rt(M, K) - 1) / (16 * pw_rt(M, K));
+}
 int pw_blocks(int npix_per_group, int groups, int M, int K, bool pro, int HW)
 {
     if (pro && pw_gemm_takes(M, K, true, false, HW)) return pw_gemm_blocks(npix_per_group);   // train forward of a fused project conv
@@ -1313,7 +1319,10 @@ static int pw_gemm_bm(int M) { return M <= 64 ? 64 : 128; }
 static bool pw_gemm_pro_shape(int M, int K)
 {
     static const int mink = fm_tune("FM_PW_GEMM_PRO_MINK", 240);
-    return pw_gemm_pro_on() && K >= mink && M <= 128;
+    // (256 = blocks 11-14, M = 192, as two 128-channel tiles with the gate fused instead of a materialised a_s: measured slower,
+    // project forward 2.52 -> 2.85 ms and its weight gradient 1.59 -> 1.84 ms per step against 0.16 ms of se_scale saved)
+    static const int maxm = fm_tune("FM_PW_GEMM_PRO_MAXM", 128);
+    return pw_gemm_pro_on() && K >= mink && M <= maxm;
 }
 bool pw_gemm_takes(int M, int K, bool pro, bool plain, int HW)
 {
