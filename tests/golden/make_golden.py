@@ -239,10 +239,13 @@ def g_train_traj(out):
     pos, neg = class_lists(ds.targets, C)
     users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
     rs = np.random.RandomState(101)
-    netglob = build_net(C, 1037)
+    # conditioned init (round 4): a non-trivial BatchNorm affine like the other trajectory goldens.  With the default beta = 0
+    # the first Adam steps move every bias by +-lr*sign(g), and the norms of those rounding-decided biases were only
+    # reproducible to 5e-2 by ANY second implementation (the oracle's own sensitivity, tests/golden/conditioning.json)
+    netglob = perturb_bn(build_net(C, 1037), 76)
     locals_ = [LT.LocalUpdate(args, i, deepcopy(ds), users[i], pos, neg, active_class_list=[i])
                for i in range(n_cl)]
-    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": 11, "init_seed": 1037,
+    rec = {"C": C, "n_clients": n_cl, "N": N, "hw": hw, "data_seed": 11, "init_seed": 1037, "bn_seed": 76,
            "bs": 32, "lr": args.base_lr, "users": users, "rounds": []}
     xprobe = torch.from_numpy(ds.x1[:4])
     for rnd in range(2):

@@ -62,7 +62,7 @@ def _norms(sd):
 COND = load_golden("conditioning.json")["norms"]
 
 
-def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6):
+def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6, bn_bias_tol=5e-2):
     """Per-tensor tolerance = max(rtol, 3x the deviation the CPU oracle itself shows for that
     tensor under a 1e-7 input perturbation / a different summation order, measured by
     tests/golden/make_conditioning.py): zero-initialised BN biases move by +-lr*sign(g) per
@@ -79,7 +79,7 @@ def _cmp_norms(got, want, rtol, what, report, atol=7.5e-6):
         worst[kind] = max(worst.get(kind, 0.0), rel)
         # BN biases of a beta = 0 init (this golden's; the conditioned goldens of test_golden_r2_gpu.py start from
         # beta = 0.1 n and hold 1e-3): the oracle's own deviation reaches 1.1e-2.  Fixed bounds, no per-round factor.
-        tol = 5e-2 if kind == "bn_bias" else max(rtol, 3.0 * COND.get(k, 0.0))
+        tol = bn_bias_tol if kind == "bn_bias" else max(rtol, 3.0 * COND.get(k, 0.0))
         if err > tol * abs(w) + atol:
             bad.append(f"{k}: got {got[k]} want {w} rel {rel:.2e} tol {tol:.1e}")
     report[what + " max norm rel err"] = worst
@@ -104,6 +104,13 @@ def test_traj_train_config1():
     ds = SynthDataset(n_cl * N, C, g["hw"], g["data_seed"], False)
     pos, neg = class_lists(ds.targets, C)
     netglob = build_model(args)
+    if g.get("bn_seed") is not None:         # conditioned init of the golden (round 4): BatchNorm biases then hold 1e-3 like the
+        from tests.synth import perturbed_bn     # other conditioned goldens instead of the 5e-2 a beta = 0 start allows
+        sd = netglob.state_dict()
+        for k, v in perturbed_bn([(k, tuple(t.shape)) for k, t in sd.items()], g["bn_seed"]):
+            sd[k] = torch.from_numpy(v)
+        netglob.load_state_dict(sd)
+    bias_tol = 1e-3 if g.get("bn_seed") is not None else 5e-2
     locs = [LocalUpdate(args, i, ds, g["users"][i], pos, neg, active_class_list=[i]) for i in range(n_cl)]
     report = {}
     for i in range(n_cl):
@@ -117,10 +124,10 @@ def test_traj_train_config1():
             report[f"r{rnd}c{i} loss rel err"] = rel
             assert rel < 2e-3, (rnd, i, loss, r["loss"][i])
             assert negl == r["neg"][i] and actl == r["act"][i]
-            _cmp_norms(_norms(sd), r["norms"][i], 1e-3, f"r{rnd}c{i}", report)
+            _cmp_norms(_norms(sd), r["norms"][i], 1e-3, f"r{rnd}c{i}", report, bn_bias_tol=bias_tol)
             w.append(copy.deepcopy(sd))
         netglob.load_state_dict(FedAvg(w, [N] * n_cl))
-        _cmp_norms(_norms(netglob.state_dict()), r["glob_norms"], 1e-3, f"r{rnd}glob", report)
+        _cmp_norms(_norms(netglob.state_dict()), r["glob_norms"], 1e-3, f"r{rnd}glob", report, bn_bias_tol=bias_tol)
         netglob.eval()
         _, z = netglob(ds.x1[:4])
         np.testing.assert_allclose(z.cpu().numpy(), np.array(r["probe_logits"]), rtol=5e-3, atol=5e-4)

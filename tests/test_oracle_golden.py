@@ -107,7 +107,7 @@ def test_traj_train_config1():
     args = make_args(n_classes=C, n_clients=n_cl)
     data = data_dict(n_cl * N, C, g["hw"], g["data_seed"], False)
     _, neg = class_lists(data["targets"], C)
-    glob = oracle_net(C, g["init_seed"])
+    glob = _perturb_bn(oracle_net(C, g["init_seed"]), g.get("bn_seed"))
     clients = [R.RefClient(args, i, data, g["users"][i], neg, [i]) for i in range(n_cl)]
     for i in range(n_cl):
         np.testing.assert_allclose(clients[i].loss_w, g["loss_w"][i], rtol=0)
