@@ -1632,7 +1632,8 @@ __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const flo
     const float inv = 1.f / (float)HW;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float t = 0.f;
-        for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * C + c];
+#pragma unroll 4
+        for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * C + c];     // (loads of 4 chunks in flight; same order of sums)
         t *= inv;
         s_[c] = t;
         sq[(size_t)img * C + c] = t;
@@ -1641,13 +1642,19 @@ __global__ void se_fwd_kernel(const float* __restrict__ pool, int nch, const flo
     // four squeezed channels per wave at a time: their weight rows are in flight together and lanes 0-3 finish one each (the
     // one-row-at-a-time form was a chain of up to 12 dependent L2 round trips per image: 43 us per launch, 1.4 ms per step);
     // per channel the sums are formed in the same order as before
+    // (round 4: the `j0 + u < Cs` test inside the loop made every one of the four loads its own load -> s_waitcnt vmcnt(0) -> FMA
+    // sequence, 4 x C/64 x Cs/16 dependent L2 round trips per image: 44 us per launch.  Rows past Cs are clamped instead -- their
+    // sums are never used -- so the loop body is branch-free and the loads of three iterations are in flight together.)
     for (int j0 = 4 * wave; j0 < Cs; j0 += 16) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[u] = W1 + (size_t)min(j0 + u, Cs - 1) * C;
+#pragma unroll 3
         for (int c = lane; c < C; c += 64) {
             const float sv = s_[c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j0 + u < Cs) t[u] += W1[(size_t)(j0 + u) * C + c] * sv;
+            for (int u = 0; u < 4; ++u) t[u] += wr[u][c] * sv;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -1730,6 +1737,7 @@ __global__ void se_bwd_kernel(const float* __restrict__ pool, int nch, int pstri
     const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float t = 0.f;
+#pragma unroll 4
         for (int k = 0; k < nch; ++k) t += pool[((size_t)img * nch + k) * pstride + c];
         const float g = gate[(size_t)img * C + c];
         t *= g * (1.f - g);
@@ -1739,11 +1747,14 @@ __global__ void se_bwd_kernel(const float* __restrict__ pool, int nch, int pstri
     __syncthreads();
     for (int j0 = 4 * wave; j0 < Cs; j0 += 16) {          // four squeezed channels per wave at a time, as in se_fwd_kernel
         float t[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[u] = W2 + (size_t)min(j0 + u, Cs - 1) * C;     // rows past Cs clamped: branch-free loop body
+#pragma unroll 3
         for (int c = lane; c < C; c += 64) {
             const float gv = g_[c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j0 + u < Cs) t[u] += W2[(size_t)(j0 + u) * C + c] * gv;
+            for (int u = 0; u < 4; ++u) t[u] += wr[u][c] * gv;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
