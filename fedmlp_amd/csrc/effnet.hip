@@ -1956,16 +1956,27 @@ __global__ __launch_bounds__(256) void se_wgrad_part_kernel(const float* __restr
         }
         __syncthreads();
         const int ni = min(SE_TI, i1 - it);
-        for (int ii = 0; ii < ni; ++ii) {
-            const size_t img = (size_t)(it + ii);
-            const float g = cv ? dgp[img * C + c] : 0.f, q = cv ? sq[img * C + c] : 0.f;
-            b2 += g;
+        // four images per pass: their eight loads are issued together (one image at a time was a chain of dependent L2 round
+        // trips); images past the range contribute exact zeros (g = q = 0 against the zero-staged sw / dd rows), sums in image order
+        for (int ii = 0; ii < ni; ii += 4) {
+            float g[4], q[4];
 #pragma unroll
-            for (int k = 0; k < SE_NJ; ++k) {
-                const int j = jl + 4 * k;
-                if (j < Cs) {
-                    acc2[k] += g * sw[ii][j];
-                    acc1[k] += dd[ii][j] * q;
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = cv && ii + u < ni;
+                const size_t img = (size_t)(it + (ok ? ii + u : 0));
+                g[u] = ok ? dgp[img * C + c] : 0.f;
+                q[u] = ok ? sq[img * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b2 += g[u];
+#pragma unroll
+                for (int k = 0; k < SE_NJ; ++k) {
+                    const int j = jl + 4 * k;
+                    if (j < Cs) {
+                        acc2[k] += g[u] * sw[ii + u][j];
+                        acc1[k] += dd[ii + u][j] * q[u];
+                    }
                 }
             }
         }
@@ -1985,8 +1996,10 @@ __global__ __launch_bounds__(256) void se_wgrad_part_kernel(const float* __restr
     }
     if (blockIdx.x == 0 && t < cs4) {                        // db1 (and its padding, written as zeros)
         float v = 0.f;
-        if (t < Cs)
+        if (t < Cs) {
+#pragma unroll 8
             for (int img = i0; img < i1; ++img) v += drp[(size_t)img * Cs + t];
+        }
         slab[o_b1 + t] = v;
     }
 }
