@@ -316,7 +316,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
     for (int g = 0; g < groups; ++g) {
         double s1 = 0.0, s2 = 0.0;
         const float* st = stats + (size_t)g * tiles * 2 * C;
-        for (int t = sl; t < tiles; t += 4) {
+#pragma unroll 4
+        for (int t = sl; t < tiles; t += 4) {                  // (eight loads in flight: the loop was one L2 round trip per tile)
             s1 += (double)st[(size_t)t * 2 * C + ch];
             s2 += (double)st[(size_t)t * 2 * C + C + ch];
         }
@@ -744,6 +745,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int group
     for (int g = 0; g < groups; ++g) {
         double s1 = 0.0, s2 = 0.0;
         const float* pt = part + (size_t)g * nblk * 2 * C;
+#pragma unroll 4
         for (int t = sl; t < nblk; t += 4) {
             s1 += (double)pt[(size_t)t * 2 * C + ch];
             s2 += (double)pt[(size_t)t * 2 * C + C + ch];

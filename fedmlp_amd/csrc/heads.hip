@@ -44,6 +44,7 @@ __global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ feat
     const int img = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
+#pragma unroll 7
         for (int p = 0; p < HW; ++p) s += (float)x[((size_t)img * HW + p) * C + c];
         feat[(size_t)img * C + c] = s / (float)HW;
     }
@@ -318,12 +319,14 @@ __global__ void cos_tag_kernel(const float* __restrict__ feat, int64_t N, int D,
     if (n >= N) return;
     const float* f = feat + n * D;
     float ff = 0.f;
+#pragma unroll 8
     for (int d = lane; d < D; d += 64) ff += f[d] * f[d];
     const float fn = sqrtf(wave_sum(ff));
     for (int k = 0; k < ncls; ++k) {
         const float* p0 = proto + (size_t)(2 * classes[k]) * D;
         const float* p1 = p0 + D;
         float d0 = 0.f, d1 = 0.f, n0 = 0.f, n1 = 0.f;
+#pragma unroll 4
         for (int d = lane; d < D; d += 64) {
             const float x = f[d], a = p0[d], b = p1[d];
             d0 += x * a; d1 += x * b; n0 += a * a; n1 += b * b;
