@@ -38,6 +38,19 @@ inline int fm_tune(const char* name, int dflt)
 #endif
 }
 
+// The ResNet conv GEMMs (igemm.hip, wgrad.hip) form their fp32 products either on the fp32 matrix pipe (0) or as exact bf16
+// partial products on the bf16 matrix pipe (9 = all nine, 6 = the six above 2^-26 of the product; split3.h).  Runtime switch
+// FM_MFMA_SPLIT, read per call (tests compare the forms in one process).
+#ifndef FM_MFMA_SPLIT_DEFAULT
+#define FM_MFMA_SPLIT_DEFAULT 0
+#endif
+inline int fm_mfma_split()
+{
+    const char* v = getenv("FM_MFMA_SPLIT");
+    const int s = v ? atoi(v) : FM_MFMA_SPLIT_DEFAULT;
+    return (s == 9 || s == 6) ? s : 0;
+}
+
 // ---- activation storage types -------------------------------------------------------------------
 // The EfficientNet-B0 path stores its NHWC activations either as fp32 (the reference's arithmetic)
 // or as bf16 (BASELINE configs[4]); every kernel computes in fp32 registers.  ld4 / st4 move 4

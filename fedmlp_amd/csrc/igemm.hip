@@ -42,13 +42,17 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split3.h"
 
 // STEM: 0 = 3x3 / 1x1 convs, 1 = stem with K = [kh][kw padded][4] (EfficientNet's 3x3, ResNet's padded form), 2 = ResNet's
 // packed 7x7 stem over the zero-framed NHWC3 input
-template <int BM, int BN, int WN, int STEM, int NS = 4, int KS = 16>
+// SP: 0 = fp32 products on v_mfma_f32_16x16x4_f32; 9 / 6 = fp32 products as exact bf16 partial products on
+// v_mfma_f32_16x16x32_bf16 (split3.h; KS = 32 only: a stage is one bf16 k-step)
+template <int BM, int BN, int WN, int STEM, int NS = 4, int KS = 16, int SP = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__     // the host pass only needs the launch stub (the body uses gfx950-only builtins)
+    static_assert(SP == 0 || KS == 32, "the split form takes one 32-k stage per MFMA step");
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
     static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
@@ -237,6 +241,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
             asm volatile("" ::: "memory");
             if (s + D < k1) issue(s + D);      // refill the slot step s-1 just vacated
             const int slot = (s - k0) % NS;
+            if constexpr (SP != 0) {
+                // lane group lg supplies k = 4lg..4lg+3 and 16+4lg..16+4lg+3 of the stage as its 8 k-slots (same for A and B)
+                const int sl0 = (lg ^ fsw) << 2, sl1 = ((4 + lg) ^ fsw) << 2;
+                const float* A = As + slot * STG_A + aoff;
+                const float* B = Bs + slot * STG_B + boff;
+                sp_u32x4 ah[FR], am[FR], al[FR], bh[FC], bm[FC], bl[FC];
+#pragma unroll
+                for (int r = 0; r < FR; ++r)
+                    split3(*reinterpret_cast<const f32x4*>(A + r * 16 * KS + sl0),
+                           *reinterpret_cast<const f32x4*>(A + r * 16 * KS + sl1), ah[r], am[r], al[r]);
+#pragma unroll
+                for (int c = 0; c < FC; ++c)
+                    split3(*reinterpret_cast<const f32x4*>(B + c * 16 * KS + sl0),
+                           *reinterpret_cast<const f32x4*>(B + c * 16 * KS + sl1), bh[c], bm[c], bl[c]);
+#pragma unroll
+                for (int r = 0; r < FR; ++r)
+#pragma unroll
+                    for (int c = 0; c < FC; ++c)
+                        acc[r][c] = mfma_split<SP>(ah[r], am[r], al[r], bh[c], bm[c], bl[c], acc[r][c]);
+            } else
 #pragma unroll
             for (int h = 0; h < KS / 16; ++h) {
                 const int sl = ((4 * h + lg) ^ fsw) << 2;
@@ -403,6 +427,10 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0>), LDS_S, "igemm_kernel<64, 256, 4, 0>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 9>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32, 9>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 6>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32, 6>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32, 6>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 1>), LDS_S, "igemm_kernel<64, 256, 4, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 2>), LDS_S, "igemm_kernel<64, 256, 4, 2>");
         attr_done = true;
@@ -430,14 +458,21 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, igemm_max_blocks()), p.total_steps);
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
     dim3 grid(nblk);
+    const int split = fm_mfma_split();
     if (p.stem_kw && p.stem3)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 2>), grid, dim3(256), LDS_S, s, p);
     else if (p.stem_kw)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 1>), grid, dim3(256), LDS_S, s, p);
     else if (p.M >= 128) {
-        if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32>), grid, dim3(256), LDS_L, s, p);
+        if (ks32 && split == 9) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 9>), grid, dim3(256), LDS_L, s, p);
+        else if (ks32 && split == 6) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 6>), grid, dim3(256), LDS_L, s, p);
+        else if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32>), grid, dim3(256), LDS_L, s, p);
         else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0>), grid, dim3(256), LDS_L, s, p);
     }
+    else if (ks32 && split == 9)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32, 9>), grid, dim3(256), LDS_S, s, p);
+    else if (ks32 && split == 6)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32, 6>), grid, dim3(256), LDS_S, s, p);
     else if (ks32)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32>), grid, dim3(256), LDS_S, s, p);
     else

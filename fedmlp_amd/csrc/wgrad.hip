@@ -20,12 +20,31 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split3.h"
+
+// SP = 9 / 6: the products as exact bf16 partial products (split3.h).  The staging threads split their 16-B fragments ONCE per
+// block on the way into LDS (three bf16 planes per operand, [plane][32 pixels][channels], rows padded to 32 B x odd); the
+// MFMA fragments come out of the pixel-major tiles through ds_read_b64_tr_b16 (hardware transpose: a lane supplies the
+// address of pixel row 4 lg + (li >> 2), columns 4 (li & 3).. of a 16-channel block and receives channel li of pixels
+// 4 lg .. 4 lg + 3; two reads = the 8 k-slots of v_mfma_f32_16x16x32_bf16, the same pixel permutation for both operands).
+// X is the row operand of the MFMA, so a lane ends up with 4 consecutive n of one m: one 16-B slab store per tile.
+// The planes take 6 B per element where fp32 takes 4: ONE LDS buffer (two barriers per step) keeps two blocks per CU.
+#if __HIP_DEVICE_COMPILE__
+__device__ __forceinline__ uint2 wg_read_tr16(const unsigned char* lds_ptr)
+{
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const unsigned off = (unsigned)(size_t)lds_ptr;          // generic -> LDS: the low 32 bits are the LDS offset
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)off));
+}
+#endif
 
 // FC = 16-column MFMA tiles per wave: 4 (64x64 wave tile) or 3 (64x48: BN = 192 tiles N = 576 = 9 taps x 64
 // channels of ResNet layer 1 exactly, where 256-wide tiles waste a quarter of the MFMA work)
-template <int BM, int BN, int WN, int FC = 4>
+template <int BM, int BN, int WN, int FC = 4, int SP = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 {
+#if __HIP_DEVICE_COMPILE__
     constexpr int WM = 4 / WN;
     static_assert(BM == WM * 64 && BN == WN * 16 * FC && (FC == 4 || FC == 3), "wave tile is 64 x 16*FC");
     constexpr int BNP = FC == 4 ? BN : BN + 16;  // LDS row stride of the B tile (the pad keeps the FC = 3 reads conflict-free)
@@ -134,6 +153,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int q = 0; q < NB; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[q], 0, 0);
     };
+    // split form: byte strides of a pixel row / a plane of the two tiles
+    constexpr int SA = BM * 2 + 32, SB = BN * 2 + 32, PA = 32 * SA, PB = 32 * SB;
+    unsigned char* const Ap = reinterpret_cast<unsigned char*>(smem);          // [3][32][SA]
+    unsigned char* const Bp = Ap + 3 * PA;                                      // [3][32][SB], then 64 x 8-B dummy slots
+    auto lstore_split = [&]() {
+        unsigned char* a = Ap + ra0 * SA + 8 * ca;
+        unsigned char* b = bstage ? Bp + rb0 * SB + 8 * cb : Bp + 3 * PB + 8 * (tid & 63);
+        const int bstep = bstage ? RPB * SB : 0, bplane = bstage ? PB : 0;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, ra[q]);
+            uint2 H, M, L;
+            split3_pair(sp_f32x2{v[0], v[1]}, H.x, M.x, L.x);
+            split3_pair(sp_f32x2{v[2], v[3]}, H.y, M.y, L.y);
+            *reinterpret_cast<uint2*>(a + q * RPA * SA) = H;
+            *reinterpret_cast<uint2*>(a + q * RPA * SA + PA) = M;
+            *reinterpret_cast<uint2*>(a + q * RPA * SA + 2 * PA) = L;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, rb[q]);
+            uint2 H, M, L;
+            split3_pair(sp_f32x2{v[0], v[1]}, H.x, M.x, L.x);
+            split3_pair(sp_f32x2{v[2], v[3]}, H.y, M.y, L.y);
+            *reinterpret_cast<uint2*>(b + q * bstep) = H;
+            *reinterpret_cast<uint2*>(b + q * bstep + bplane) = M;
+            *reinterpret_cast<uint2*>(b + q * bstep + 2 * bplane) = L;
+        }
+    };
     auto lstore = [&](int buf) {
         float* a = As + buf * 32 * BM + ra0 * BM + 4 * ca;
         // threads that stage no B row (64 of 256 when CB = 48) store their zeros to a private 16-B slot behind the tiles:
@@ -153,6 +201,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (SP != 0) {
+        // acc[r][c][q] = dW[m = m0 + wm*64 + 16 r + li][n = n0 + wn*16FC + 16 c + 4 lg + q]
+        if (nsteps > 0) {
+            gaddr(0);
+            gissue();
+            lstore_split();
+            gaddr(1);
+        }
+        __syncthreads();
+        const int trow = 4 * lg + (li >> 2), tcol = 4 * (li & 3);
+        const unsigned char* fa = Ap + trow * SA + (wm * 64 + tcol) * 2;
+        const unsigned char* fb = Bp + trow * SB + (wn * (16 * FC) + tcol) * 2;
+        for (int s = 0; s < nsteps; ++s) {
+            gissue();                    // step s+1 (the step after the last loads zeros)
+            __builtin_amdgcn_sched_barrier(0);
+            gaddr(s + 2);
+            if (wave_cols) {
+                sp_u32x4 xh[FC], xm[FC], xl[FC];
+#pragma unroll
+                for (int c = 0; c < FC; ++c) {
+                    const unsigned char* q = fb + 32 * c;
+                    const uint2 h0 = wg_read_tr16(q), h1 = wg_read_tr16(q + 16 * SB);
+                    const uint2 m0 = wg_read_tr16(q + PB), m1 = wg_read_tr16(q + PB + 16 * SB);
+                    const uint2 l0 = wg_read_tr16(q + 2 * PB), l1 = wg_read_tr16(q + 2 * PB + 16 * SB);
+                    xh[c] = sp_u32x4{h0.x, h0.y, h1.x, h1.y};
+                    xm[c] = sp_u32x4{m0.x, m0.y, m1.x, m1.y};
+                    xl[c] = sp_u32x4{l0.x, l0.y, l1.x, l1.y};
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned char* q = fa + 32 * r;
+                    const uint2 h0 = wg_read_tr16(q), h1 = wg_read_tr16(q + 16 * SA);
+                    const uint2 m0 = wg_read_tr16(q + PA), m1 = wg_read_tr16(q + PA + 16 * SA);
+                    const uint2 l0 = wg_read_tr16(q + 2 * PA), l1 = wg_read_tr16(q + 2 * PA + 16 * SA);
+                    const sp_u32x4 yh = {h0.x, h0.y, h1.x, h1.y}, ym = {m0.x, m0.y, m1.x, m1.y}, yl = {l0.x, l0.y, l1.x, l1.y};
+#pragma unroll
+                    for (int c = 0; c < FC; ++c) acc[r][c] = mfma_split<SP>(xh[c], xm[c], xl[c], yh, ym, yl, acc[r][c]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();             // every wave has read step s
+            lstore_split();
+            __syncthreads();
+        }
+        const int nb = n0 + wn * (16 * FC) + 4 * lg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + 16 * r + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) {
+                const int n = nb + 16 * c;
+                if (n < p.Nw) *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + m) * p.Nw + n) = acc[r][c];
+            }
+        }
+        return;
+    }
     if (nsteps > 0) {
         gaddr(0);
         gissue();
@@ -213,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p)
                 }
             }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -409,7 +515,17 @@ bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
     constexpr int LDS_L = 2 * 32 * (128 + 128) * 4 + 1024;   // + 64 x 16 B dummy slots
     constexpr int LDS_S = 2 * 32 * (64 + 256) * 4 + 1024;
     constexpr int LDS_T = 2 * 32 * (64 + 192 + 16) * 4 + 1024;
+    // split form: three bf16 planes of both tiles, single-buffered, + 64 x 8 B dummy slots
+    constexpr int SPL_L = 3 * 32 * ((128 * 2 + 32) + (128 * 2 + 32)) + 512;
+    constexpr int SPL_S = 3 * 32 * ((64 * 2 + 32) + (256 * 2 + 32)) + 512;
+    constexpr int SPL_T = 3 * 32 * ((64 * 2 + 32) + (192 * 2 + 32)) + 512;
     if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2, 4, 9>), SPL_L, "wgrad_kernel<128, 128, 2, 4, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4, 4, 9>), SPL_S, "wgrad_kernel<64, 256, 4, 4, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3, 9>), SPL_T, "wgrad_kernel<64, 192, 4, 3, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2, 4, 6>), SPL_L, "wgrad_kernel<128, 128, 2, 4, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4, 4, 6>), SPL_S, "wgrad_kernel<64, 256, 4, 4, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3, 6>), SPL_T, "wgrad_kernel<64, 192, 4, 3, 6>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<128, 128, 2>), LDS_L, "wgrad_kernel<128, 128, 2>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 256, 4>), LDS_S, "wgrad_kernel<64, 256, 4>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&wgrad_kernel<64, 192, 4, 3>), LDS_T, "wgrad_kernel<64, 192, 4, 3>");
@@ -425,7 +541,16 @@ bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
         }
     }
     dim3 grid(p.tilesM * p.tilesN, splits);
-    if (p.M >= 128)
+    const int sp = fm_mfma_split();
+    if (sp == 9) {
+        if (p.M >= 128) hipLaunchKernelGGL((wgrad_kernel<128, 128, 2, 4, 9>), grid, dim3(256), SPL_L, s, p);
+        else if (p.bn == 192) hipLaunchKernelGGL((wgrad_kernel<64, 192, 4, 3, 9>), grid, dim3(256), SPL_T, s, p);
+        else hipLaunchKernelGGL((wgrad_kernel<64, 256, 4, 4, 9>), grid, dim3(256), SPL_S, s, p);
+    } else if (sp == 6) {
+        if (p.M >= 128) hipLaunchKernelGGL((wgrad_kernel<128, 128, 2, 4, 6>), grid, dim3(256), SPL_L, s, p);
+        else if (p.bn == 192) hipLaunchKernelGGL((wgrad_kernel<64, 192, 4, 3, 6>), grid, dim3(256), SPL_T, s, p);
+        else hipLaunchKernelGGL((wgrad_kernel<64, 256, 4, 4, 6>), grid, dim3(256), SPL_S, s, p);
+    } else if (p.M >= 128)
         hipLaunchKernelGGL((wgrad_kernel<128, 128, 2>), grid, dim3(256), LDS_L, s, p);
     else if (p.bn == 192)
         hipLaunchKernelGGL((wgrad_kernel<64, 192, 4, 3>), grid, dim3(256), LDS_T, s, p);

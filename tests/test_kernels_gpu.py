@@ -104,6 +104,44 @@ def _check_conv(e, sd, ci, imgs, groups, seed):
                                    err_msg=f"dgrad {name}")
 
 
+@pytest.mark.parametrize("ci", [1, 6, 11, 16])
+def test_split_products_are_fp32_accurate(monkeypatch, eng224, ci):
+    """FM_MFMA_SPLIT = 9 / 6 (fp32 products as exact bf16 partial products on the bf16 matrix pipe, csrc/split3.h) against
+    float64 convolutions: forward, data gradient and weight gradient are as close to float64 as the fp32-MFMA kernels are."""
+    e, sd = eng224
+    info = e.debug_conv_info(ci)
+    imgs = 3
+    g = torch.Generator().manual_seed(900 + ci)
+    w = torch.from_numpy(sd[conv_names()[ci] + ".weight"]).double()
+    x = torch.randn((imgs, info["cin"], info["hin"], info["win"]), generator=g)
+    dy = torch.randn((imgs, info["cout"], info["hout"], info["wout"]), generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, info["stride"], info["pad"])
+    y.backward(dy.double())
+    dev = e.device
+    x_d = _nhwc(x, info["cin_p"]).to(dev)
+    dy_d = _nhwc(dy, info["cout"]).to(dev)
+    want_w = wr.grad.permute(0, 2, 3, 1).reshape(info["cout"], -1)
+    errs = {}
+    for sp in (0, 9, 6):
+        monkeypatch.setenv("FM_MFMA_SPLIT", str(sp))
+        out = torch.empty((imgs, info["hout"], info["wout"], info["cout"]), device=dev)
+        e.debug_conv(0, ci, x_d, None, out, imgs, 1, torch.empty((1, 2, info["cout"]), device=dev))
+        dx = torch.empty((imgs, info["hin"], info["win"], info["cin"]), device=dev)
+        e.debug_conv(1, ci, None, dy_d, dx, imgs)
+        dw = torch.empty((info["cout"], info["Kw"]), device=dev)
+        e.debug_conv(2, ci, x_d, dy_d, dw, imgs)
+        rel = lambda got, want: ((got.double() - want).norm() / want.norm()).item()
+        errs[sp] = (rel(out.cpu().permute(0, 3, 1, 2), y.detach()), rel(dx.cpu().permute(0, 3, 1, 2), xr.grad),
+                    rel(dw.cpu()[:, :want_w.shape[1]], want_w))
+    print(f"conv{ci} relative L2 error vs float64 (fwd, dgrad, wgrad): {errs}")
+    for sp in (9, 6):
+        for k in range(3):
+            assert errs[sp][k] <= 1.25 * errs[0][k] + 1e-9, (sp, k, errs)
+            assert errs[sp][k] < 2e-6
+
+
 @pytest.mark.parametrize("ci", list(range(20)))
 def test_conv_all_layers_64(eng64, ci):
     e, sd = eng64
