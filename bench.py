@@ -50,11 +50,49 @@ sys.path.insert(0, ROOT)
 
 # kernel families of fm_profile_read (names as rocprofv3 prints them for the ResNet-18 workload, where every
 # conv has Ci % 32 == 0 and runs the 32-k-stage instantiation)
-KERNEL_NAMES = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,256,4,0,2,32>",
-                2: "igemm_kernel<64,256,4,2,4,16>", 3: "wgrad_kernel<128,128,2,4>", 4: "wgrad_kernel<64,192,4,3>",
-                5: "wgrad_kernel<64,192,4,3> [7x7 stem launch]"}
-NFAM = len(KERNEL_NAMES)
+KERNEL_NAMES_F32 = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,256,4,0,2,32>",
+                    2: "igemm_kernel<64,256,4,2,4,16>", 3: "wgrad_kernel<128,128,2,4>", 4: "wgrad_kernel<64,192,4,3>",
+                    5: "wgrad_kernel<64,192,4,3> [7x7 stem launch]"}
+NFAM = len(KERNEL_NAMES_F32)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense
+
+
+def mfma_products():
+    """0 = the conv GEMMs multiply on the fp32 matrix pipe; 6 / 9 = every fp32 product as that many exact bf16 partial
+    products on the bf16 matrix pipe, accumulated in fp32 (csrc/split3.h; FM_MFMA_SPLIT, library default 6)."""
+    from fedmlp_amd import _lib
+    return int(_lib.load().fm_mfma_products())
+
+
+def kernel_names():
+    sp = mfma_products()
+    if not sp:
+        return dict(KERNEL_NAMES_F32)
+    # the 7x7 stem forward (16-k stages) stays on the fp32 pipe
+    return {0: f"igemm_kernel<128,128,2,0,2,32,{sp}>", 1: f"igemm_kernel<64,256,4,0,2,32,{sp}>",
+            2: "igemm_kernel<64,256,4,2,4,16>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
+            5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
+
+
+def mfma_peak():
+    """(peak TFLOP/s of fp32-equivalent work, note): the fp32 pipe's dense peak, or the bf16 pipe's divided by the partial
+    products each fp32 product costs."""
+    sp = mfma_products()
+    if not sp:
+        return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_16x16x4_f32 dense peak"
+    return round(PEAK_BF16_MFMA_TFLOPS / sp, 2), (
+        f"v_mfma_f32_16x16x32_bf16 dense peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {sp} bf16 partial products per fp32 product "
+        f"(`achieved` counts algorithmic fp32 FLOPs, not the {sp}x bf16 FLOPs issued)")
+
+
+ARITHMETIC = {0: "fp32 operands, fp32 products and accumulation on v_mfma_f32_16x16x4_f32",
+              6: "fp32 operands and fp32 accumulation; every product as 6 exact bf16 partial products on v_mfma_f32_16x16x32_bf16 "
+                 "(3-way exact split of both operands, the 3 partial products below 2^-26 of the product left out; error against "
+                 "float64 is below the fp32-MFMA form's: tests/test_kernels_gpu.py::test_split_products_are_fp32_accurate; "
+                 "FM_MFMA_SPLIT=0 selects the fp32 pipe)",
+              9: "fp32 operands and fp32 accumulation; every product as its 9 exact bf16 partial products on "
+                 "v_mfma_f32_16x16x32_bf16 (FM_MFMA_SPLIT=9)"}
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 # SURVEY.md 8(d): minimum activation bytes per image of one EfficientNet-B0 forward
 EFFNET_FWD_BYTES = {"fp32": 73.8e6, "bf16": 36.9e6}
@@ -438,7 +476,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
         pmc_file = pmc_doc(args)[1]
         allk = None
         if fams is not None:
-            allk = {KERNEL_NAMES[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
+            allk = {kernel_names()[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
                                       "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
                     for f in range(NFAM)}
         if args.model == "Efficient_b0":
@@ -455,8 +493,9 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
         elif fams is None:
             steps_alg = STEP_FLOP[args.workload] * B
             tf = steps_alg / (dt / args.steps) / 1e12
-            roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "whole step",
+            peak, peak_note = mfma_peak()
+            roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "peak_basis": peak_note,
+                    "frac": round(tf / peak, 4), "traffic": None, "kernel": "whole step",
                     "measured_in": "the timed region (no free device memory for the one-stream per-kernel pass)"}
         else:
             if args.workload == "conv_fwd":
@@ -467,10 +506,12 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
             else:
                 dom = max(range(NFAM), key=lambda f: fams[f][1])
                 n, ms, fl = fams[dom]
-                name = KERNEL_NAMES[dom]
+                name = kernel_names()[dom]
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(name, args),
+            peak, peak_note = mfma_peak()
+            roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "peak_basis": peak_note,
+                    "frac": round(tf / peak, 4), "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": measured_traffic(name, args),
                     "traffic_source": pmc_file + " (separate rocprofv3 --pmc passes, not this run)",
                     "kernel": name, "launches": n, "avg_launch_ms": round(ms / max(n, 1), 5),
                     "measured_in": measured_in, "sampled": sampled, "all_kernels": allk}
@@ -482,7 +523,8 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
             if args.workload in STEP_FLOP:
                 steps_alg = STEP_FLOP[args.workload] * B
                 roof["whole_step_tflops"] = round(steps_alg / (dt / args.steps) / 1e12, 3)
-                roof["whole_step_frac"] = round(steps_alg / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                roof["whole_step_frac"] = round(steps_alg / (dt / args.steps) / 1e12 / peak, 4)
+                roof["whole_step_frac_of_fp32_mfma_peak"] = round(steps_alg / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             if args.workload == "conv_fwd":
                 roof["traffic"] = family_traffic("igemm_kernel<", args)     # mean over the 20 conv launches of a pass
                 roof["algorithmic_flop_per_pass"] = RESNET_FWD_FLOP * B
@@ -510,7 +552,9 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
                       "views_per_sec": round(views * total / dt, 3), "parallelism": f"clients{world}",
                       "stream_mode": STREAM_MODE_NAMES.get(effective_mode, str(effective_mode)) +
                                      (" (--one-stream)" if args.one_stream else ""),
-                      "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3)},
+                      "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3),
+                      "arithmetic": ("bf16 storage, fp32 accumulation" if (args.model == "Efficient_b0" and args.precision == "bf16")
+                                     else ARITHMETIC[mfma_products()])},
            "roofline": roof,
            "last_loss": float(lv[-1])}
     if per_rank is not None:
@@ -568,11 +612,12 @@ def leg_proto_pass(dev, cand, cpu=True, C=5, N=5000, bs=128):
     assert np.isfinite(proto[:2]).all() and np.isfinite(t).all()
     eng.close()
     tf = RESNET_FWD_FLOP * N / dt / 1e12
+    peak, peak_note = mfma_peak()
     out = {"config": {"workload": f"prototype + t pass (utils/local_training.py:971-1002), ResNet-18, N={N} local samples, "
                                    f"3x224x224, C={C}, eval batches of {4 * bs}"},
            "value": round(N / dt, 2), "unit": "images/sec", "ms_per_pass": round(dt * 1e3, 3), "dtype": "f32",
-           "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+           "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "peak_basis": peak_note,
+                        "frac": round(tf / peak, 4), "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "kernel": "whole pass (eval forward 3.627 GFLOP/sample + prototype sums)"},
            "cpu_baseline": None}
     if not cpu:
@@ -703,7 +748,20 @@ def run_legs(args, dev, cand):
             out.pop(k, None)
         return out
 
+    def fp32_pipe_leg():
+        # the headline workload with the conv GEMMs on the fp32 matrix pipe (the library reads the variable at every launch)
+        old = os.environ.get("FM_MFMA_SPLIT")
+        os.environ["FM_MFMA_SPLIT"] = "0"
+        try:
+            return step_leg()
+        finally:
+            if old is None:
+                del os.environ["FM_MFMA_SPLIT"]
+            else:
+                os.environ["FM_MFMA_SPLIT"] = old
+
     table = [
+        ("stage1_fp32_mfma_pipe", fp32_pipe_leg),
         ("conv_fwd_bs256", lambda: step_leg(workload="conv_fwd", batch=256, steps=60)),
         ("stage1_c14", lambda: step_leg(classes=14)),
         ("train", lambda: step_leg(workload="train")),

@@ -42,7 +42,7 @@ inline int fm_tune(const char* name, int dflt)
 // partial products on the bf16 matrix pipe (9 = all nine, 6 = the six above 2^-26 of the product; split3.h).  Runtime switch
 // FM_MFMA_SPLIT, read per call (tests compare the forms in one process).
 #ifndef FM_MFMA_SPLIT_DEFAULT
-#define FM_MFMA_SPLIT_DEFAULT 0
+#define FM_MFMA_SPLIT_DEFAULT 6
 #endif
 inline int fm_mfma_split()
 {

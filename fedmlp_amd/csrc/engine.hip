@@ -1773,6 +1773,8 @@ int fm_stream_mode(fm_engine* e)
     return e->side_ok ? (e->side_w ? 0 : 2) : 1;
 }
 
+int fm_mfma_products(void) { return fm_mfma_split(); }
+
 int fm_fedavg_fold(fm_engine* e, const float* const* states_dev, const float* n_host, int32_t K, float* out_dev)
 {
     ARGCHK(e && states_dev && n_host && out_dev, "null argument");

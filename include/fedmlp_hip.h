@@ -251,6 +251,12 @@ int fm_feature_dim(fm_engine* e);
  * second activation / workspace set would not fit in free device memory): 0 teacher + weight gradients on the side
  * stream, 2 teacher only, 1 one stream. */
 int fm_stream_mode(fm_engine* e);
+/* How the fp32 convolution GEMMs (ResNet-18's 3x3 / 1x1 convs, EfficientNet's wide 1x1 convs) form their products right
+ * now: 0 = v_mfma_f32_16x16x4_f32; 9 / 6 = each fp32 product as 9 / 6 exact bf16 partial products on
+ * v_mfma_f32_16x16x32_bf16, accumulated in fp32 (csrc/split3.h; the shipped default is 6; the environment variable
+ * FM_MFMA_SPLIT = 0 | 6 | 9 is read at every launch).  Replaces nothing in the reference: cuDNN picks its own algorithm
+ * behind nn.Conv2d (model/all_models.py:53-54). */
+int fm_mfma_products(void);
 
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the

@@ -45,20 +45,11 @@ class _Learnable:
         return self._v
 
 
-def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, avg_last=1):
-    """2 clients x `rounds` FedAvg rounds of LocalUpdate.train on the GPU and through the CPU oracle (same init, same
-    batch orders); test mAP / AUROC averaged over the last `avg_last` rounds on both sides."""
-    import copy
-    import json
-    import os
-    import torch
-    from fedmlp_amd.model import build_model
-    from tests.helpers import replay_local_update
-    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
-    from fedmlp_amd.fedavg import FedAvg
-    from fedmlp_amd.evaluations import globaltest, multilabel_metrics
-    from oracle import steps_ref as R
-    from tests.helpers import oracle_net
+CONVERGED = dict(N=512, rounds=10, lr=3e-4, ntest=4096, signal=0.25, label_noise=0.06, avg_last=3)
+CONVERGED_ORDERS = (3, 4, 5)
+
+
+def _map_problem(N, rounds, lr, ntest, signal, label_noise, order_seed):
     from tests.synth import class_lists
     C, hw, n_cl = 4, 32, 2
     args = make_args(n_classes=C, n_clients=n_cl, batch_size=32, seed=21, base_lr=lr)
@@ -66,8 +57,48 @@ def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, av
     test = _Learnable(ntest, C, hw, 6, signal, label_noise)
     pos, neg = class_lists(train.targets, C)
     users = [list(range(i * N, (i + 1) * N)) for i in range(n_cl)]
-    rs = np.random.RandomState(3)
+    rs = np.random.RandomState(order_seed)
     orders = [[rs.permutation(N).tolist() for _ in range(n_cl)] for _ in range(rounds)]
+    return C, n_cl, args, train, test, pos, neg, users, orders
+
+
+def map_flow_oracle(N, rounds, lr, ntest, signal=0.6, label_noise=0.0, avg_last=1, order_seed=3):
+    """CPU-oracle half: [(mAP, AUROC)] of the last `avg_last` rounds (also run by tools/map_study.py converged)."""
+    import copy
+    import torch
+    from fedmlp_amd.evaluations import multilabel_metrics
+    from oracle import steps_ref as R
+    from tests.helpers import oracle_net
+    C, n_cl, args, train, test, pos, neg, users, orders = _map_problem(N, rounds, lr, ntest, signal, label_noise, order_seed)
+    data = {"targets": train.targets, "image": train.x}
+    glob = oracle_net(C, 21)
+    cls = [R.RefClient(args, i, data, users[i], neg, list(range(C))) for i in range(n_cl)]
+    want = []
+    for r in range(rounds):
+        w = [copy.deepcopy(cls[i].train(copy.deepcopy(glob), orders[r][i])[0]) for i in range(n_cl)]
+        glob.load_state_dict(R.fedavg(w, [N] * n_cl))
+        if r >= rounds - avg_last:
+            glob.eval()
+            with torch.no_grad():
+                _, z = glob(test.x)
+            m = multilabel_metrics(test.targets, torch.sigmoid(z).numpy())
+            want.append((float(m["mAP"]), float(m["auc"])))
+    return want
+
+
+def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, avg_last=1, order_seed=3, oracle=None):
+    """2 clients x `rounds` FedAvg rounds of LocalUpdate.train on the GPU and through the CPU oracle (same init, same
+    batch orders; `oracle` = its recorded per-round metrics when it was run elsewhere); test mAP / AUROC averaged over the
+    last `avg_last` rounds on both sides."""
+    import copy
+    import json
+    import os
+    from fedmlp_amd.model import build_model
+    from tests.helpers import replay_local_update
+    LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
+    from fedmlp_amd.fedavg import FedAvg
+    from fedmlp_amd.evaluations import globaltest
+    C, n_cl, args, train, test, pos, neg, users, orders = _map_problem(N, rounds, lr, ntest, signal, label_noise, order_seed)
     # ---- GPU product
     netglob = build_model(args)
     locs = [LocalUpdate(args, i, train, users[i], pos, neg, active_class_list=list(range(C))) for i in range(n_cl)]
@@ -82,19 +113,7 @@ def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, av
             m = globaltest(netglob, test, args)
             got.append((float(m["mAP"]), float(m["auc"])))
     # ---- CPU oracle
-    data = {"targets": train.targets, "image": train.x}
-    glob = oracle_net(C, 21)
-    cls = [R.RefClient(args, i, data, users[i], neg, list(range(C))) for i in range(n_cl)]
-    want = []
-    for r in range(rounds):
-        w = [copy.deepcopy(cls[i].train(copy.deepcopy(glob), orders[r][i])[0]) for i in range(n_cl)]
-        glob.load_state_dict(R.fedavg(w, [N] * n_cl))
-        if r >= rounds - avg_last:
-            glob.eval()
-            with torch.no_grad():
-                _, z = glob(test.x)
-            m = multilabel_metrics(test.targets, torch.sigmoid(z).numpy())
-            want.append((float(m["mAP"]), float(m["auc"])))
+    want = oracle if oracle is not None else map_flow_oracle(N, rounds, lr, ntest, signal, label_noise, avg_last, order_seed)
     g_map, g_auc = np.mean([v[0] for v in got]), np.mean([v[1] for v in got])
     w_map, w_auc = np.mean([v[0] for v in want]), np.mean([v[1] for v in want])
     base = float((test.targets.mean(0)).mean())          # mAP of a random scorer ~ prevalence
@@ -105,6 +124,7 @@ def _map_flow(N, rounds, lr, ntest, tol, report, signal=0.6, label_noise=0.0, av
     assert w_map > base + 0.4, ("the oracle did not learn", w_map, base)
     assert abs(g_map - w_map) < tol, (g_map, w_map)
     assert abs(g_auc - w_auc) < tol
+    return float(g_map - w_map), float(g_auc - w_auc)
 
 
 def test_map_after_training_matches_oracle():
@@ -120,13 +140,25 @@ def test_map_after_training_matches_oracle():
 def test_map_after_converged_training_matches_oracle():
     """The same flow trained to convergence on a problem whose ceiling is below 1 (weak patterns, 6 % of the labels
     flipped in train and test; 2 clients x 512 samples, 10 FedAvg rounds = 160 Adam steps per client, 4096 test
-    samples): once the fit has converged the chaotic early trajectory no longer decides the metric, and the GPU and
-    CPU-oracle models land on the same plateau.  Measured (mean of the last 3 rounds): mAP 0.8302 (HIP) vs 0.8364
-    (oracle), AUROC 0.8910 vs 0.8926.  The oracle alone moves by +-0.4 % from round to round on that plateau and by
-    0.3-0.5 % between two hosts (0.8346 / 0.8322 / 0.8358 in the 8-core build container, 0.8329 / 0.8354 / 0.8409 on the
-    GPU box's host for the same three rounds), so 0.6 % is agreement within the metric's own resolution on a 4096-sample
-    test set; the north star's +-0.2 % needs a real dataset to be decidable.  Bound: 1 % absolute."""
-    _map_flow(512, 10, 3e-4, 4096, 1e-2, "parity_map_converged.json", signal=0.25, label_noise=0.06, avg_last=3)
+    samples), for THREE batch orders; the oracle half was run in the build container (`python tools/map_study.py
+    converged` -> tests/golden/map_converged_oracle.json; 2.3 minutes per order on 8 cores).  Once the fit has converged the
+    chaotic early trajectory no longer decides the metric, and the GPU and CPU-oracle models land on the same plateau --
+    but a single pair is still one draw of a chaotic optimisation: the oracle alone moves by +-0.4 % from round to round
+    on that plateau and by 0.3-0.5 % between two hosts (order 3: 0.8342 in the build container, 0.8325 and 0.8364 on two GPU
+    boxes' hosts), and the HIP side of that pair measured 0.8302, 0.8284 and 0.8216 under three roundings of the engine's
+    GEMMs (fp32 MFMA of rounds 3 and 4, the bf16-partial-product form).  So one pair is bounded by 2 % absolute and the
+    statement is the MEAN over the three orders, below 0.75 % (measured: mAP -0.33 %, AUROC -0.2 %).  The 32-seed paired study
+    below is the statistical form; the north star's +-0.2 % needs a real dataset to be decidable."""
+    import json
+    g = load_golden("map_converged_oracle.json")
+    assert g["config"] == {k: CONVERGED[k] for k in g["config"]}
+    d = [_map_flow(tol=2e-2, report=f"parity_map_converged_order{o}.json", order_seed=o,
+                   oracle=[tuple(v) for v in g["orders"][str(o)]], **CONVERGED) for o in CONVERGED_ORDERS]
+    with open("gpurun_out/parity_map_converged.json", "w") as f:
+        json.dump({"orders": list(CONVERGED_ORDERS), "mAP_hip_minus_oracle": [v[0] for v in d],
+                   "auc_hip_minus_oracle": [v[1] for v in d]}, f)
+    assert abs(np.mean([v[0] for v in d])) < 7.5e-3, d
+    assert abs(np.mean([v[1] for v in d])) < 7.5e-3, d
 
 
 def test_map_two_stage_flow_paired_study():
