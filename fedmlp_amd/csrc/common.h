@@ -163,6 +163,9 @@ struct IgemmParams {
     // Xe = swish(X * psc[group][k] + psh[group][k]) * gate; null = gate only
     const float* psc = nullptr;
     const float* psh = nullptr;
+    // split-product form (split3.h), M >= 128: the bf16 planes of W made by k_split_weights, [M][nsteps of 32 k][3 planes][32]
+    // (192 B per 32-k block, the k order inside a block as the kernel's lane groups take it); null = split W in the kernel
+    const unsigned short* Wsp = nullptr;
 };
 
 // Weight-gradient GEMM: dW[m][n] = sum_p dY[p][m] * Xg[p][n], split over p.

@@ -53,6 +53,7 @@ struct DgradClass {
     int ph, pw;
     int nsteps;
     float* wpack = nullptr;
+    long long sp_off = -1;    // bf16 planes of wpack inside fm_engine::wsp_d (2-byte units), -1 = none
 };
 
 struct Conv {
@@ -70,6 +71,7 @@ struct Conv {
     int ncls = 0;
     DgradClass cls[4];
     int bn;                   // index of the BatchNorm that follows
+    long long sp_off = -1;    // bf16 planes of the forward weights inside fm_engine::wsp_f / twsp_f (2-byte units), -1 = none
     long long wb_off = -1, wbt_off = -1;   // bf16 shadow of a 1x1 conv's weights [cout_p][cin_p] / transposed (bf16 mode)
     bool last_pro = false;    // the last conv_fwd of this conv carried an operand prologue (decides the bf16 statistics layout)
     double macs_per_img;      // algorithmic MACs (real k, real cin)
@@ -185,6 +187,11 @@ struct fm_engine {
     PackJob* pack_jobs = nullptr;
     int n_pack_jobs = 0, n_pack_blocks = 0;
     bool wpack_dirty = true;
+    // bf16 planes of the conv weights for the split-product GEMMs (split3.h; ResNet, fp32 mode): student forward, teacher
+    // forward, student data-gradient packs; rebuilt with the packs (wpack_dirty) / the teacher shadows (twb_dirty)
+    unsigned short *wsp_f = nullptr, *twsp_f = nullptr, *wsp_d = nullptr;
+    SplitJob *split_f = nullptr, *split_d = nullptr;
+    int n_split_f = 0, n_split_f_blocks = 0, n_split_d = 0, n_split_d_blocks = 0;
     // RCCL (comm.hip)
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -393,6 +400,45 @@ int build_tables(fm_engine* e)
     DALLOC(e->pack_jobs, jobs.size());
     if (!jobs.empty())
         HIPCHK(hipMemcpy(e->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    if (e->model == 0 && !e->precision) {
+        // weight planes for the GEMMs with >= 128 output rows and whole 32-k blocks per tap (igemm.hip, WP form)
+        std::vector<SplitJob> jf, jd;
+        long long off_f = 0, off_d = 0;
+        int bf = 0, bd = 0;
+        for (auto& c : e->convs) {
+            if (c.cin == 3) continue;
+            if (c.cout_p >= 128 && c.cin_p % 32 == 0) {
+                c.sp_off = off_f;
+                jf.push_back({(long long)c.w_off, nullptr, off_f, c.cout_p, c.Kw / 32, bf});
+                bf += split_job_blocks(c.cout_p, c.Kw / 32);
+                off_f += (long long)c.cout_p * c.Kw * 3;
+            }
+            if (c.cin_p >= 128 && c.cout_p % 32 == 0)
+                for (int k = 0; k < c.ncls; ++k) {
+                    DgradClass& d = c.cls[k];
+                    const int K = d.taps.n * c.cout_p;
+                    d.sp_off = off_d;
+                    jd.push_back({0, d.wpack, off_d, c.cin_p, K / 32, bd});
+                    bd += split_job_blocks(c.cin_p, K / 32);
+                    off_d += (long long)c.cin_p * K * 3;
+                }
+        }
+        float* tmp = nullptr;
+        if (off_f) {
+            DALLOC(tmp, (size_t)(off_f + 1) / 2); e->wsp_f = reinterpret_cast<unsigned short*>(tmp);
+            DALLOC(tmp, (size_t)(off_f + 1) / 2); e->twsp_f = reinterpret_cast<unsigned short*>(tmp);
+        }
+        if (off_d) { DALLOC(tmp, (size_t)(off_d + 1) / 2); e->wsp_d = reinterpret_cast<unsigned short*>(tmp); }
+        e->n_split_f = (int)jf.size(); e->n_split_f_blocks = bf; e->n_split_d = (int)jd.size(); e->n_split_d_blocks = bd;
+        if (!jf.empty()) {
+            DALLOC(e->split_f, jf.size());
+            HIPCHK(hipMemcpy(e->split_f, jf.data(), jf.size() * sizeof(SplitJob), hipMemcpyHostToDevice));
+        }
+        if (!jd.empty()) {
+            DALLOC(e->split_d, jd.size());
+            HIPCHK(hipMemcpy(e->split_d, jd.data(), jd.size() * sizeof(SplitJob), hipMemcpyHostToDevice));
+        }
+    }
     return FM_OK;
 }
 
@@ -828,6 +874,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     }
     IgemmParams p{};
     p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+    if (c.sp_off >= 0 && e->wsp_f) p.Wsp = (S == e->tstate ? e->twsp_f : e->wsp_f) + c.sp_off;
     if (c.cin == 3) {
         p.stem_kw = c.k; p.stem_pad = c.pad; p.stem_h2 = c.kw_p == 8 ? 1 : 0; p.stem3 = c.stem3 ? 1 : 0;
         if (c.stem3) p.X = e->x3;               // `x` is ignored: the operand is the framed NHWC3 image
@@ -890,6 +937,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         DgradClass& d = c.cls[k];
         IgemmParams p{};
         p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+        if (d.sp_off >= 0 && e->wsp_d) p.Wsp = e->wsp_d + d.sp_off;
         p.ntaps = d.taps.n;
         for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
         p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
@@ -1094,12 +1142,15 @@ void ensure_packed(fm_engine* e)
     if (!e->wpack_dirty) return;
     if (e->precision) launch_cast_weights(e->state, e->wb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
     else if (e->n_pack_jobs) k_pack_dgrad_all(e->state, e->pack_jobs, e->n_pack_jobs, e->n_pack_blocks, e->st);
+    k_split_weights(e->state, e->wsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
+    k_split_weights(nullptr, e->wsp_d, e->split_d, e->n_split_d, e->n_split_d_blocks, e->st);     // planes of the packs just made
     e->wpack_dirty = false;
 }
 void ensure_teacher_shadow(fm_engine* e)
 {
-    if (!e->precision || !e->twb_dirty) return;
-    launch_cast_weights(e->tstate, e->twb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
+    if (!e->twb_dirty) return;
+    if (e->precision) launch_cast_weights(e->tstate, e->twb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
+    else k_split_weights(e->tstate, e->twsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
     e->twb_dirty = false;
 }
 

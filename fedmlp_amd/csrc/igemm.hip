@@ -42,27 +42,32 @@
 #include <algorithm>
 
 #include "common.h"
+#include "kernels.h"
 #include "split3.h"
 
 // STEM: 0 = 3x3 / 1x1 convs, 1 = stem with K = [kh][kw padded][4] (EfficientNet's 3x3, ResNet's padded form), 2 = ResNet's
 // packed 7x7 stem over the zero-framed NHWC3 input
 // SP: 0 = fp32 products on v_mfma_f32_16x16x4_f32; 9 / 6 = fp32 products as exact bf16 partial products on
 // v_mfma_f32_16x16x32_bf16 (split3.h; KS = 32 only: a stage is one bf16 k-step)
-template <int BM, int BN, int WN, int STEM, int NS = 4, int KS = 16, int SP = 0>
+// WP (with SP): the weight operand arrives as the bf16 planes of k_split_weights (p.Wsp) -- no split arithmetic for A in the
+// kernel.  Its LDS stage is [3 planes][BM rows][64 B] (one LDS-DMA instruction = 16 rows of one plane, the 64-B-row swizzle
+// slot = chunk ^ ((row>>1)&3)), 24 KB for BM = 128 where the fp32 tile takes 16.
+template <int BM, int BN, int WN, int STEM, int NS = 4, int KS = 16, int SP = 0, int WP = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__     // the host pass only needs the launch stub (the body uses gfx950-only builtins)
     static_assert(SP == 0 || KS == 32, "the split form takes one 32-k stage per MFMA step");
+    static_assert(WP == 0 || (SP != 0 && STEM == 0 && BM % 64 == 0), "weight planes: split form, no stem");
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
     static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
     static_assert(KS == 16 || (KS == 32 && STEM == 0), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
     constexpr int D = NS - 1;                   // LDS ring of NS stages of KS k; DMA runs D steps ahead
-    constexpr int STG_A = BM * KS, STG_B = BN * KS;   // floats per stage
+    constexpr int STG_A = WP ? 3 * BM * 16 : BM * KS, STG_B = BN * KS;   // floats per stage (planes: 3 x BM x 64 B)
     constexpr int CPR = KS / 4;                 // 16-B chunks per row of a stage (4 or 8)
     constexpr int RPI = 64 / CPR;               // rows one LDS-DMA instruction stages (16 or 8)
     constexpr int SM = CPR - 1;                 // swizzle mask: chunk c of row r lives in slot c ^ ((r>>1)&SM)
-    constexpr int GA = BM / (4 * RPI), GB = BN / (4 * RPI);   // DMA instructions each wave issues per step
+    constexpr int GA = WP ? 3 * BM / 64 : BM / (4 * RPI), GB = BN / (4 * RPI);   // DMA instructions each wave issues per step
     constexpr int PER = GA + GB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [NS][BM][KS]
@@ -115,9 +120,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
         bool av[GA];                                               // rows past M (M % BM != 0) read the zero page
 #pragma unroll
         for (int q = 0; q < GA; ++q) {
-            const int m = m0 + RPI * (wave * GA + q) + drow;
-            av[q] = m < p.M;
-            asrc[q] = p.W + (size_t)(av[q] ? m : 0) * Ktot + csrc_of(wave * GA + q);
+            if constexpr (WP) {
+                // DMA job j = wave*GA + q stages 16 rows (group j % (BM/16)) of plane j / (BM/16); lane = (row lane>>2, slot lane&3)
+                const int j = wave * GA + q, plane = j / (BM / 16), group = j % (BM / 16);
+                const int m = m0 + 16 * group + (lane >> 2);
+                av[q] = m < p.M;
+                const int chunk = (lane & 3) ^ ((lane >> 3) & 3);          // source-side swizzle of the 64-B rows
+                asrc[q] = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.Wsp) +
+                                                         (size_t)(av[q] ? m : 0) * nsteps * 192 + plane * 64 + chunk * 16);
+            } else {
+                const int m = m0 + RPI * (wave * GA + q) + drow;
+                av[q] = m < p.M;
+                asrc[q] = p.W + (size_t)(av[q] ? m : 0) * Ktot + csrc_of(wave * GA + q);
+            }
         }
         int ih0[GB], iw0[GB], xb[GB];
         bool rv[GB];
@@ -204,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 const unsigned f = (unsigned)(p.tapcode >> (4 * it)) & 15u;
                 const int dh = (int)(f & 3u) - 1, dw = (int)(f >> 2) - 1;
                 const int tapoff = (dh * p.Wi + dw) * p.Ci + icc * KS;       // scalar
-                const int koff = it * p.Ci + icc * KS;                        // scalar
+                // floats from the row start: fp32 rows hold K floats, plane rows 48 floats (192 B) per 32-k block
+                const int koff = WP ? (it * (p.Ci >> 5) + icc) * 48 : it * p.Ci + icc * KS;      // scalar
 #pragma unroll
                 for (int q = 0; q < GA; ++q)
                     __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
@@ -247,6 +263,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 const float* A = As + slot * STG_A + aoff;
                 const float* B = Bs + slot * STG_B + boff;
                 sp_u32x4 ah[FR], am[FR], al[FR], bh[FC], bm[FC], bl[FC];
+                if constexpr (WP) {
+                    // plane rows are 16 floats (64 B); chunk lg of row li + 16 r sits in slot lg ^ ((li>>1)&3)
+                    const float* Ap = As + slot * STG_A + (wm * (16 * FR) + li) * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
+#pragma unroll
+                    for (int r = 0; r < FR; ++r) {
+                        ah[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256);
+                        am[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256 + BM * 16);
+                        al[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256 + 2 * BM * 16);
+                    }
+                } else
 #pragma unroll
                 for (int r = 0; r < FR; ++r)
                     split3(*reinterpret_cast<const f32x4*>(A + r * 16 * KS + sl0),
@@ -408,6 +434,34 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #endif
 }
 
+// bf16 planes of the weight matrices (kernels.h SplitJob): one thread = one 8-value chunk (k = 4g..4g+3, 16+4g..16+4g+3 of
+// a 32-k block): two 16-B reads 64 B apart (4 threads = one 128-B line), three 16-B writes (4 threads = 64 B per plane)
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ src_base, unsigned short* __restrict__ dst_base,
+                                                            const SplitJob* __restrict__ jobs, int njobs)
+{
+#if __HIP_DEVICE_COMPILE__
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+    const SplitJob jb = jobs[j];
+    const long long idx = (long long)((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+    if (idx >= (long long)jb.M * jb.nkb * 4) return;
+    const int g = (int)(idx & 3);
+    const long long blk = idx >> 2;                       // m * nkb + kb
+    const float* src = (jb.src ? jb.src : src_base + jb.src_off) + blk * 32;
+    sp_u32x4 H, M, L;
+    split3(ld4(src + 4 * g), ld4(src + 16 + 4 * g), H, M, L);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(dst_base + jb.dst_off) + blk * 192 + g * 16;
+    *reinterpret_cast<sp_u32x4*>(dst) = H;
+    *reinterpret_cast<sp_u32x4*>(dst + 64) = M;
+    *reinterpret_cast<sp_u32x4*>(dst + 128) = L;
+#endif
+}
+int split_job_blocks(int M, int nkb) { return (int)(((long long)M * nkb * 4 + 255) / 256); }
+void k_split_weights(const float* src_base, unsigned short* dst_base, const SplitJob* jobs, int njobs, int nblocks, hipStream_t s)
+{
+    if (njobs > 0) hipLaunchKernelGGL(split_weights_kernel, dim3(nblocks), dim3(256), 0, s, src_base, dst_base, jobs, njobs);
+}
+
 // Tile configuration.  Measured on MI355X (conv 3x3, 256 images, tools/probe_conv.py):
 //   two 4-wave blocks per CU, 128x128 / 64x256 tiles (this build) : 100 / 116 / 117 / 118 TFLOP/s
 //   one block per CU, 256x128 / 128x256 / 64x512 tiles (128x64 wave tiles):  90 / 107 / 116 / 115
@@ -422,11 +476,14 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     static bool attr_done = false;
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
+    constexpr int LDS_P = 2 * (3 * 128 * 64 + 128 * 32 * 4);   // 80 KB: two stages of (weight planes + fp32 pixel rows)
     if (!attr_done) {
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0>), LDS_L, "igemm_kernel<128, 128, 2, 0>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0>), LDS_S, "igemm_kernel<64, 256, 4, 0>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 9, 1>), LDS_P, "igemm_kernel<128, 128, 2, 0, 2, 32, 9, 1>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 6, 1>), LDS_P, "igemm_kernel<128, 128, 2, 0, 2, 32, 6, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 9>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 9>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32, 9>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32, 9>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 6>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 6>");
@@ -464,7 +521,12 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     else if (p.stem_kw)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 1>), grid, dim3(256), LDS_S, s, p);
     else if (p.M >= 128) {
-        if (ks32 && split == 9) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 9>), grid, dim3(256), LDS_L, s, p);
+        static const int planes = fm_tune("FM_WPLANES", 1);
+        if (ks32 && split == 9 && p.Wsp && planes)
+            hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 9, 1>), grid, dim3(256), LDS_P, s, p);
+        else if (ks32 && split == 6 && p.Wsp && planes)
+            hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 6, 1>), grid, dim3(256), LDS_P, s, p);
+        else if (ks32 && split == 9) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 9>), grid, dim3(256), LDS_L, s, p);
         else if (ks32 && split == 6) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32, 6>), grid, dim3(256), LDS_L, s, p);
         else if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32>), grid, dim3(256), LDS_L, s, p);
         else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0>), grid, dim3(256), LDS_L, s, p);

@@ -29,6 +29,12 @@ void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList tap
 struct PackJob { long long w_off; float* out; int Co, T, Ci, ntaps; int taps[9]; int blk0; };
 void k_pack_dgrad_all(const float* state, const PackJob* jobs, int njobs, int nblocks, hipStream_t s);
 int pack_job_blocks(int Co, int Ci, int ntaps);      // blocks of one job (32 x 32 tiles per tap); PackJob.blk0 = running sum
+// bf16 planes (split3.h) of [M][32 nkb] fp32 weight matrices for the split-product conv GEMMs, every matrix of a list in ONE
+// launch: job j reads src (or src_base + src_off when src is null) and writes dst_base + dst_off (in 2-byte units) as
+// [M][nkb][3 planes][32]; inside a 32-k block, 8-value chunk g holds k = 4g..4g+3, 16+4g..16+4g+3 (the igemm lane groups' order)
+struct SplitJob { long long src_off; const float* src; long long dst_off; int M, nkb, blk0; };
+void k_split_weights(const float* src_base, unsigned short* dst_base, const SplitJob* jobs, int njobs, int nblocks, hipStream_t s);
+int split_job_blocks(int M, int nkb);
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
 // utils/FedAvg.py:7-14 over K engine-layout states on one GPU: out = ((s0*n0 + s1*n1) + ...) / tot, the reference's
 // left-to-right order with separately rounded products, sums and an IEEE division (bit-identical on fp32 entries)

@@ -16,15 +16,25 @@ typedef unsigned int sp_u32x4 __attribute__((ext_vector_type(4)));
 typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
 
+// a - b as ONE v_sub_f32: beside MFMAs a packed v_pk_add_f32 (which -O3 forms from two adjacent subtractions) costs more
+// issue time than the two plain instructions (MI355X_MICROARCH.md, per-instruction constants)
+__device__ __forceinline__ float sp_sub(float a, float b)
+{
+#ifdef FM_SPLIT_PK
+    return a - b;
+#else
+    float r;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
 // planes of the pair (a, b): element a in the low half of each word, b in the high half
 __device__ __forceinline__ void split3_pair(const sp_f32x2 e, unsigned& H, unsigned& M, unsigned& L)
 {
     const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(e, sp_bf16x2));
-    const sp_f32x2 hf = {__builtin_bit_cast(float, hw << 16), __builtin_bit_cast(float, hw & 0xffff0000u)};
-    const sp_f32x2 r = e - hf;
+    const sp_f32x2 r = {sp_sub(e.x, __builtin_bit_cast(float, hw << 16)), sp_sub(e.y, __builtin_bit_cast(float, hw & 0xffff0000u))};
     const unsigned mw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sp_bf16x2));
-    const sp_f32x2 mf = {__builtin_bit_cast(float, mw << 16), __builtin_bit_cast(float, mw & 0xffff0000u)};
-    const sp_f32x2 l = r - mf;
+    const sp_f32x2 l = {sp_sub(r.x, __builtin_bit_cast(float, mw << 16)), sp_sub(r.y, __builtin_bit_cast(float, mw & 0xffff0000u))};
     H = hw;
     M = mw;
     L = __builtin_bit_cast(unsigned, __builtin_convertvector(l, sp_bf16x2));

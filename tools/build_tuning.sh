@@ -6,7 +6,7 @@ mkdir -p build_tune
 for f in fedmlp_amd/csrc/*.hip; do
   o=build_tune/$(basename "${f%.hip}").o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find fedmlp_amd/csrc include -name '*.h' -newer "$o" | head -1)" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -DFM_TUNING -c "$f" -o "$o" &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -DFM_TUNING $EXTRA_FLAGS -c "$f" -o "$o" &
   fi
 done
 wait

@@ -1,6 +1,9 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-bash tools/prof_stats.sh r4s6_s1 --steps 30 --warmup 3 --no-legs --sustain-s 0 > gpurun_out/r4s6_s1.log 2>&1
-head -24 gpurun_out/r4s6_s1/kernel_stats.csv | cut -c1-150
-timeout 600 python -m pytest tests/test_eval_gpu.py -m gpu -q -x -k "converged" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
-cat gpurun_out/parity_map_converged.json; echo
-python bench.py --legs stage1_fp32_mfma_pipe,conv_fwd_bs256 --sustain-s 3 > gpurun_out/r4s6_bench.json 2> gpurun_out/r4s6_bench.err; tail -3 gpurun_out/r4s6_bench.err; cut -c1-1500 gpurun_out/r4s6_bench.json
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8
+export FEDMLP_HIP_LIB=$PWD/fedmlp_amd/libfedmlp_hip_tune.so
+for w in 1 0; do
+echo "== FM_WPLANES=$w"
+FM_WPLANES=$w python tools/probe_conv.py 256 6,11,16 0,1 2>&1 | grep conv
+FM_WPLANES=$w python bench.py --no-legs --no-cpu-baseline --sustain-s 0 --steps 40 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('r18 planes=$w', d['ms_per_step'])"
+done
+FM_WPLANES=1 FM_MFMA_SPLIT=9 python bench.py --no-legs --no-cpu-baseline --sustain-s 0 --steps 40 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('r18 planes=1 x9', d['ms_per_step'])"
