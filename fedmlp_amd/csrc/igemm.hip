@@ -262,17 +262,50 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 const int sl0 = (lg ^ fsw) << 2, sl1 = ((4 + lg) ^ fsw) << 2;
                 const float* A = As + slot * STG_A + aoff;
                 const float* B = Bs + slot * STG_B + boff;
-                sp_u32x4 ah[FR], am[FR], al[FR], bh[FC], bm[FC], bl[FC];
                 if constexpr (WP) {
-                    // plane rows are 16 floats (64 B); chunk lg of row li + 16 r sits in slot lg ^ ((li>>1)&3)
+                    // Weight planes straight from LDS (plane rows are 16 floats = 64 B; chunk lg of row li + 16 r sits in slot
+                    // lg ^ ((li>>1)&3)); the pixel columns are split one column AHEAD of the MFMAs that use them, and the
+                    // schedule is pinned: two VALU instructions of the next column's split in the shadow of every MFMA (an MFMA
+                    // holds the vector issue port for 8 of its 16 cycles: two plain VALU instructions are what fits).  Left to
+                    // itself the compiler splits every column up front (6 VALU per MFMA at first, then 77 bare MFMAs).
+                    constexpr int SPLIT_VALU = 44;                       // 4 pairs x (3 cvt_pk + 2 shl + 2 and + 4 sub)
+                    constexpr int COL_MFMA = FR * SP;
+                    static_assert(2 * COL_MFMA >= SPLIT_VALU, "a column's MFMAs cover the next column's split");
                     const float* Ap = As + slot * STG_A + (wm * (16 * FR) + li) * 16 + ((lg ^ ((li >> 1) & 3)) << 2);
+                    sp_u32x4 ah[FR], am[FR], al[FR], bh[2], bm[2], bl[2];
+                    f32x4 b0[FC], b1[FC];
+#pragma unroll
+                    for (int c = 0; c < FC; ++c) {
+                        b0[c] = *reinterpret_cast<const f32x4*>(B + c * 16 * KS + sl0);
+                        b1[c] = *reinterpret_cast<const f32x4*>(B + c * 16 * KS + sl1);
+                    }
 #pragma unroll
                     for (int r = 0; r < FR; ++r) {
                         ah[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256);
                         am[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256 + BM * 16);
                         al[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256 + 2 * BM * 16);
                     }
-                } else
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3 * FR + 2 * FC, 0);
+                    split3(b0[0], b1[0], bh[0], bm[0], bl[0]);
+                    __builtin_amdgcn_sched_group_barrier(0x002, SPLIT_VALU, 0);
+#pragma unroll
+                    for (int c = 0; c < FC; ++c) {
+                        if (c + 1 < FC) split3(b0[c + 1], b1[c + 1], bh[(c + 1) & 1], bm[(c + 1) & 1], bl[(c + 1) & 1]);
+#pragma unroll
+                        for (int r = 0; r < FR; ++r)
+                            acc[r][c] = mfma_split<SP>(ah[r], am[r], al[r], bh[c & 1], bm[c & 1], bl[c & 1], acc[r][c]);
+                        if (c + 1 < FC) {
+#pragma unroll
+                            for (int i = 0; i < SPLIT_VALU / 2; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, COL_MFMA - SPLIT_VALU / 2, 0);
+                        } else
+                            __builtin_amdgcn_sched_group_barrier(0x008, COL_MFMA, 0);
+                    }
+                } else {
+                sp_u32x4 ah[FR], am[FR], al[FR], bh[FC], bm[FC], bl[FC];
 #pragma unroll
                 for (int r = 0; r < FR; ++r)
                     split3(*reinterpret_cast<const f32x4*>(A + r * 16 * KS + sl0),
@@ -286,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
                     for (int c = 0; c < FC; ++c)
                         acc[r][c] = mfma_split<SP>(ah[r], am[r], al[r], bh[c], bm[c], bl[c], acc[r][c]);
+                }
             } else
 #pragma unroll
             for (int h = 0; h < KS / 16; ++h) {
