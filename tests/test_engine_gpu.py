@@ -369,3 +369,33 @@ def test_relu_mask_from_conv_output_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
+
+
+def test_step_in_the_three_product_forms(monkeypatch, eng):
+    """FM_MFMA_SPLIT = 6 (the default: six exact bf16 partial products per fp32 product on the bf16 matrix pipe), 9 (all nine) and
+    0 (the fp32 matrix pipe): each form's stage-1 step matches the fp32 CPU oracle under the engine's own ReLU masks to the same
+    5e-5 (test_step_stage1 is this check under the default), each form is run-to-run bit-identical, and the losses of the three
+    forms agree to 1e-6.  (Two forms are NOT compared gradient by gradient: at 16 images x 64 x 64 one ReLU input within rounding
+    of zero flips between two roundings and moves single tensors by 2-3 % -- the reason the oracle comparisons share the masks.)"""
+    from fedmlp_amd import _lib
+    (x1, x2), y = _data(6, 47, views=2)
+    mask = [0.0, 1.0, 0.0, 0.0, 0.0]
+    outs = {}
+    for mode in ("9", "0", "6", "6"):
+        monkeypatch.setenv("FM_MFMA_SPLIT", mode)
+        assert _lib.load().fm_mfma_products() == int(mode)
+        if mode not in outs:
+            _stage1_step_check(eng, f"stage1, FM_MFMA_SPLIT={mode}")
+        _load(eng)
+        eng.teacher_snapshot()
+        lo = torch.zeros(1, device="cuda")
+        eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+        res = (lo.item(), eng.debug_get_grads().copy())
+        if mode in outs:                                   # second run of the default form: the same bits
+            assert outs[mode][0] == res[0]
+            np.testing.assert_array_equal(outs[mode][1], res[1])
+        outs[mode] = res
+    monkeypatch.delenv("FM_MFMA_SPLIT")
+    assert _lib.load().fm_mfma_products() == 6
+    for mode in ("6", "9"):
+        assert abs(outs[mode][0] - outs["0"][0]) <= 1e-6 * abs(outs["0"][0]), (mode, outs[mode][0], outs["0"][0])
