@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 # kernel families of fm_profile_read (names as rocprofv3 prints them for the ResNet-18 workload, where every
 # conv has Ci % 32 == 0 and runs the 32-k-stage instantiation)
-KERNEL_NAMES_F32 = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,256,4,0,2,32>",
+KERNEL_NAMES_F32 = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,192,4,0,2,32>",
                     2: "igemm_kernel<64,256,4,2,4,16>", 3: "wgrad_kernel<128,128,2,4>", 4: "wgrad_kernel<64,192,4,3>",
                     5: "wgrad_kernel<64,192,4,3> [7x7 stem launch]"}
 NFAM = len(KERNEL_NAMES_F32)
@@ -70,7 +70,7 @@ def kernel_names():
     if not sp:
         return dict(KERNEL_NAMES_F32)
     # the 7x7 stem forward (16-k stages) stays on the fp32 pipe
-    return {0: f"igemm_kernel<128,128,2,0,2,32,{sp}>", 1: f"igemm_kernel<64,256,4,0,2,32,{sp}>",
+    return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},1>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},1>",
             2: "igemm_kernel<64,256,4,2,4,16>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
             5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
 

@@ -193,7 +193,7 @@ bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s);    // false 
 int wgrad_tile_n(int M, int Nw);
 // 1x1 stride-1 convs with min(M, Nw) <= 128: returns the splits written to p.slab, 0 = not handled
 int launch_wgrad_skinny(const WgradParams& p, size_t slab_floats, hipStream_t s);
-int igemm_tile_n(int M);   // pixel-tile width the igemm uses for this M
+int igemm_tile_n(int M, bool stem = false);   // pixel-tile width the igemm uses for this M (the stem kernels: 256)
 int igemm_tile_m(int M);
 
 // hipFuncSetAttribute with the failure reported (a kernel whose dynamic-LDS limit was not raised fails at its

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
     const int K = p.Ci, nkk = K >> 4;
     const int m0 = blockIdx.x * MT;
     const int grp = blockIdx.y / blocks_per_group, pb_idx = blockIdx.y - grp * blocks_per_group;
-    const int BNv = p.M >= 128 ? 128 : 256;                         // igemm's pixel-tile width for this M (statistics layout)
+    const int BNv = p.M >= 128 ? 128 : 192;                         // igemm's pixel-tile width for this M (statistics layout)
     const int npix = p.imgs_per_group * p.Hg * p.Wg;                // pixels per group
     const int vt0 = pb_idx * vt_per_block;
     const int pb = vt0 * BNv, pe = min(npix, pb + vt_per_block * BNv);
@@ -214,7 +214,7 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     // traffic, but no more -- small blocks launched in order keep the concurrently running ones on
     // neighbouring memory (DRAM locality, tools/ew_bw.hip)
     static const int vt_env = fm_tune("FM_STREAM_VT", 0);
-    const int bnv = p.M >= 128 ? 128 : 256;
+    const int bnv = igemm_tile_n(p.M);
     int vt = std::max(1, (int)((10LL * MT * p.Ci + (long long)bnv * (p.Ci + MT) - 1) / ((long long)bnv * (p.Ci + MT))));
     if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;

@@ -401,19 +401,19 @@ int build_tables(fm_engine* e)
     if (!jobs.empty())
         HIPCHK(hipMemcpy(e->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
     if (e->model == 0 && !e->precision) {
-        // weight planes for the GEMMs with >= 128 output rows and whole 32-k blocks per tap (igemm.hip, WP form)
+        // weight planes for the GEMMs with whole 64-row tiles and whole 32-k blocks per tap (igemm.hip, WP form)
         std::vector<SplitJob> jf, jd;
         long long off_f = 0, off_d = 0;
         int bf = 0, bd = 0;
         for (auto& c : e->convs) {
             if (c.cin == 3) continue;
-            if (c.cout_p >= 128 && c.cin_p % 32 == 0) {
+            if (c.cout_p % 64 == 0 && c.cin_p % 32 == 0) {
                 c.sp_off = off_f;
                 jf.push_back({(long long)c.w_off, nullptr, off_f, c.cout_p, c.Kw / 32, bf});
                 bf += split_job_blocks(c.cout_p, c.Kw / 32);
                 off_f += (long long)c.cout_p * c.Kw * 3;
             }
-            if (c.cin_p >= 128 && c.cout_p % 32 == 0)
+            if (c.cin_p % 64 == 0 && c.cout_p % 32 == 0)
                 for (int k = 0; k < c.ncls; ++k) {
                     DgradClass& d = c.cls[k];
                     const int K = d.taps.n * c.cout_p;
@@ -641,7 +641,7 @@ int alloc_workspaces(fm_engine* e)
     for (auto& c : e->convs) {
         AALLOC(c.y, B * c.hout * c.wout * c.cout_p);
         if (c.cin == 3 && e->precision) AALLOC(e->stem_col, B * c.hout * c.wout * c.Kw);   // bf16 im2col of the input batch
-        size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout_p) - 1) / igemm_tile_n(c.cout_p) + 2;
+        size_t tiles = (B * c.hout * c.wout + igemm_tile_n(c.cout_p, c.cin == 3) - 1) / igemm_tile_n(c.cout_p, c.cin == 3) + 2;
         if (e->precision) tiles = std::max<size_t>(tiles, B * c.hout * c.wout / 128 + 4);   // pw_blocks(): >= 128 pixels per block
         max_stats = std::max(max_stats, (tiles + 2 * 32) * 2 * c.cout_p);   // + folded partials
         max_slab = std::max(max_slab, c.w_numel);
@@ -899,7 +899,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     p.os = 1; p.oh0 = 0; p.ow0 = 0;
     p.imgs_per_group = imgs / groups;
     p.tilesM = (c.cout_p + igemm_tile_m(c.cout_p) - 1) / igemm_tile_m(c.cout_p);
-    const int bn = igemm_tile_n(c.cout_p);
+    const int bn = igemm_tile_n(c.cout_p, c.cin == 3);
     p.tilesN = (p.imgs_per_group * c.hout * c.wout + bn - 1) / bn;
     p.relu = relu;           // 0 none, 1 relu, 2 swish
     ProfScope ps(e, c.cin == 3 ? 2 : (c.cout_p >= 128 ? 0 : 1), 2.0 * c.macs_per_img * imgs);
@@ -911,7 +911,7 @@ int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
     const Conv& c = e->convs[ci];
     if (e->precision && (c.k == 1 || c.cin == 3))
         return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro, c.hout * c.wout);
-    const int bn = igemm_tile_n(c.cout_p);
+    const int bn = igemm_tile_n(c.cout_p, c.cin == 3);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
 
@@ -2457,6 +2457,7 @@ int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, co
     Conv& c = e->convs[conv];
     if (c.stem3 && x_dev)       // the packed stem reads the framed copy of its [imgs][H][W][3] input
         k_frame_nhwc3(x_dev, e->x3, imgs, c.hin, c.win, c.Hp, c.Wp, 3, 3, 1, e->st);
+    ensure_packed(e);           // the forward reads the weight planes, the data gradient the transposed packs
     if (op == 0) {
         ARGCHK(x_dev, "x");
         conv_fwd(e, conv, e->state, x_dev, out_dev, imgs, groups, nullptr, nullptr, nullptr, 0,

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     static_assert(WP == 0 || (SP != 0 && STEM == 0 && BM % 64 == 0), "weight planes: split form, no stem");
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
-    static_assert(FR * FC == 16 || FR * FC == 32, "wave tile is 64x64 (or 128x64 / 64x128)");
+    static_assert(FR * FC == 12 || FR * FC == 16 || FR * FC == 32, "wave tile is 64x64, 64x48 (or 128x64 / 64x128)");
     static_assert(KS == 16 || (KS == 32 && STEM == 0), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
     constexpr int D = NS - 1;                   // LDS ring of NS stages of KS k; DMA runs D steps ahead
     constexpr int STG_A = WP ? 3 * BM * 16 : BM * KS, STG_B = BN * KS;   // floats per stage (planes: 3 x BM x 64 B)
@@ -501,7 +501,9 @@ void k_split_weights(const float* src_base, unsigned short* dst_base, const Spli
 //   one block per CU, 256x128 / 128x256 / 64x512 tiles (128x64 wave tiles):  90 / 107 / 116 / 115
 // for layer1 / layer2 / layer3 / layer4; the kernel template supports both.
 int igemm_tile_m(int M) { return M >= 128 ? 128 : 64; }
-int igemm_tile_n(int M) { return M >= 128 ? 128 : 256; }
+// 64-row layers: 192 pixels (wave tile 64 x 48) -- with the weight planes a 64 x 256 tile's two stages (88 KB) no longer fit
+// twice into a CU's LDS, 64 x 192 takes 72 KB; the stem kernels keep 64 x 256
+int igemm_tile_n(int M, bool stem) { return M >= 128 ? 128 : (stem ? 256 : 192); }
 int igemm_max_blocks() { return 512; }    // 2 blocks per CU x 256 CUs (64-80 KB LDS each)
 
 void launch_igemm(IgemmParams p, int groups, hipStream_t s)
@@ -511,17 +513,21 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     constexpr int LDS_L = 4 * (128 + 128) * 16 * 4;     // 64 KB
     constexpr int LDS_S = 4 * (64 + 256) * 16 * 4;      // 80 KB
     constexpr int LDS_P = 2 * (3 * 128 * 64 + 128 * 32 * 4);   // 80 KB: two stages of (weight planes + fp32 pixel rows)
+    constexpr int LDS_T = 4 * (64 + 192) * 16 * 4;             // 64 KB: 64 x 192 tiles
+    constexpr int LDS_PT = 2 * (3 * 64 * 64 + 192 * 32 * 4);   // 72 KB: 64 x 192 with weight planes
     if (!attr_done) {
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0>), LDS_L, "igemm_kernel<128, 128, 2, 0>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0>), LDS_S, "igemm_kernel<64, 256, 4, 0>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 192, 4, 0>), LDS_T, "igemm_kernel<64, 192, 4, 0>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 192, 4, 0, 2, 32>), LDS_T, "igemm_kernel<64, 192, 4, 0, 2, 32>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 192, 4, 0, 2, 32, 9>), LDS_T, "igemm_kernel<64, 192, 4, 0, 2, 32, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 192, 4, 0, 2, 32, 6>), LDS_T, "igemm_kernel<64, 192, 4, 0, 2, 32, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 192, 4, 0, 2, 32, 9, 1>), LDS_PT, "igemm_kernel<64, 192, 4, 0, 2, 32, 9, 1>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 192, 4, 0, 2, 32, 6, 1>), LDS_PT, "igemm_kernel<64, 192, 4, 0, 2, 32, 6, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 9, 1>), LDS_P, "igemm_kernel<128, 128, 2, 0, 2, 32, 9, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 6, 1>), LDS_P, "igemm_kernel<128, 128, 2, 0, 2, 32, 6, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 9>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 9>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32, 9>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32, 9>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 6>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 6>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 0, 2, 32, 6>), LDS_S, "igemm_kernel<64, 256, 4, 0, 2, 32, 6>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 1>), LDS_S, "igemm_kernel<64, 256, 4, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 2>), LDS_S, "igemm_kernel<64, 256, 4, 2>");
         attr_done = true;
@@ -565,12 +571,15 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
         else if (ks32) hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0, 2, 32>), grid, dim3(256), LDS_L, s, p);
         else hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 0>), grid, dim3(256), LDS_L, s, p);
     }
-    else if (ks32 && split == 9)
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32, 9>), grid, dim3(256), LDS_S, s, p);
-    else if (ks32 && split == 6)
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32, 6>), grid, dim3(256), LDS_S, s, p);
-    else if (ks32)
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0, 2, 32>), grid, dim3(256), LDS_S, s, p);
-    else
-        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 0>), grid, dim3(256), LDS_S, s, p);
+    else {
+        static const int planes = fm_tune("FM_WPLANES", 1);
+        if (ks32 && split == 9 && p.Wsp && planes)
+            hipLaunchKernelGGL((igemm_kernel<64, 192, 4, 0, 2, 32, 9, 1>), grid, dim3(256), LDS_PT, s, p);
+        else if (ks32 && split == 6 && p.Wsp && planes)
+            hipLaunchKernelGGL((igemm_kernel<64, 192, 4, 0, 2, 32, 6, 1>), grid, dim3(256), LDS_PT, s, p);
+        else if (ks32 && split == 9) hipLaunchKernelGGL((igemm_kernel<64, 192, 4, 0, 2, 32, 9>), grid, dim3(256), LDS_T, s, p);
+        else if (ks32 && split == 6) hipLaunchKernelGGL((igemm_kernel<64, 192, 4, 0, 2, 32, 6>), grid, dim3(256), LDS_T, s, p);
+        else if (ks32) hipLaunchKernelGGL((igemm_kernel<64, 192, 4, 0, 2, 32>), grid, dim3(256), LDS_T, s, p);
+        else hipLaunchKernelGGL((igemm_kernel<64, 192, 4, 0>), grid, dim3(256), LDS_T, s, p);
+    }
 }

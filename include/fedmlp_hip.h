@@ -261,7 +261,7 @@ int fm_mfma_products(void);
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the
  * engine's stream; fm_profile_read drains them (synchronises) and returns, per
- * kernel (family 0 = igemm_kernel<128,128,2,0,...>, 1 = igemm_kernel<64,256,4,0,...>,
+ * kernel (family 0 = igemm_kernel<128,128,2,0,...>, 1 = igemm_kernel<64,192,4,0,...>,
  * 2 = igemm_kernel<64,256,4,2,...> (7x7 stem): conv forward + data gradient; 3 = wgrad_kernel<128,128,2,4>,
  * 4 = wgrad_kernel<64,192,4,3> (64-channel 3x3 layers) and the skinny 1x1 wgrad, 5 = the 7x7 stem's weight
  * gradient), the launch count, total milliseconds and algorithmic FLOPs since the last read. */
