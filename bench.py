@@ -48,12 +48,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# kernel families of fm_profile_read (names as rocprofv3 prints them for the ResNet-18 workload, where every
-# conv has Ci % 32 == 0 and runs the 32-k-stage instantiation)
-KERNEL_NAMES_F32 = {0: "igemm_kernel<128,128,2,0,2,32>", 1: "igemm_kernel<64,192,4,0,2,32>",
-                    2: "igemm_kernel<64,256,4,2,4,16>", 3: "wgrad_kernel<128,128,2,4>", 4: "wgrad_kernel<64,192,4,3>",
-                    5: "wgrad_kernel<64,192,4,3> [7x7 stem launch]"}
-NFAM = len(KERNEL_NAMES_F32)
+NFAM = 6                              # kernel families of fm_profile_read (kernel_names())
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense
 
@@ -66,12 +61,13 @@ def mfma_products():
 
 
 def kernel_names():
+    """kernel families of fm_profile_read, named as rocprofv3 prints them for the ResNet-18 workload (every non-stem conv has
+    Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes).  The
+    7x7 stem forward (16-k stages) stays on the fp32 pipe."""
     sp = mfma_products()
-    if not sp:
-        return dict(KERNEL_NAMES_F32)
-    # the 7x7 stem forward (16-k stages) stays on the fp32 pipe
-    return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},1>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},1>",
-            2: "igemm_kernel<64,256,4,2,4,16>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
+    wp = 1 if sp else 0
+    return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},{wp}>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},{wp}>",
+            2: "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
             5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
 
 
