@@ -242,20 +242,31 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
 #pragma unroll
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        // LA2 (weight-plane form): a wave holds ALL its fragments of a stage in registers before the first MFMA, so the stage's
+        // slot is free as soon as everyone has read it -- a second barrier right after the reads lets the DMA of step s+2 start
+        // at the TOP of step s: two stages of lookahead from a two-stage ring (a 96-MFMA stage is ~1 us, no longer enough to
+        // cover a MALL / HBM round trip with one)
+        constexpr bool LA2 = WP != 0 && NS == 2;
         issue(k0);
+        if constexpr (LA2) {
+            if (k0 + 1 < k1) issue(k0 + 1);
+        } else {
 #pragma unroll
-        for (int d = 1; d < D; ++d)
-            if (k0 + d < k1) issue(k0 + d);
+            for (int d = 1; d < D; ++d)
+                if (k0 + d < k1) issue(k0 + d);
+        }
         for (int s = k0; s < k1; ++s) {
             // my DMA of step s has landed once at most the younger steps' instructions are outstanding
-            const int younger = min(D - 1, k1 - 1 - s);
+            const int younger = LA2 ? min(1, k1 - 1 - s) : min(D - 1, k1 - 1 - s);
             if (D >= 4 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
             else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // everyone's step-s data landed; everyone finished reading step s-1
             asm volatile("" ::: "memory");
-            if (s + D < k1) issue(s + D);      // refill the slot step s-1 just vacated
+            if constexpr (!LA2) {
+                if (s + D < k1) issue(s + D);      // refill the slot step s-1 just vacated
+            }
             const int slot = (s - k0) % NS;
             if constexpr (SP != 0) {
                 // lane group lg supplies k = 4lg..4lg+3 and 16+4lg..16+4lg+3 of the stage as its 8 k-slots (same for A and B)
@@ -285,7 +296,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                         am[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256 + BM * 16);
                         al[r] = *reinterpret_cast<const sp_u32x4*>(Ap + r * 256 + 2 * BM * 16);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3 * FR + 2 * FC, 0);
+                    if constexpr (LA2) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();      // every wave holds its fragments of step s: the slot is free
+                        asm volatile("" ::: "memory");
+                        if (s + 2 < k1) issue(s + 2);
+                    } else
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3 * FR + 2 * FC, 0);
                     split3(b0[0], b1[0], bh[0], bm[0], bl[0]);
                     __builtin_amdgcn_sched_group_barrier(0x002, SPLIT_VALU, 0);
 #pragma unroll

@@ -1,10 +1,9 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-bash tools/prof_stats.sh r4s6b_s1 --steps 30 --warmup 3 --no-legs --sustain-s 0 > gpurun_out/r4s6b_s1.log 2>&1
-python - <<'PY'
-import csv
-rows=list(csv.DictReader(open('gpurun_out/r4s6b_s1/kernel_stats.csv')))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-print('total ms/step', tot/33/1e6)
-for r in rows[:24]:
-    print(r['Name'][:64].ljust(64), r['Calls'].rjust(5), '%8.3f ms/step' % (float(r['TotalDurationNs'])/33/1e6), '%8.1f us' % (float(r['AverageNs'])/1e3), r['Percentage'])
-PY
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py -m gpu -q -x 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -5
+python tools/probe_conv.py 256 1,6,11,16 0,1 2>&1 | grep conv
+echo prev; FEDMLP_HIP_LIB=$PWD/fedmlp_amd/libfedmlp_hip_prev.so python tools/probe_conv.py 256 1,6,11,16 0,1 2>&1 | grep conv
+b() { python bench.py --no-legs --no-cpu-baseline --sustain-s 0 --steps 60 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'])"; }
+for i in 1 2 3; do
+b new
+FEDMLP_HIP_LIB=$PWD/fedmlp_amd/libfedmlp_hip_prev.so b prev
+done
