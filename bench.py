@@ -62,12 +62,11 @@ def mfma_products():
 
 def kernel_names():
     """kernel families of fm_profile_read, named as rocprofv3 prints them for the ResNet-18 workload (every non-stem conv has
-    Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes).  The
-    7x7 stem forward (16-k stages) stays on the fp32 pipe."""
+    Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes)."""
     sp = mfma_products()
     wp = 1 if sp else 0
     return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},{wp}>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},{wp}>",
-            2: "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
+            2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>" if sp else "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
             5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
 
 

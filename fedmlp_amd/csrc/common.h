@@ -166,6 +166,9 @@ struct IgemmParams {
     // split-product form (split3.h), M >= 128: the bf16 planes of W made by k_split_weights, [M][nsteps of 32 k][3 planes][32]
     // (192 B per 32-k block, the k order inside a block as the kernel's lane groups take it); null = split W in the kernel
     const unsigned short* Wsp = nullptr;
+    // floats per row of W when that is not nsteps * KS (the packed stem in 32-k stages: rows of 176 floats walked as 6 x 32 --
+    // the 16 floats past a row's end meet the zero-page chunks of X); 0 = nsteps * KS
+    int wrow = 0;
 };
 
 // Weight-gradient GEMM: dW[m][n] = sum_p dY[p][m] * Xg[p][n], split over p.

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     constexpr int WM = 4 / WN;
     constexpr int FR = BM / WM / 16, FC = BN / WN / 16;   // MFMA tiles per wave (rows, cols)
     static_assert(FR * FC == 12 || FR * FC == 16 || FR * FC == 32, "wave tile is 64x64, 64x48 (or 128x64 / 64x128)");
-    static_assert(KS == 16 || (KS == 32 && STEM == 0), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
+    static_assert(KS == 16 || (KS == 32 && (STEM == 0 || STEM == 2)), "K per stage is 16, or 32 (a whole 128-B line per DMA row)");
     constexpr int D = NS - 1;                   // LDS ring of NS stages of KS k; DMA runs D steps ahead
     constexpr int STG_A = WP ? 3 * BM * 16 : BM * KS, STG_B = BN * KS;   // floats per stage (planes: 3 x BM x 64 B)
     constexpr int CPR = KS / 4;                 // 16-B chunks per row of a stage (4 or 8)
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
     const int fsw = (li >> 1) & SM;
 
     const int nsteps = p.nsteps;                // steps of KS k
-    const int Ktot = nsteps * KS;
+    const int Ktot = p.wrow ? p.wrow : nsteps * KS;      // floats per row of W
     const int HWg = p.Hg * p.Wg;
     const int npix = p.imgs_per_group * HWg;
     const int tiles_pg = p.tilesM * p.tilesN;
@@ -184,16 +184,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
               if constexpr (STEM == 2) {
                 // packed 7x7 stem: chunk c of K = floats 4j .. 4j+3 of kernel row kh's 24-float window, which starts at the
                 // framed pixel (2 oh + kh, 2 ow): no bounds to check, chunks past the 42 real ones read the zero page
-                const int c = 4 * s + (csrc >> 2);
-                const int kh = c / 6, j = c - 6 * kh;
-                const bool cv = c < 42;
-                const int koff = s * 16;
+                const int koff = s * KS;
 #pragma unroll
                 for (int q = 0; q < GA; ++q)
                     __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
                                                      (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
 #pragma unroll
                 for (int q = 0; q < GB; ++q) {
+                    const int c = CPR * s + (csrc_of(wave * GB + q) >> 2);       // (KS == 16: the same chunk for every group)
+                    const int kh = c / 6, j = c - 6 * kh;
+                    const bool cv = c < 42;
                     const float* src = (rv[q] && cv) ? p.X + (size_t)(xb[q] + ((ih0[q] + kh) * p.Wi + iw0[q]) * 3 + 4 * j) : p.zeros;
                     __builtin_amdgcn_global_load_lds(src, (lds_void*)(Bs + slot * STG_B + (wave * GB + q) * 256), 16, 0, 0);
                 }
@@ -547,6 +547,8 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<128, 128, 2, 0, 2, 32, 6>), LDS_L, "igemm_kernel<128, 128, 2, 0, 2, 32, 6>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 1>), LDS_S, "igemm_kernel<64, 256, 4, 1>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 2>), LDS_S, "igemm_kernel<64, 256, 4, 2>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 2, 2, 32, 9>), LDS_S, "igemm_kernel<64, 256, 4, 2, 2, 32, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&igemm_kernel<64, 256, 4, 2, 2, 32, 6>), LDS_S, "igemm_kernel<64, 256, 4, 2, 2, 32, 6>");
         attr_done = true;
     }
     // K per LDS stage: 32 (two stages) stages a whole 128-B line per DMA row -- the L1 hands out whole
@@ -554,6 +556,10 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     static const int ks32_mode = fm_tune("FM_KS32", 2);
     const bool ks32 = !p.stem_kw && p.Ci % 32 == 0 && (ks32_mode == 2 || (ks32_mode == 1 && p.M < 128));
     if (ks32) p.nsteps /= 2;           // the caller counts 16-k steps
+    const int split = fm_mfma_split();
+    // the packed 7x7 stem in the split form: 11 steps of 16 k become 6 of 32, the rows of W keep their 176 floats
+    const bool stem_split = p.stem_kw && p.stem3 && split != 0;
+    if (stem_split) { p.wrow = p.nsteps * 16; p.nsteps = (p.nsteps + 1) / 2; }
     const long long T = (long long)p.tilesM * p.tilesN * groups;
     p.total_steps = T * p.nsteps;
     p.tap_minor = 1;
@@ -572,8 +578,11 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, igemm_max_blocks()), p.total_steps);
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
     dim3 grid(nblk);
-    const int split = fm_mfma_split();
-    if (p.stem_kw && p.stem3)
+    if (stem_split && split == 9)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 2, 2, 32, 9>), grid, dim3(256), LDS_S, s, p);
+    else if (stem_split)
+        hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 2, 2, 32, 6>), grid, dim3(256), LDS_S, s, p);
+    else if (p.stem_kw && p.stem3)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 2>), grid, dim3(256), LDS_S, s, p);
     else if (p.stem_kw)
         hipLaunchKernelGGL((igemm_kernel<64, 256, 4, 1>), grid, dim3(256), LDS_S, s, p);
