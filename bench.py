@@ -15,10 +15,15 @@ usage: python bench.py --gpus N --steps K --warmup W
   (python -m torch.distributed.run ... bench.py, one rank per GPU) before touching
   the GPU and exits with their code.  Rank 0 prints ONE JSON line.
 
+Arithmetic: operands, accumulators and stored tensors are fp32 (`dtype` "f32"); the conv GEMMs form every fp32 product as
+six exact bf16 partial products on the bf16 matrix pipe (csrc/split3.h; as close to float64 as the fp32-MFMA
+kernels, tests/test_kernels_gpu.py).  `roofline.peak` is that form's roofline (bf16 dense peak / 6); FM_MFMA_SPLIT=0 runs
+the fp32 matrix pipe instead, and the default line times that too (`legs.stage1_fp32_mfma_pipe`, `value_on_fp32_mfma_pipe`).
+
 The ONE line of a default N = 1 run carries, after the headline fields:
   sustained      the same step repeated back to back for >= --sustain-s seconds (steady clock)
   legs           every other BASELINE config and BASELINE.md section-4 leg, each with its own
-                 `roofline` and `cpu_baseline` (oracle on this host): conv forward bs 256, stage 1
+                 `roofline` and `cpu_baseline` (oracle on this host): the headline step on the fp32 pipe, conv forward bs 256, stage 1
                  with C = 14, LocalUpdate.train, stage-2 step, EfficientNet-B0 fp32 bs 256 / bf16
                  bs 512, prototype pass over N = 5 000, cosine tagging + top-k at N = 5 000 for
                  C = 5 / 14, FedAvg of 8 client states.  --no-legs skips them.
@@ -810,6 +815,12 @@ def main():
             if out.get("cpu_baseline"):
                 best = [out["cpu_baseline"]["threads"]]          # the legs' CPU baselines run at the headline's best thread count
             out["legs"] = run_legs(args, dev, best or thread_candidates(args.cpu_threads)[:1])
+            f32 = out["legs"].get("stage1_fp32_mfma_pipe") or {}
+            if "value" in f32:
+                # the headline metric with the conv GEMMs on the fp32 matrix pipe (FM_MFMA_SPLIT=0), for a reader who wants
+                # the figure of that arithmetic beside `value` without digging into `legs`
+                out["value_on_fp32_mfma_pipe"] = {"value": f32["value"], "ms_per_step": f32["ms_per_step"],
+                                                  "roofline_frac_of_fp32_mfma_peak": (f32.get("roofline") or {}).get("frac")}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
