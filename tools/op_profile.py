@@ -63,8 +63,9 @@ T = 2 * B                                      # images per train-mode / teacher
 
 
 def nbytes(op, blk):
-    i = blk % 100 if blk >= 0 else -1
-    if not (0 <= i < 16) or blk in (100, 300, 500):
+    # labels (engine.hip): train forward @0..@15, eval forward @201..@216, backward @400..@415 (heads @100 / @300 / @500, stem @-1 / @399)
+    i = blk if 0 <= blk < 16 else blk - 201 if 201 <= blk <= 216 else blk - 400 if 400 <= blk <= 415 else -1
+    if not (0 <= i < 16):
         return None
     b = blocks[i]
     E, Ep, S, Sp = b["hin"] ** 2 * b["ce"], b["hout"] ** 2 * b["ce"], b["hin"] ** 2 * b["cin"], b["hout"] ** 2 * b["cout"]
