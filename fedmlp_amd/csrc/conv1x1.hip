@@ -19,10 +19,11 @@
 #include <algorithm>
 
 #include "common.h"
+#include "split3.h"
 
 namespace {
 
-constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
+[[maybe_unused]] constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
 
 // RT = 16-row MFMA tiles per block (MT = 16*RT output channels), P = 16-pixel groups per wave iteration:
 // the shipped instantiation is <4,2> = 64 channels x 32 pixels
@@ -30,9 +31,14 @@ constexpr int KB = 4;             // 16-k chunks preloaded per pass (64 k)
 // data-gradient launches do not carry the 32 sum registers (3 -> 4 waves per SIMD)
 // GATE: 1 = the operand is multiplied by a per-image, per-channel gate on load (IgemmParams::gate); 2 = BN affine + Swish of
 // the operand first (IgemmParams::psc / psh, per statistics group): a_s = swish(bn1(y_d)) * gate is never written (train forward)
-template <int RT, int P, bool STATS, int GATE = 0>
+// SP = 6 / 9: the fp32 products as exact bf16 partial products (split3.h): the weight slice is split ONCE per block on its way
+// into LDS ([K/32][3 planes][MT rows][64 B], chunk g of a row = k 4g..4g+3, 16+4g..16+4g+3 of the 32-k block, slot g ^ ((row>>1)&3)),
+// a lane splits its two 16-B pixel pieces of a 32-k block in registers (after the gate / BN + Swish prologue).  K <= 192
+// (the planes take 1.5x the fp32 bytes: 72 KB there).
+template <int RT, int P, bool STATS, int GATE = 0, int SP = 0>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p, int vt_per_block, int blocks_per_group)
 {
+#if __HIP_DEVICE_COMPILE__
     constexpr int MT = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float As[];     // [K/16][MT][16], chunk c of row r in slot c ^ ((r>>1)&3)
     const int tid = threadIdx.x;
@@ -49,6 +55,26 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
 
     // ---- stage the weight slice once ---------------------------------------------------------------
     const int cpr = K >> 2;                                         // 16-B chunks per weight row
+    const int nk32 = (K + 31) >> 5;
+    unsigned char* const Ap = reinterpret_cast<unsigned char*>(As);
+    if constexpr (SP != 0) {
+        for (int idx = tid; idx < MT * nk32 * 4; idx += 256) {
+            const int row = idx / (nk32 * 4), rem = idx - row * (nk32 * 4);
+            const int kb32 = rem >> 2, g = rem & 3;
+            const int ka = 32 * kb32 + 4 * g, kc = ka + 16;
+            const bool rv = m0 + row < p.M;
+            const float* wr = p.W + (size_t)(rv ? m0 + row : 0) * K;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 x0 = (rv && ka < K) ? *reinterpret_cast<const f32x4*>(wr + ka) : z;
+            const f32x4 x1 = (rv && kc < K) ? *reinterpret_cast<const f32x4*>(wr + kc) : z;
+            sp_u32x4 H, M, L;
+            split3(x0, x1, H, M, L);
+            unsigned char* dst = Ap + ((size_t)(kb32 * 3) * MT + row) * 64 + ((g ^ ((row >> 1) & 3)) << 4);
+            *reinterpret_cast<sp_u32x4*>(dst) = H;
+            *reinterpret_cast<sp_u32x4*>(dst + MT * 64) = M;
+            *reinterpret_cast<sp_u32x4*>(dst + 2 * MT * 64) = L;
+        }
+    } else
     for (int idx = tid; idx < MT * cpr; idx += 256) {
         const int row = idx / cpr, ch = idx - row * cpr;
         const int kk = ch >> 2, c4 = ch & 3;
@@ -103,6 +129,27 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
         for (int kb = 0; kb < nkk; kb += KB) {
             f32x4 b[P][KB];
             load_b(it, b, kb);
+            if constexpr (SP != 0) {
+#pragma unroll
+                for (int pp = 0; pp < KB / 2; ++pp) {
+                    if (kb + 2 * pp < nkk) {
+                        sp_u32x4 bh[P], bm[P], bl[P];
+#pragma unroll
+                        for (int g = 0; g < P; ++g) split3(b[g][2 * pp], b[g][2 * pp + 1], bh[g], bm[g], bl[g]);
+                        const unsigned char* A3 = Ap + ((size_t)(((kb >> 1) + pp) * 3) * MT + li) * 64 + ((lg ^ ((li >> 1) & 3)) << 4);
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) {
+                            if (r < nrt) {
+                                const sp_u32x4 ah = *reinterpret_cast<const sp_u32x4*>(A3 + r * 1024);
+                                const sp_u32x4 am = *reinterpret_cast<const sp_u32x4*>(A3 + r * 1024 + MT * 64);
+                                const sp_u32x4 al = *reinterpret_cast<const sp_u32x4*>(A3 + r * 1024 + 2 * MT * 64);
+#pragma unroll
+                                for (int g = 0; g < P; ++g) acc[r][g] = mfma_split<SP>(ah, am, al, bh[g], bm[g], bl[g], acc[r][g]);
+                            }
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 if (kb + k >= nkk) break;
@@ -181,6 +228,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const IgemmParams p
             }
         }
     }
+#endif
 }
 
 }  // namespace
@@ -199,12 +247,6 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (p.sg != 1 || p.os != 1 || p.oh0 != 0 || p.ow0 != 0) return false;
     if (p.Hg != p.Ho || p.Wg != p.Wo || p.Hi != p.Ho || p.Wi != p.Wo) return false;
     if (p.Ci > 256 || p.Ci % 16 != 0 || p.Co != p.M) return false;
-    static bool attr_done = false;
-    if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, true>), 64 * 256 * 4, "conv1x1_stream_kernel<4, 2, true>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, false>), 64 * 256 * 4, "conv1x1_stream_kernel<4, 2, false>");
-        attr_done = true;
-    }
     // (128-channel instantiations for wide outputs measured 2 % slower end to end, both <8,1> -- shorter pixel
     // iterations -- and <8,2> -- 252 VGPRs, two waves per SIMD: reading x once per 128 instead of once per 64
     // channels does not pay for either)
@@ -218,17 +260,35 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     int vt = std::max(1, (int)((10LL * MT * p.Ci + (long long)bnv * (p.Ci + MT) - 1) / ((long long)bnv * (p.Ci + MT))));
     if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;
-    const size_t lds = std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
+    // split-product form (split3.h) while its weight planes fit two blocks per CU
+    const int sp = p.Ci <= 192 ? fm_mfma_split() : 0;
+    const size_t lds = sp ? std::max<size_t>((size_t)((p.Ci + 31) / 32) * 3 * MT * 64, (size_t)4 * MT * 2 * 4)
+                          : std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
+    const dim3 grid(tilesM, bpg * groups);
+    constexpr int LDS_MAX = 6 * 3 * 64 * 64;        // 72 KB (K = 192 planes) >= the fp32 slice of K = 256 (64 KB)
+#define FM_C1_LAUNCH(STATS_, GATE_)                                                                                              \
+    do {                                                                                                                         \
+        static bool done_ = false;                                                                                               \
+        if (!done_) {                                                                                                            \
+            set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, STATS_, GATE_, 0>), LDS_MAX, "conv1x1_stream_kernel"); \
+            set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, STATS_, GATE_, 6>), LDS_MAX, "conv1x1_stream_kernel<6>"); \
+            set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, STATS_, GATE_, 9>), LDS_MAX, "conv1x1_stream_kernel<9>"); \
+            done_ = true;                                                                                                        \
+        }                                                                                                                        \
+        if (sp == 6) hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, STATS_, GATE_, 6>), grid, dim3(256), lds, s, p, vt, bpg);   \
+        else if (sp == 9) hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, STATS_, GATE_, 9>), grid, dim3(256), lds, s, p, vt, bpg); \
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, STATS_, GATE_, 0>), grid, dim3(256), lds, s, p, vt, bpg);           \
+    } while (0)
     if (p.gate && p.psc) {
         if (!p.stats) return false;                          // the affine prologue exists for the train forward only
-        static bool g_done = false;
-        if (!g_done) { set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, true, 2>), 64 * 256 * 4, "conv1x1_stream_kernel<affine gate>"); g_done = true; }
-        hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, true, 2>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+        FM_C1_LAUNCH(true, 2);
     } else if (p.gate) {
-        static bool g_done = false;
-        if (!g_done) { set_max_dyn_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<4, 2, false, 1>), 64 * 256 * 4, "conv1x1_stream_kernel<gate>"); g_done = true; }
-        hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false, 1>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
-    } else if (p.stats) hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, true>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
-    else hipLaunchKernelGGL((conv1x1_stream_kernel<4, 2, false>), dim3(tilesM, bpg * groups), dim3(256), lds, s, p, vt, bpg);
+        FM_C1_LAUNCH(false, 1);
+    } else if (p.stats) {
+        FM_C1_LAUNCH(true, 0);
+    } else {
+        FM_C1_LAUNCH(false, 0);
+    }
+#undef FM_C1_LAUNCH
     return true;
 }
