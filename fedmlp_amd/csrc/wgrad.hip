@@ -459,6 +459,141 @@ __global__ __launch_bounds__(256) void wgrad_skinny_kernel(const SkinnyParams p)
     }
 }
 
+// The same GEMM in the split-product form (split3.h): the staging threads split their 16-B fragments on the way into LDS (three
+// bf16 planes per operand, [plane][32 pixels][channels], rows padded to 32 B x odd), fragments by ds_read_b64_tr_b16 -- the
+// structure of wgrad_kernel's SP form: one LDS buffer, two barriers per step.  On the fp32 pipe a 32-pixel step of a 64 x 128
+// tile is 64 MFMAs of 32 cycles per wave against ~1 200 cycles of bytes; here it is 48 of 16.
+template <int CC, int SP>
+__global__ __launch_bounds__(256) void wgrad_skinny_split_kernel(const SkinnyParams p)
+{
+#if __HIP_DEVICE_COMPILE__
+    constexpr int BS = 16 * CC;
+    constexpr int CB = BS / 4;
+    constexpr int NB = (32 * CB + 255) / 256;
+    constexpr int SA = 160, SB = 32 * ((CC + 1) | 1);        // row strides in bytes (32 x odd)
+    constexpr int PA = 32 * SA, PB = 32 * SB;
+    __shared__ __attribute__((aligned(16))) unsigned char Pl[3 * PA + 3 * PB];
+    unsigned char* const Ap = Pl;
+    unsigned char* const Bp = Pl + 3 * PA;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    int tile, split;
+    const int nsplit = p.nsplit;
+    {
+        const int T = p.tilesL, id = blockIdx.x;
+        const int full = p.xcd ? (nsplit >> 3) << 3 : 0;
+        if (id < full * T) {
+            const int q = id >> 3, x = id & 7;
+            split = (q / T) * 8 + x;
+            tile = q - (q / T) * T;
+        } else {
+            const int r = id - full * T;
+            split = full + r / T;
+            tile = r - (r / T) * T;
+        }
+    }
+    const int l0 = tile * 64;
+    const int tsteps = (p.npix + 31) >> 5;
+    const int nsteps = split < tsteps ? (tsteps - split + nsplit - 1) / nsplit : 0;
+    const int pend = p.npix;
+    const int ca = tid & 15, ra = tid >> 4;
+    const bool a_ok = l0 + 4 * ca < p.L;
+    f32x4 va[2], vb[NB];
+    auto xgather = [&](const float* X, int pix, int ch) -> const float* {
+        const int HWo = p.Ho * p.Wo;
+        const int img = pix / HWo, rem = pix - img * HWo;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int kh = ch / p.kw_p, kw = ch - kh * p.kw_p;
+        const int ih = oh * p.stride + kh - p.pad, iw = ow * p.stride + kw - p.pad;
+        const bool ok = kw < p.k && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        return ok ? X + ((size_t)(img * p.Hi + ih) * p.Wi + iw) * 4 : p.zeros;
+    };
+    const bool big_g = p.gather && p.swap, small_g = p.gather && !p.swap;
+    auto gload = [&](int s) {
+        const int pb = (split + s * nsplit) * 32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pix = pb + ra + 16 * q;
+            const float* src = p.zeros;
+            if (a_ok && pix < pend) src = big_g ? xgather(p.Big, pix, (l0 >> 2) + ca) : p.Big + (size_t)pix * p.L + l0 + 4 * ca;
+            va[q] = *reinterpret_cast<const f32x4*>(src);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c / CB, cb = c - row * CB;
+            const int pix = pb + row;
+            const float* src = p.zeros;
+            if (c < 32 * CB && 4 * cb < p.S && pix < pend) src = small_g ? xgather(p.Small, pix, cb) : p.Small + (size_t)pix * p.S + 4 * cb;
+            vb[q] = *reinterpret_cast<const f32x4*>(src);
+        }
+    };
+    auto put = [&](unsigned char* dst, int plane_bytes, const f32x4 v) {
+        uint2 H, M, L;
+        split3_pair(sp_f32x2{v[0], v[1]}, H.x, M.x, L.x);
+        split3_pair(sp_f32x2{v[2], v[3]}, H.y, M.y, L.y);
+        *reinterpret_cast<uint2*>(dst) = H;
+        *reinterpret_cast<uint2*>(dst + plane_bytes) = M;
+        *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = L;
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) put(Ap + (ra + 16 * q) * SA + 8 * ca, PA, va[q]);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int c = tid + 256 * q;
+            const int row = c / CB, cb = c - row * CB;
+            if (c < 32 * CB) put(Bp + row * SB + 8 * cb, PB, vb[q]);
+        }
+    };
+    f32x4 acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nsteps > 0) { gload(0); lstore(); }
+    __syncthreads();
+    const int trow = 4 * lg + (li >> 2), tcol = 4 * (li & 3);
+    const unsigned char* fa = Ap + trow * SA + (16 * wave + tcol) * 2;
+    const unsigned char* fb = Bp + trow * SB + tcol * 2;
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) gload(s + 1);
+        {
+            const uint2 h0 = wg_read_tr16(fa), h1 = wg_read_tr16(fa + 16 * SA);
+            const uint2 m0 = wg_read_tr16(fa + PA), m1 = wg_read_tr16(fa + PA + 16 * SA);
+            const uint2 q0 = wg_read_tr16(fa + 2 * PA), q1 = wg_read_tr16(fa + 2 * PA + 16 * SA);
+            const sp_u32x4 ah = {h0.x, h0.y, h1.x, h1.y}, am = {m0.x, m0.y, m1.x, m1.y}, al = {q0.x, q0.y, q1.x, q1.y};
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const unsigned char* q = fb + 32 * c;
+                const uint2 bh0 = wg_read_tr16(q), bh1 = wg_read_tr16(q + 16 * SB);
+                const uint2 bm0 = wg_read_tr16(q + PB), bm1 = wg_read_tr16(q + PB + 16 * SB);
+                const uint2 bl0 = wg_read_tr16(q + 2 * PB), bl1 = wg_read_tr16(q + 2 * PB + 16 * SB);
+                acc[c] = mfma_split<SP>(ah, am, al, sp_u32x4{bh0.x, bh0.y, bh1.x, bh1.y}, sp_u32x4{bm0.x, bm0.y, bm1.x, bm1.y},
+                                        sp_u32x4{bl0.x, bl0.y, bl1.x, bl1.y}, acc[c]);
+            }
+        }
+        __syncthreads();
+        if (s + 1 < nsteps) lstore();
+        __syncthreads();
+    }
+    // acc[c][q] = P[l = l0 + 16*wave + 4*lg + q][s = 16*c + li]
+    const int l = l0 + 16 * wave + 4 * lg;
+    if (l < p.L) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const int sc = 16 * c + li;
+            if (sc >= p.S) continue;
+            if (p.swap) {
+                *reinterpret_cast<f32x4*>(p.slab + ((size_t)split * p.M + sc) * p.Nw + l) = acc[c];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p.slab[((size_t)split * p.M + l + q) * p.Nw + sc] = acc[c][q];
+            }
+        }
+    }
+#endif
+}
+
 // returns the number of splits used, or 0 if the shape is not handled (caller falls back)
 int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
 {
@@ -486,16 +621,17 @@ int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
     p.tilesL = tilesL; p.nsplit = splits; p.xcd = xcd;
     dim3 grid(tilesL * splits);
     const int cc = (S + 15) / 16;
-    switch (cc) {
-    case 1: hipLaunchKernelGGL(wgrad_skinny_kernel<1>, grid, dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL(wgrad_skinny_kernel<2>, grid, dim3(256), 0, s, p); break;
-    case 3: hipLaunchKernelGGL(wgrad_skinny_kernel<3>, grid, dim3(256), 0, s, p); break;
-    case 4: hipLaunchKernelGGL(wgrad_skinny_kernel<4>, grid, dim3(256), 0, s, p); break;
-    case 5: hipLaunchKernelGGL(wgrad_skinny_kernel<5>, grid, dim3(256), 0, s, p); break;
-    case 6: hipLaunchKernelGGL(wgrad_skinny_kernel<6>, grid, dim3(256), 0, s, p); break;
-    case 7: hipLaunchKernelGGL(wgrad_skinny_kernel<7>, grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(wgrad_skinny_kernel<8>, grid, dim3(256), 0, s, p); break;
+    const int sp = fm_mfma_split();
+#define FM_SK(CC_)                                                                                                    \
+    case CC_:                                                                                                         \
+        if (sp == 6) hipLaunchKernelGGL((wgrad_skinny_split_kernel<CC_, 6>), grid, dim3(256), 0, s, p);               \
+        else if (sp == 9) hipLaunchKernelGGL((wgrad_skinny_split_kernel<CC_, 9>), grid, dim3(256), 0, s, p);          \
+        else hipLaunchKernelGGL(wgrad_skinny_kernel<CC_>, grid, dim3(256), 0, s, p);                                  \
+        break;
+    switch (cc < 8 ? cc : 8) {
+        FM_SK(1) FM_SK(2) FM_SK(3) FM_SK(4) FM_SK(5) FM_SK(6) FM_SK(7) FM_SK(8)
     }
+#undef FM_SK
     return splits;
 }
 
