@@ -88,7 +88,7 @@ def mfma_peak():
 
 ARITHMETIC = {0: "fp32 operands, fp32 products and accumulation on v_mfma_f32_16x16x4_f32",
               6: "fp32 operands and fp32 accumulation; every product as 6 exact bf16 partial products on v_mfma_f32_16x16x32_bf16 "
-                 "(3-way exact split of both operands, the 3 partial products below 2^-26 of the product left out; error against "
+                 "(3-way exact split of both operands, the 3 partial products of at most 2^-24 of the product left out (at most 2 more unit roundoffs in a K-term sum that carries K); error against "
                  "float64 is below the fp32-MFMA form's: tests/test_kernels_gpu.py::test_split_products_are_fp32_accurate; "
                  "FM_MFMA_SPLIT=0 selects the fp32 pipe)",
               9: "fp32 operands and fp32 accumulation; every product as its 9 exact bf16 partial products on "

@@ -39,7 +39,7 @@ inline int fm_tune(const char* name, int dflt)
 }
 
 // The ResNet conv GEMMs (igemm.hip, wgrad.hip) form their fp32 products either on the fp32 matrix pipe (0) or as exact bf16
-// partial products on the bf16 matrix pipe (9 = all nine, 6 = the six above 2^-26 of the product; split3.h).  Runtime switch
+// partial products on the bf16 matrix pipe (9 = all nine, 6 = without the three below 2^-24 of the product; split3.h).  Runtime switch
 // FM_MFMA_SPLIT, read per call (tests compare the forms in one process).
 #ifndef FM_MFMA_SPLIT_DEFAULT
 #define FM_MFMA_SPLIT_DEFAULT 6
