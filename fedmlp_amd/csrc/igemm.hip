@@ -1,15 +1,19 @@
-// Implicit-GEMM convolution (forward + data gradient) on fp32 MFMA, gfx950.
+// Implicit-GEMM convolution (forward + data gradient), gfx950: fp32 operands and accumulators; the products on the bf16 matrix
+// pipe as exact bf16 partial products (split3.h, template parameter SP = 6 / 9: the shipped form) or on the fp32 pipe (SP = 0).
 //
 // Reference op replaced: every nn.Conv2d forward inside net(images)
 // (utils/local_training.py:657, 937-947, 983, 1030, 1178) and its input
 // gradient inside loss.backward() (:674, 965, 1191), which the reference gets
 // from cuDNN through torchvision's resnet18 (model/all_models.py:53-54).
 //
-// Roofline: fp32 matrix pipe (v_mfma_f32_16x16x4_f32, 157 TFLOP/s).  Design:
+// Roofline: SP = 6: v_mfma_f32_16x16x32_bf16, 2 500 TFLOP/s / 6 products = 416.7 TFLOP/s of fp32 products; SP = 0: fp32 matrix pipe
+// (v_mfma_f32_16x16x4_f32, 157 TFLOP/s).  Design (the bullets describe the fp32-pipe generation the split forms grew out of; what the
+// split forms change is said at the template: one 32-k stage per bf16 MFMA step, the weight operand as pre-split planes (WP),
+// 64 x 192 tiles for the 64-row layers, two-stage DMA lookahead from the two-stage ring):
 //  * D = Wp * Xg^T with output CHANNELS on the MFMA row axis, so each lane ends
 //    up with 4 consecutive channels of one pixel -> one 16-B NHWC store.
 //  * 256 threads = 4 waves, each wave owns a 64x64 sub-tile (4x4 MFMA tiles,
-//    64 accumulator VGPRs); block tile 128x128 (M>=128) or 64x256 (M==64); two
+//    64 accumulator VGPRs); block tile 128x128 (M>=128), 64x192 (M==64) or 64x256 (stem); two
 //    blocks per CU.  (The template also builds one-block-per-CU 256x128 /
 //    128x256 / 64x512 tiles with 128x64 wave tiles; measured slower, see the
 //    table above launch_igemm.)
