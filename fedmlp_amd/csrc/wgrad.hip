@@ -1,4 +1,5 @@
-// Convolution weight gradient as a split-K fp32-MFMA GEMM, gfx950.
+// Convolution weight gradient as a split-K GEMM, gfx950: fp32 operands and accumulators, the products as exact bf16 partial
+// products on the bf16 matrix pipe (split3.h; template parameter SP = 6 / 9, the shipped form) or on the fp32 pipe (SP = 0).
 //
 // Reference op replaced: the weight-gradient half of loss.backward()
 // (utils/local_training.py:674, 965, 1191) for every nn.Conv2d of the model
