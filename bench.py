@@ -17,8 +17,8 @@ usage: python bench.py --gpus N --steps K --warmup W
 
 Arithmetic: operands, accumulators and stored tensors are fp32 (`dtype` "f32"); the conv GEMMs form every fp32 product as
 six exact bf16 partial products on the bf16 matrix pipe (csrc/split3.h; as close to float64 as the fp32-MFMA
-kernels, tests/test_kernels_gpu.py).  `roofline.peak` is that form's roofline (bf16 dense peak / 6); FM_MFMA_SPLIT=0 runs
-the fp32 matrix pipe instead, and the default line times that too (`legs.stage1_fp32_mfma_pipe`, `value_on_fp32_mfma_pipe`).
+kernels, tests/test_kernels_gpu.py).  `roofline.peak` is that form's roofline (bf16 dense peak / 6); --products 0 (fm_config.reserved[2]
+= 1) runs the fp32 matrix pipe instead, and the default run times that too (leg `stage1_fp32_mfma_pipe`, `value_on_fp32_mfma_pipe`).
 
 The ONE line of a default N = 1 run carries, after the headline fields:
   sustained      the same step repeated back to back for >= --sustain-s seconds (steady clock)
@@ -58,27 +58,30 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense
 
 
-def mfma_products():
+def mfma_products(args=None):
     """0 = the conv GEMMs multiply on the fp32 matrix pipe; 6 / 9 = every fp32 product as that many exact bf16 partial
-    products on the bf16 matrix pipe, accumulated in fp32 (csrc/split3.h; FM_MFMA_SPLIT, library default 6)."""
+    products on the bf16 matrix pipe, accumulated in fp32 (csrc/split3.h).  The form is a property of the engine handle
+    (fm_config.reserved[2], --products); without --products it is the library default (6)."""
+    if args is not None and getattr(args, "products", None) is not None:
+        return int(args.products)
     from fedmlp_amd import _lib
     return int(_lib.load().fm_mfma_products())
 
 
-def kernel_names():
+def kernel_names(sp=None):
     """kernel families of fm_profile_read, named as rocprofv3 prints them for the ResNet-18 workload (every non-stem conv has
     Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes)."""
-    sp = mfma_products()
+    sp = mfma_products() if sp is None else sp
     wp = 1 if sp else 0
     return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},{wp}>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},{wp}>",
             2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>" if sp else "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
             5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
 
 
-def mfma_peak():
+def mfma_peak(sp=None):
     """(peak TFLOP/s of fp32-equivalent work, note): the fp32 pipe's dense peak, or the bf16 pipe's divided by the partial
     products each fp32 product costs."""
-    sp = mfma_products()
+    sp = mfma_products() if sp is None else sp
     if not sp:
         return PEAK_F32_MFMA_TFLOPS, "v_mfma_f32_16x16x4_f32 dense peak"
     return round(PEAK_BF16_MFMA_TFLOPS / sp, 2), (
@@ -90,9 +93,9 @@ ARITHMETIC = {0: "fp32 operands, fp32 products and accumulation on v_mfma_f32_16
               6: "fp32 operands and fp32 accumulation; every product as 6 exact bf16 partial products on v_mfma_f32_16x16x32_bf16 "
                  "(3-way exact split of both operands, the 3 partial products of at most 2^-24 of the product left out (at most 2 more unit roundoffs in a K-term sum that carries K); error against "
                  "float64 is below the fp32-MFMA form's: tests/test_kernels_gpu.py::test_split_products_are_fp32_accurate; "
-                 "FM_MFMA_SPLIT=0 selects the fp32 pipe)",
+                 "fm_config.reserved[2] = 1 selects the fp32 pipe)",
               9: "fp32 operands and fp32 accumulation; every product as its 9 exact bf16 partial products on "
-                 "v_mfma_f32_16x16x32_bf16 (FM_MFMA_SPLIT=9)"}
+                 "v_mfma_f32_16x16x32_bf16 (fm_config.reserved[2] = 2)"}
 PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 # minimum activation bytes per image of one EfficientNet-B0 forward
 EFFNET_FWD_BYTES = {"fp32": 73.8e6, "bf16": 36.9e6}
@@ -127,6 +130,8 @@ def parse(argv=None):
     ap.add_argument("--sustain-s", type=float, default=10.0,
                     help="seconds of back-to-back repeats of the headline step after the timed region (N = 1, default "
                          "workload; 0 = off)")
+    ap.add_argument("--products", type=int, default=None, choices=[0, 6, 9],
+                    help="product form of the fp32 conv GEMMs (fm_config.reserved[2]): 6 = library default, 0 = fp32 matrix pipe")
     ap.add_argument("--one-stream", action="store_true",
                     help="engine stream mode 1: every kernel on one stream, roofline measured inside the timed region "
                          "(use this under rocprofv3: per-kernel durations of co-running kernels describe no kernel alone)")
@@ -271,7 +276,7 @@ def one_stream_roofline_pass(args, eng, step_fn, max_images, dev):
     free_b, _ = torch.cuda.mem_get_info(torch.device(dev))
     if free_b < (24 << 30):                  # a bs-128 two-view ResNet-18 engine holds ~12 GB
         return None, None
-    e1 = Engine(args.model, args.classes, args.hw, args.hw, max_images, device=dev, streams=1)
+    e1 = Engine(args.model, args.classes, args.hw, args.hw, max_images, device=dev, streams=1, products=eng.products)
     try:
         flat, cnt = eng.get_state()
         e1.set_state(flat, cnt)
@@ -327,7 +332,8 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
     B, C = args.batch, args.classes
     views = 2 if args.workload == "stage1" else 1
     eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev), precision=args.precision,
-                 streams=1 if args.one_stream else 0)
+                 streams=1 if args.one_stream else 0, products=getattr(args, "products", None))
+    sp = eng.products
     flat, cnt = spec.init_state(args.model, C, 1037)
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
@@ -476,7 +482,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
         pmc_file = pmc_doc(args)[1]
         allk = None
         if fams is not None:
-            allk = {kernel_names()[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
+            allk = {kernel_names(sp)[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
                                       "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
                     for f in range(NFAM)}
         if args.model == "Efficient_b0":
@@ -493,7 +499,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
         elif fams is None:
             steps_alg = STEP_FLOP[args.workload] * B
             tf = steps_alg / (dt / args.steps) / 1e12
-            peak, peak_note = mfma_peak()
+            peak, peak_note = mfma_peak(sp)
             roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "peak_basis": peak_note,
                     "frac": round(tf / peak, 4), "traffic": None, "kernel": "whole step",
                     "measured_in": "the timed region (no free device memory for the one-stream per-kernel pass)"}
@@ -506,9 +512,9 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
             else:
                 dom = max(range(NFAM), key=lambda f: fams[f][1])
                 n, ms, fl = fams[dom]
-                name = kernel_names()[dom]
+                name = kernel_names(sp)[dom]
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            peak, peak_note = mfma_peak()
+            peak, peak_note = mfma_peak(sp)
             roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "peak_basis": peak_note,
                     "frac": round(tf / peak, 4), "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": measured_traffic(name, args),
@@ -554,9 +560,9 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
                                      (" (--one-stream)" if args.one_stream else ""),
                       "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3),
                       "arithmetic": ("bf16 storage, fp32 accumulation" if (args.model == "Efficient_b0" and args.precision == "bf16")
-                                     else ARITHMETIC[mfma_products()])},
+                                     else ARITHMETIC[sp])},
            "roofline": roof,
-           "last_loss": float(lv[-1])}
+           "last_loss": float(lv[-1]), "_products": sp}
     if per_rank is not None:
         out["config"]["per_rank"] = per_rank
     if sustained is not None:
@@ -749,16 +755,8 @@ def run_legs(args, dev, cand):
         return out
 
     def fp32_pipe_leg():
-        # the headline workload with the conv GEMMs on the fp32 matrix pipe (the library reads the variable at every launch)
-        old = os.environ.get("FM_MFMA_SPLIT")
-        os.environ["FM_MFMA_SPLIT"] = "0"
-        try:
-            return step_leg()
-        finally:
-            if old is None:
-                del os.environ["FM_MFMA_SPLIT"]
-            else:
-                os.environ["FM_MFMA_SPLIT"] = old
+        # the headline workload on a handle whose conv GEMMs multiply on the fp32 matrix pipe (fm_config.reserved[2] = 1)
+        return step_leg(products=0)
 
     table = [
         ("stage1_fp32_mfma_pipe", fp32_pipe_leg),
@@ -917,11 +915,10 @@ def main():
             out["legs"] = run_legs(args, dev, best or thread_candidates(args.cpu_threads)[:1])
             f32 = out["legs"].get("stage1_fp32_mfma_pipe") or {}
             if "value" in f32:
-                # the headline metric with the conv GEMMs on the fp32 matrix pipe (FM_MFMA_SPLIT=0), for a reader who wants
+                # the headline metric with the conv GEMMs on the fp32 matrix pipe (fm_config.reserved[2] = 1), for a reader who wants
                 # the figure of that arithmetic beside `value` without digging into `legs`
                 out["value_on_fp32_mfma_pipe"] = {"value": f32["value"], "ms_per_step": f32["ms_per_step"],
                                                   "roofline_frac_of_fp32_mfma_peak": (f32.get("roofline") or {}).get("frac")}
-        out["_products"] = mfma_products()
         emit(out)
     if dist is not None:
         dist.barrier()

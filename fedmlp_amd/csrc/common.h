@@ -39,8 +39,10 @@ inline int fm_tune(const char* name, int dflt)
 }
 
 // The ResNet conv GEMMs (igemm.hip, wgrad.hip) form their fp32 products either on the fp32 matrix pipe (0) or as exact bf16
-// partial products on the bf16 matrix pipe (9 = all nine, 6 = without the three below 2^-24 of the product; split3.h).  Runtime switch
-// FM_MFMA_SPLIT, read per call (tests compare the forms in one process).
+// partial products on the bf16 matrix pipe (9 = all nine, 6 = without the three below 2^-24 of the product; split3.h).  The form is
+// a property of the engine: fm_config.reserved[2] (0 = this default, 1 = fp32 pipe, 2 = nine products), fixed at fm_create
+// and carried to the launchers in IgemmParams / WgradParams `sp`.  fm_mfma_split() resolves the default; the environment
+// variable FM_MFMA_SPLIT overrides it for tests and is read there, once per fm_create, never per launch.
 #ifndef FM_MFMA_SPLIT_DEFAULT
 #define FM_MFMA_SPLIT_DEFAULT 6
 #endif
@@ -163,6 +165,7 @@ struct IgemmParams {
     // Xe = swish(X * psc[group][k] + psh[group][k]) * gate; null = gate only
     const float* psc = nullptr;
     const float* psh = nullptr;
+    int sp = 0;           // product form of the launch (fm_engine::products): 0 fp32 matrix pipe, 6 / 9 bf16 partial products
     // split-product form (split3.h), M >= 128: the bf16 planes of W made by k_split_weights, [M][nsteps of 32 k][3 planes][32]
     // (192 B per 32-k block, the k order inside a block as the kernel's lane groups take it); null = split W in the kernel
     const unsigned short* Wsp = nullptr;
@@ -185,6 +188,7 @@ struct WgradParams {
     int tilesM, tilesN;
     int bn;               // N-tile width the caller tiled with (wgrad_tile_n)
     int gather_k, gather_pad, gather_kw_p;   // stem form for launch_wgrad_skinny (kernel size, top/left pad, padded width)
+    int sp = 0;           // product form of the launch (fm_engine::products): 0 fp32 matrix pipe, 6 / 9 bf16 partial products
 };
 
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);

@@ -261,7 +261,7 @@ bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s)
     if (vt_env > 0) vt = vt_env;
     const int bpg = (p.tilesN + vt - 1) / vt;
     // split-product form (split3.h) while its weight planes fit two blocks per CU
-    const int sp = p.Ci <= 192 ? fm_mfma_split() : 0;
+    const int sp = p.Ci <= 192 ? p.sp : 0;
     const size_t lds = sp ? std::max<size_t>((size_t)((p.Ci + 31) / 32) * 3 * MT * 64, (size_t)4 * MT * 2 * 4)
                           : std::max<size_t>((size_t)MT * p.Ci * 4, (size_t)4 * MT * 2 * 4);
     const dim3 grid(tilesM, bpg * groups);

@@ -198,6 +198,7 @@ struct fm_engine {
     double* comm_buf = nullptr;       // device scratch of the small all-reduces
     size_t comm_buf_n = 0;
     int precision = 0;                // 0 fp32 activations, 1 bf16 activations (EfficientNet-B0 only)
+    int products = 6;                 // fm_config.reserved[2]: how the fp32 conv GEMMs form their products (0 fp32 pipe, 6 / 9 bf16 partials)
     int stream_mode = 0;              // fm_config.reserved[1]: 0 side stream for teacher + weight gradients, 1 one stream, 2 teacher only
     int dt = DT_F32;                  // storage type of activations / their gradients (DT_F32 or DT_BF16)
     bf16 *wb = nullptr, *twb = nullptr;   // bf16 weight shadows of the student / the teacher (1x1 convs, W and W^T)
@@ -874,6 +875,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     }
     IgemmParams p{};
     p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+    p.sp = e->products;
     if (c.sp_off >= 0 && e->wsp_f) p.Wsp = (S == e->tstate ? e->twsp_f : e->wsp_f) + c.sp_off;
     if (c.cin == 3) {
         p.stem_kw = c.k; p.stem_pad = c.pad; p.stem_h2 = c.kw_p == 8 ? 1 : 0; p.stem3 = c.stem3 ? 1 : 0;
@@ -937,6 +939,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         DgradClass& d = c.cls[k];
         IgemmParams p{};
         p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+        p.sp = e->products;
         if (d.sp_off >= 0 && e->wsp_d) p.Wsp = e->wsp_d + d.sp_off;
         p.ntaps = d.taps.n;
         for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
@@ -976,6 +979,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
     }
     WgradParams p{};
     p.dY = dy; p.X = x; p.slab = e->ws_slab; p.tab = c.tab; p.zeros = e->zeros;
+    p.sp = e->products;
     p.M = c.cout_p; p.Nw = c.Kw;
     p.Ho = c.hout; p.Wo = c.wout; p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p; p.stride = c.stride;
     if (c.stem3) { p.X = e->x3; p.Hi = c.Hp; p.Wi = c.Wp; }      // gather table of build_tables: framed rows, no bounds
@@ -1685,10 +1689,16 @@ int fm_create(const fm_config* cfg, fm_engine** out)
     ARGCHK(cfg->max_images >= 1, "max_images");
     ARGCHK(cfg->reserved[0] == 0 || (cfg->reserved[0] == 1 && cfg->model == 1),
            "precision (reserved[0]) must be 0 (fp32) or, for EfficientNet-B0, 1 (bf16 activations)");
-    ARGCHK(cfg->reserved[1] >= 0 && cfg->reserved[1] <= 2 && cfg->reserved[2] == 0, "reserved[1] (stream mode) must be 0, 1 or 2; reserved[2] must be 0");
+    ARGCHK(cfg->reserved[1] >= 0 && cfg->reserved[1] <= 2, "reserved[1] (stream mode) must be 0, 1 or 2");
+    ARGCHK(cfg->reserved[2] >= 0 && cfg->reserved[2] <= 2,
+           "reserved[2] (product form of the fp32 conv GEMMs) must be 0 (library default: six bf16 partial products), 1 (fp32 "
+           "matrix pipe) or 2 (nine bf16 partial products)");
     fm_engine* e = new fm_engine();
     e->precision = cfg->reserved[0];
     e->stream_mode = cfg->reserved[1];
+    // the product form belongs to the handle: fixed here, carried to every launch in the kernels' parameter blocks.  0 resolves
+    // to the library default, which the test-only FM_MFMA_SPLIT overrides (read once, here)
+    e->products = cfg->reserved[2] == 1 ? 0 : (cfg->reserved[2] == 2 ? 9 : fm_mfma_split());
     e->dt = e->precision ? DT_BF16 : DT_F32;
     e->fuse_gate = e->precision && !(getenv("FM_FUSE_GATE") && atoi(getenv("FM_FUSE_GATE")) == 0);
     e->cfg = *cfg;
@@ -1825,6 +1835,7 @@ int fm_stream_mode(fm_engine* e)
 }
 
 int fm_mfma_products(void) { return fm_mfma_split(); }
+int fm_products(fm_engine* e) { return e ? e->products : FM_ERR_ARG; }
 
 int fm_fedavg_fold(fm_engine* e, const float* const* states_dev, const float* n_host, int32_t K, float* out_dev)
 {

@@ -560,7 +560,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s)
     static const int ks32_mode = fm_tune("FM_KS32", 2);
     const bool ks32 = !p.stem_kw && p.Ci % 32 == 0 && (ks32_mode == 2 || (ks32_mode == 1 && p.M < 128));
     if (ks32) p.nsteps /= 2;           // the caller counts 16-k steps
-    const int split = fm_mfma_split();
+    const int split = p.sp;
     // the packed 7x7 stem in the split form: 11 steps of 16 k become 6 of 32, the rows of W keep their 176 floats
     const bool stem_split = p.stem_kw && p.stem3 && split != 0;
     if (stem_split) { p.wrow = p.nsteps * 16; p.nsteps = (p.nsteps + 1) / 2; }

@@ -622,7 +622,7 @@ int launch_wgrad_skinny(const WgradParams& w, size_t slab_floats, hipStream_t s)
     p.tilesL = tilesL; p.nsplit = splits; p.xcd = xcd;
     dim3 grid(tilesL * splits);
     const int cc = (S + 15) / 16;
-    const int sp = fm_mfma_split();
+    const int sp = w.sp;
 #define FM_SK(CC_)                                                                                                    \
     case CC_:                                                                                                         \
         if (sp == 6) hipLaunchKernelGGL((wgrad_skinny_split_kernel<CC_, 6>), grid, dim3(256), 0, s, p);               \
@@ -678,7 +678,7 @@ bool launch_wgrad(const WgradParams& p, int splits, hipStream_t s)
         }
     }
     dim3 grid(p.tilesM * p.tilesN, splits);
-    const int sp = fm_mfma_split();
+    const int sp = p.sp;
     if (sp == 9) {
         if (p.M >= 128) hipLaunchKernelGGL((wgrad_kernel<128, 128, 2, 4, 9>), grid, dim3(256), SPL_L, s, p);
         else if (p.bn == 192) hipLaunchKernelGGL((wgrad_kernel<64, 192, 4, 3, 9>), grid, dim3(256), SPL_T, s, p);

@@ -12,6 +12,8 @@ from . import _lib, spec
 
 MODEL_IDS = {"Resnet18": 0, "Efficient_b0": 1}
 PRECISION_IDS = {"fp32": 0, "bf16": 1}
+# fm_config.reserved[2]: None = the library default (six products), 0 = fp32 matrix pipe, 9 = all nine partial products
+PRODUCT_FORMS = {None: 0, 6: 0, 0: 1, 9: 2}
 
 
 def _ptr(t):
@@ -26,9 +28,11 @@ class Engine:
     """One per process/GPU. Owns the device-resident model state, optimiser
     moments, teacher snapshot and activation workspaces for `max_images`."""
 
-    def __init__(self, model, n_classes, in_h, in_w, max_images, device=None, precision="fp32", streams=0):
+    def __init__(self, model, n_classes, in_h, in_w, max_images, device=None, precision="fp32", streams=0, products=None):
         """streams: fm_config.reserved[1] -- 0 the engine forks its side stream for the frozen teacher and the weight
-        gradients (default, bit-identical to one stream), 1 one stream (per-kernel profiling), 2 teacher only."""
+        gradients (default, bit-identical to one stream), 1 one stream (per-kernel profiling), 2 teacher only.
+        products: fm_config.reserved[2] -- how the fp32 conv GEMMs form their products, fixed for the handle: None = library
+        default (six exact bf16 partial products per fp32 product on the bf16 matrix pipe), 0 = fp32 matrix pipe, 6, 9."""
         if not torch.cuda.is_available():
             raise RuntimeError("fedmlp_amd.Engine needs a GPU (no CPU fallback)")
         self.lib = _lib.load()
@@ -47,7 +51,8 @@ class Engine:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         self.streams = int(streams)
         cfg = _lib.FmConfig(MODEL_IDS[model], self.n_classes, self.in_h, self.in_w,
-                            self.max_images, (C.c_int32 * 3)(PRECISION_IDS[precision], self.streams, 0),
+                            self.max_images, (C.c_int32 * 3)(PRECISION_IDS[precision], self.streams,
+                                                             PRODUCT_FORMS[products]),
                             C.c_void_p(self.stream) if self.stream else None)
         h = C.c_void_p()
         _lib.check(self.lib.fm_create(C.byref(cfg), C.byref(h)))
@@ -60,6 +65,7 @@ class Engine:
         self.feature_dim = spec.FEATURE_DIM[model]
         # what fm_create actually set up (it keeps one stream when the second buffer set does not fit in free memory)
         self.stream_mode = int(self.lib.fm_stream_mode(self.h))
+        self.products = int(self.lib.fm_products(self.h))      # 0 fp32 matrix pipe, 6 / 9 bf16 partial products
         # Efficient_b0: draw drop-connect / dropout multipliers before every train step, like the
         # reference's model does inside net(images) in train mode.  Parity tests switch it off and
         # install their own draws with set_stochastic().

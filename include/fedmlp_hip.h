@@ -57,7 +57,11 @@ typedef struct fm_config {
                              backward's weight gradients are enqueued on an engine-owned side stream that is
                              forked from and joined to `stream` inside every call (same bits as one stream);
                              1 = everything on `stream` (use for per-kernel profiling); 2 = teacher forward on
-                             the side stream only.  reserved[2] must be 0. */
+                             the side stream only.
+                             reserved[2] = product form of the fp32 convolution GEMMs, fixed for the handle's life:
+                             0 (default) the library default = every fp32 product as six exact bf16 partial products
+                             on the bf16 matrix pipe, fp32 accumulation (csrc/split3.h); 1 = products on the fp32
+                             matrix pipe; 2 = all nine partial products.  fm_products() reports it. */
     void*   stream;       /* hipStream_t; NULL = null stream                         */
 } fm_config;
 
@@ -253,10 +257,13 @@ int fm_feature_dim(fm_engine* e);
 int fm_stream_mode(fm_engine* e);
 /* How the fp32 convolution GEMMs (ResNet-18's 3x3 / 1x1 convs, EfficientNet's wide 1x1 convs) form their products right
  * now: 0 = v_mfma_f32_16x16x4_f32; 9 / 6 = each fp32 product as 9 / 6 exact bf16 partial products on
- * v_mfma_f32_16x16x32_bf16, accumulated in fp32 (csrc/split3.h; the shipped default is 6; the environment variable
- * FM_MFMA_SPLIT = 0 | 6 | 9 is read at every launch).  Replaces nothing in the reference: cuDNN picks its own algorithm
- * behind nn.Conv2d (model/all_models.py:53-54). */
+ * v_mfma_f32_16x16x32_bf16, accumulated in fp32 (csrc/split3.h).  fm_products(e): the form of this handle, set at
+ * fm_create from fm_config.reserved[2].  fm_mfma_products(): what reserved[2] = 0 resolves to (6 in the shipped library;
+ * the test-only environment variable FM_MFMA_SPLIT = 0 | 6 | 9 overrides it and is read once per fm_create, never per
+ * launch).  The reference has one arithmetic (utils/local_training.py:14 imports autocast and never uses it); cuDNN picks
+ * its own algorithm behind nn.Conv2d (model/all_models.py:53-54). */
 int fm_mfma_products(void);
+int fm_products(fm_engine* e);
 
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the

@@ -371,31 +371,48 @@ def test_relu_mask_from_conv_output_is_bit_identical(monkeypatch):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
 
 
-def test_step_in_the_three_product_forms(monkeypatch, eng):
-    """FM_MFMA_SPLIT = 6 (the default: six exact bf16 partial products per fp32 product on the bf16 matrix pipe), 9 (all nine) and
-    0 (the fp32 matrix pipe): each form's stage-1 step matches the fp32 CPU oracle under the engine's own ReLU masks to the same
-    5e-5 (test_step_stage1 is this check under the default), each form is run-to-run bit-identical, and the losses of the three
-    forms agree to 1e-6.  (Two forms are NOT compared gradient by gradient: at 16 images x 64 x 64 one ReLU input within rounding
-    of zero flips between two roundings and moves single tensors by 2-3 % -- the reason the oracle comparisons share the masks.)"""
+def test_step_in_the_three_product_forms(monkeypatch):
+    """fm_config.reserved[2] (Engine(products=...)): six exact bf16 partial products per fp32 product on the bf16 matrix pipe (the
+    default), all nine, and the fp32 matrix pipe, each form its own handle: every form's stage-1 step matches the fp32 CPU oracle
+    under the engine's own ReLU masks to the same 5e-5 (test_step_stage1 is this check under the default), each form is run-to-run
+    bit-identical, and the losses of the three forms agree to 1e-6.  The form is a property of the handle, not of the
+    environment at launch time: FM_MFMA_SPLIT is read once per fm_create (and only when reserved[2] = 0).  (Two forms are NOT
+    compared gradient by gradient: at 16 images x 64 x 64 one ReLU input within rounding of zero flips between two roundings
+    and moves single tensors by 2-3 % -- the reason the oracle comparisons share the masks.)"""
     from fedmlp_amd import _lib
+    from fedmlp_amd.engine import Engine
     (x1, x2), y = _data(6, 47, views=2)
     mask = [0.0, 1.0, 0.0, 0.0, 0.0]
     outs = {}
-    for mode in ("9", "0", "6", "6"):
-        monkeypatch.setenv("FM_MFMA_SPLIT", mode)
-        assert _lib.load().fm_mfma_products() == int(mode)
-        if mode not in outs:
-            _stage1_step_check(eng, f"stage1, FM_MFMA_SPLIT={mode}")
-        _load(eng)
-        eng.teacher_snapshot()
-        lo = torch.zeros(1, device="cuda")
-        eng.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
-        res = (lo.item(), eng.debug_get_grads().copy())
-        if mode in outs:                                   # second run of the default form: the same bits
-            assert outs[mode][0] == res[0]
-            np.testing.assert_array_equal(outs[mode][1], res[1])
-        outs[mode] = res
-    monkeypatch.delenv("FM_MFMA_SPLIT")
     assert _lib.load().fm_mfma_products() == 6
-    for mode in ("6", "9"):
-        assert abs(outs[mode][0] - outs["0"][0]) <= 1e-6 * abs(outs["0"][0]), (mode, outs[mode][0], outs["0"][0])
+    for mode in (9, 0, 6, None):
+        e = Engine("Resnet18", C_, HW, HW, 16, products=mode)
+        try:
+            want = 6 if mode is None else mode
+            assert e.products == want
+            monkeypatch.setenv("FM_MFMA_SPLIT", "0")       # changing the environment after fm_create changes nothing
+            if want not in outs:
+                _stage1_step_check(e, f"stage1, products={mode}")
+            _load(e)
+            e.teacher_snapshot()
+            lo = torch.zeros(1, device="cuda")
+            e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+            res = (lo.item(), e.debug_get_grads().copy())
+            assert e.products == want
+            monkeypatch.delenv("FM_MFMA_SPLIT")
+        finally:
+            e.close()
+        if want in outs:                                   # second handle of the default form: the same bits
+            assert outs[want][0] == res[0]
+            np.testing.assert_array_equal(outs[want][1], res[1])
+        outs[want] = res
+    # the test-only override of the default, read at fm_create
+    monkeypatch.setenv("FM_MFMA_SPLIT", "9")
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    try:
+        assert e.products == 9
+    finally:
+        e.close()
+    monkeypatch.delenv("FM_MFMA_SPLIT")
+    for mode in (6, 9):
+        assert abs(outs[mode][0] - outs[0][0]) <= 1e-6 * abs(outs[0][0]), (mode, outs[mode][0], outs[0][0])

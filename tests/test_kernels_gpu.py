@@ -45,6 +45,20 @@ def eng224():
     e.close()
 
 
+@pytest.fixture(scope="module")
+def eng224_forms():
+    """one handle per product form of the conv GEMMs (fm_config.reserved[2]), same state"""
+    from fedmlp_amd.engine import Engine
+    flat, cnt = spec.init_state("Resnet18", 5, 7)
+    engs = {}
+    for sp in (0, 9, 6):
+        engs[sp] = Engine("Resnet18", 5, 224, 224, 4, products=sp)
+        engs[sp].set_state(flat, cnt)
+    yield engs, spec.flat_to_state_dict("Resnet18", 5, flat, cnt)
+    for e in engs.values():
+        e.close()
+
+
 def _nhwc(x_nchw, cpad):
     x = x_nchw.permute(0, 2, 3, 1).contiguous()
     if cpad > x.shape[3]:
@@ -105,10 +119,12 @@ def _check_conv(e, sd, ci, imgs, groups, seed):
 
 
 @pytest.mark.parametrize("ci", [0, 1, 6, 11, 16])
-def test_split_products_are_fp32_accurate(monkeypatch, eng224, ci):
-    """FM_MFMA_SPLIT = 9 / 6 (fp32 products as exact bf16 partial products on the bf16 matrix pipe, csrc/split3.h) against
-    float64 convolutions: forward, data gradient and weight gradient are as close to float64 as the fp32-MFMA kernels are."""
-    e, sd = eng224
+def test_split_products_are_fp32_accurate(eng224_forms, ci):
+    """fm_config.reserved[2] = nine / six products (fp32 products as exact bf16 partial products on the bf16 matrix pipe,
+    csrc/split3.h) against float64 convolutions: forward, data gradient and weight gradient are as close to float64 as the
+    fp32-MFMA kernels are.  One handle per form."""
+    engs, sd = eng224_forms
+    e = engs[0]
     info = e.debug_conv_info(ci)
     imgs = 3
     g = torch.Generator().manual_seed(900 + ci)
@@ -126,7 +142,8 @@ def test_split_products_are_fp32_accurate(monkeypatch, eng224, ci):
     want_w = F.pad(want_w, (0, info["cin_p"] - info["cin"], 0, info["kw_p"] - info["k"])).reshape(info["cout"], -1)
     errs = {}
     for sp in (0, 9, 6):
-        monkeypatch.setenv("FM_MFMA_SPLIT", str(sp))
+        e = engs[sp]
+        assert e.products == sp
         out = torch.empty((imgs, info["hout"], info["wout"], info["cout"]), device=dev)
         e.debug_conv(0, ci, x_d, None, out, imgs, 1, torch.empty((1, 2, info["cout"]), device=dev))
         dx = torch.empty((imgs, info["hin"], info["win"], info["cin"]), device=dev)

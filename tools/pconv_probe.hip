@@ -1,0 +1,425 @@
+// Probe: the inner structure of a 3x3 / stride-1 / pad-1 convolution as an implicit GEMM whose BOTH operands arrive as bf16
+// planes (split3.h: x = h + m + l), gfx950.   D[pix][co] = sum_{tap, ci} W[co][tap][ci] * X[pix + tap][ci], fp32 products as six
+// bf16 partial products, fp32 accumulation.
+// Operand layout ("block-major planes"): X[Ci/32][3 planes][pixels][32] bf16, W[K-step = (ci block, tap)][3][Co][32] bf16:
+// 64-B rows, 1 KB contiguous per 16 rows.
+// Structure under test: ONE 8-wave block per CU, two waves per SIMD; wave tile (16 FR) x 64; LDS = two stages of
+// [A planes | B planes]; a wave's A fragments are double-buffered in registers (step s+1's are read during step s), the B
+// fragments roll column by column; ONE barrier per step, placed before the step's last column; LDS-DMA (buffer_load ... lds,
+// out-of-range offsets = zero padding) one step ahead.  The LDS reads are inline asm with explicit waits: issued at the head
+// of a column's MFMAs, waited for at its end.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pconv_probe.hip -o build/pconv_probe
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct P {
+    const unsigned short* Wp;  // [nsteps][3][Co][32]
+    const unsigned short* Xp;  // [Ci/32][3][npix][32]
+    float* D;                  // [npix][Co]
+    int imgs, H, W, Ci, Co;
+    int npix, nsteps;          // nsteps = 9 * Ci/32
+    int tilesM, tilesN;
+};
+
+__device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// six of the nine partial products, small terms first (planes 0 = h, 1 = m, 2 = l)
+__device__ __forceinline__ f32x4 mfma6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 v)
+{
+    v = mfma(a[2], b[0], v);
+    v = mfma(a[0], b[2], v);
+    v = mfma(a[1], b[1], v);
+    v = mfma(a[1], b[0], v);
+    v = mfma(a[0], b[1], v);
+    v = mfma(a[0], b[0], v);
+    return v;
+}
+template <int IMM> __device__ __forceinline__ u32x4 lds_read128(unsigned addr)
+{
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+
+// WM x WN = 8 waves, wave tile (16 FR) x 64.  MODE 0: the full kernel; 1: no LDS-DMA (stale LDS: reads + MFMA + barrier);
+// 2: no DMA and no LDS reads (MFMA + barrier only); 3: full + one dword-DMA prefetch per wave and step that pulls the NEXT ci block's
+// rows of this tile into L2 (counted vmcnt(1)); 4: full, but every tile reads tile 0's pixels (L2-resident B: what latency costs)
+template <int WM, int WN, int FR, int MODE>
+__global__ __launch_bounds__(512, 2) void pconv(const P p)
+{
+    constexpr int FC = 4;
+    constexpr int BM = 16 * FR * WM, BN = 64 * WN;
+    constexpr int SA = 3 * BM * 64, SB = 3 * BN * 64;          // bytes per stage
+    constexpr int GA = BM / 16, GB = BN / 16;                  // 16-row groups per operand tile
+    constexpr int JB = 3 * GB / 8;                             // B DMA instructions per wave per stage (3 or 6)
+    constexpr int RGB = JB / 3;                                // B row groups per wave: wave handles groups wave + 8 i, all 3 planes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)smem;              // LDS byte address of the dynamic segment
+    const unsigned As = lds0, Bs = lds0 + 2 * SA;              // [2][3][BM][64], [2][3][BN][64]
+
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD and take neighbouring tiles
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int tm = tile % p.tilesM, tn = tile / p.tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int W = p.W, H = p.H, npix = p.npix;
+
+    // ---- LDS-DMA sources.  One instruction = 16 rows x 64 B of one plane; lane = (row lane>>2, slot lane&3); the chunk a slot
+    // holds is swizzled on the source side: chunk = slot ^ ((row>>1)&3).  Buffer descriptors: the per-lane part of the address is
+    // ONE 32-bit offset per row group, everything that changes per step / plane / job is a scalar offset.
+    const int drow = lane >> 2, chunk = (lane & 3) ^ ((lane >> 3) & 3);
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.Wp), 0, (unsigned)((size_t)p.nsteps * 3 * p.Co * 64), 0x00020000);
+    // X: the descriptor's base sits (W + 1) pixels BELOW the tensor, so that tap offsets (dh + 1) * W + (dw + 1) are never negative
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.Xp) - (size_t)(W + 1) * 64), 0,
+        (unsigned)((size_t)(p.Ci / 32) * 3 * npix * 64 + (size_t)(W + 1) * 64), 0x00020000);
+    // A jobs: job j = plane j / GA, row group j % GA; wave takes j = wave + 8 q
+    constexpr int JA = (3 * GA + 7) / 8;
+    const unsigned voffA = (unsigned)((m0 + drow) * 64 + chunk * 16);
+    // B: row group g = wave + 8 i holds pixels n0 + 16 g + drow
+    unsigned voffB[RGB], vmask[RGB];
+#pragma unroll
+    for (int i = 0; i < RGB; ++i) {
+        const int n = (MODE == 4 ? 0 : n0) + 16 * (wave + 8 * i) + drow;
+        const bool rv = n < npix;
+        const int nn = rv ? n : 0;
+        const int img = nn / (H * W), rem = nn - img * (H * W);
+        const int h = rem / W, w = rem - h * W;
+        unsigned vm = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = h + t / 3 - 1, iw = w + t % 3 - 1;
+            if (rv && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) vm |= 1u << t;
+        }
+        vmask[i] = vm;
+        voffB[i] = (unsigned)(nn * 64 + chunk * 16);
+    }
+    auto issueA = [&](int s, int slot) {
+        if constexpr (MODE == 0 || MODE >= 3) {
+#pragma unroll
+            for (int q = 0; q < JA; ++q) {
+                const int j = wave + 8 * q;
+                if (3 * GA % 8 != 0 && j >= 3 * GA) break;
+                const int plane = j / GA, grp = j % GA;
+                const unsigned so = (unsigned)(((s * 3 + plane) * p.Co + 16 * grp) * 64);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(size_t)(As + slot * SA + j * 1024), 16, voffA, so, 0, 0);
+            }
+        }
+    };
+    // K-step s = (ci block icc, tap it), tap-minor: the shifted re-reads of an input block stay in L1 / L2
+    auto issueB = [&](int s, int slot) {
+        if constexpr (MODE == 0 || MODE >= 3) {
+            const int icc = s / 9, it = s - 9 * icc;
+            const int dh = it / 3, dw = it - 3 * dh;               // (dh + 1, dw + 1) of the shifted descriptor base
+#pragma unroll
+            for (int i = 0; i < RGB; ++i) {
+                const unsigned vo = ((vmask[i] >> it) & 1u) ? voffB[i] : OOB;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned so = (unsigned)((((size_t)(icc * 3 + pl)) * npix + dh * W + dw) * 64);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(size_t)(Bs + slot * SB + (pl * GB + wave + 8 * i) * 1024), 16,
+                                                             vo, so, 0, 0);
+                }
+            }
+        }
+    };
+    // L2 prefetch (MODE 3): at the first tap of ci block icc, waves 0 .. 3*BN/128-1 each touch 64 lines (128 B) of block icc + 1's
+    // rows of this tile: plane = job / (BN/128), lines (job % (BN/128)) * 64 + lane; every other (step, wave) issues the same
+    // instruction with out-of-range offsets (no memory access), so that the count of outstanding operations is uniform
+    auto prefetch = [&](int s) {
+        const int icc = s / 9, it = s - 9 * icc;
+        constexpr int NJ = 3 * BN / 128;
+        const bool on = it == 0 && wave < NJ && (icc + 1) * 9 < p.nsteps;
+        const int pl = wave / (BN / 128), part = wave % (BN / 128);
+        const unsigned vo = on ? (unsigned)((n0 + part * 128 + 2 * lane) * 64) : OOB;
+        const unsigned so = (unsigned)((((size_t)((icc + 1) * 3 + pl)) * npix + W + 1) * 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(size_t)(lds0 + 2 * SA + 2 * SB + wave * 256), 4, vo, so, 0, 0);
+    };
+    // fragment reads: row 16r + li of the wave's rows, chunk lg sits in slot lg ^ ((li>>1)&3)
+    const unsigned fro = li * 64 + ((lg ^ ((li >> 1) & 3)) << 4);
+    const unsigned Af0 = As + wm * (16 * FR) * 64 + fro, Af1 = Af0 + SA;
+    const unsigned Bf0 = Bs + wn * 64 * 64 + fro, Bf1 = Bf0 + SB;
+
+    f32x4 acc[FR][FC];
+#pragma unroll
+    for (int r = 0; r < FR; ++r)
+#pragma unroll
+        for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 A0[FR][3], A1[FR][3], Bb[2][3];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < FR; ++r)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) A0[r][pl] = A1[r][pl] = u32x4{(unsigned)lane * 0x3f803f80u, 0x3f803f80u, 0x3e803e80u, 0x3f003f00u};
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) Bb[0][pl] = Bb[1][pl] = u32x4{0x3f803f80u, (unsigned)lane * 0x3f803f80u, 0x3f003f00u, 0x3e803e80u};
+    }
+#define READA(SLOT, R, DST)                                                                              \
+    if constexpr (MODE <= 1) {                                                                           \
+        DST[0] = lds_read128<(0 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                              \
+        DST[1] = lds_read128<(1 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                              \
+        DST[2] = lds_read128<(2 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                              \
+    }
+#define READB(SLOT, C, DST)                                                                              \
+    if constexpr (MODE <= 1) {                                                                           \
+        DST[0] = lds_read128<(0 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                              \
+        DST[1] = lds_read128<(1 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                              \
+        DST[2] = lds_read128<(2 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                              \
+    }
+#define LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    const int nsteps = p.nsteps;
+    issueA(0, 0);
+    issueB(0, 0);
+    if (1 < nsteps) issueA(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (1 < nsteps) issueB(1, 1);
+    READA(0, 0, A0[0]);
+    READA(0, 1, A0[1]);
+    if constexpr (FR == 4) { READA(0, 2, A0[2]); READA(0, 3, A0[3]); }
+    READB(0, 0, Bb[0]);
+    LGKM0();
+    __builtin_amdgcn_s_barrier();          // every wave holds A(0): its slot takes A(2)
+    asm volatile("" ::: "memory");
+    if (2 < nsteps) issueA(2, 0);
+    if constexpr (MODE == 3) prefetch(1);      // (it = 1: out of range) keeps the count the loop's vmcnt(1) assumes
+
+    // one K-step (slot parity PAR = s & 1): Ac = this step's A fragments (in registers), An <- the next step's.
+    // FULL: steps s+1, s+2, s+3 all exist (the main loop: no branch inside); otherwise the conditions are tested
+    auto step = [&](auto par_c, auto full_c, int s, u32x4 (&Ac)[FR][3], u32x4 (&An)[FR][3]) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
+        // ---- columns 0 .. 2: the next column's B fragments and a share of the next step's A fragments go out at the head of the
+        // column's MFMAs and are waited for at its end
+#define COLUMN(C)                                                                                        \
+        {                                                                                                \
+            READB(PAR, (C) + 1, Bb[((C) + 1) & 1]);                                                      \
+            if (FULL || s + 1 < nsteps) {                                                                \
+                if constexpr (FR == 4) {                                                                 \
+                    if constexpr ((C) == 0) { READA(PAR ^ 1, 0, An[0]); READA(PAR ^ 1, 1, An[1]); }      \
+                    if constexpr ((C) == 1) { READA(PAR ^ 1, 2, An[2]); }                                \
+                    if constexpr ((C) == 2) { READA(PAR ^ 1, 3, An[3]); }                                \
+                } else {                                                                                 \
+                    if constexpr ((C) == 0) { READA(PAR ^ 1, 0, An[0]); }                                \
+                    if constexpr ((C) == 1) { READA(PAR ^ 1, 1, An[1]); }                                \
+                }                                                                                        \
+            }                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = mfma6(Ac[r], Bb[(C) & 1], acc[r][C]); \
+            LGKM0();                                                                                     \
+        }
+        COLUMN(0)
+        COLUMN(1)
+        COLUMN(2)
+#undef COLUMN
+        // ---- last column: every wave holds all of this step's fragments and step s+1's A fragments: both read slots are free
+        if constexpr (MODE == 3) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (FULL || s + 1 < nsteps) READB(PAR ^ 1, 0, Bb[0]);
+        if (FULL || s + 2 < nsteps) issueB(s + 2, PAR);
+        if (FULL || s + 3 < nsteps) issueA(s + 3, PAR ^ 1);
+        if constexpr (MODE == 3) prefetch(s);
+#pragma unroll
+        for (int r = 0; r < FR; ++r) acc[r][FC - 1] = mfma6(Ac[r], Bb[(FC - 1) & 1], acc[r][FC - 1]);
+        LGKM0();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    int s = 0;
+    for (; s + 5 <= nsteps; s += 2) {          // steps s and s+1 are FULL: s + 1 + 3 < nsteps
+        step(I0{}, std::true_type{}, s, A0, A1);
+        step(I1{}, std::true_type{}, s + 1, A1, A0);
+    }
+    for (; s < nsteps; s += 2) {
+        step(I0{}, std::false_type{}, s, A0, A1);
+        if (s + 1 < nsteps) step(I1{}, std::false_type{}, s + 1, A1, A0);
+    }
+
+    // epilogue: acc[r][c][q] = D[pix n0 + wn*64 + 16c + li][m0 + wm*16FR + 16r + 4lg + q]
+#pragma unroll
+    for (int c = 0; c < FC; ++c) {
+        const int n = n0 + wn * 64 + 16 * c + li;
+        if (n >= npix) continue;
+#pragma unroll
+        for (int r = 0; r < FR; ++r) {
+            const int m = m0 + wm * (16 * FR) + 16 * r + 4 * lg;
+            if (m < p.Co) *reinterpret_cast<f32x4*>(p.D + (size_t)n * p.Co + m) = acc[r][c];
+        }
+    }
+}
+
+static unsigned short f2bf(float f)
+{
+    unsigned u;
+    memcpy(&u, &f, 4);
+    u += 0x7fff + ((u >> 16) & 1);
+    return (unsigned short)(u >> 16);
+}
+static float bf2f(unsigned short h)
+{
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void split3(float x, unsigned short (&o)[3])
+{
+    o[0] = f2bf(x);
+    const float r1 = x - bf2f(o[0]);
+    o[1] = f2bf(r1);
+    o[2] = f2bf(r1 - bf2f(o[1]));
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int WM, int WN, int FR, int MODE>
+static double run(const P& p, int reps)
+{
+    constexpr int BM = 16 * FR * WM, BN = 64 * WN;
+    constexpr int LDS = 2 * 3 * (BM + BN) * 64 + 2048;
+    static bool done = false;
+    if (!done) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv<WM, WN, FR, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); done = true; }
+    P q = p;
+    q.tilesM = (p.Co + BM - 1) / BM; q.tilesN = (p.npix + BN - 1) / BN;
+    const int grid = q.tilesM * q.tilesN;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < (reps > 1 ? 2 : 0); ++i) hipLaunchKernelGGL((pconv<WM, WN, FR, MODE>), dim3(grid), dim3(512), LDS, 0, q);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((pconv<WM, WN, FR, MODE>), dim3(grid), dim3(512), LDS, 0, q);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    CK(hipGetLastError());
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main(int argc, char** argv)
+{
+    // 1. correctness on a small convolution against float64 of the same fp32 values (borders, image boundaries, tails)
+    {
+        const int imgs = 3, H = 9, W = 11, Ci = 64, Co = 256, npix = imgs * H * W, nsteps = 9 * Ci / 32;
+        std::vector<float> X((size_t)npix * Ci), Wt((size_t)Co * 9 * Ci);
+        unsigned s = 1;
+        for (auto& v : X) { s = s * 1664525u + 1013904223u; v = ((float)(s >> 8) / 8388608.0f) - 1.0f; }
+        for (auto& v : Wt) { s = s * 1664525u + 1013904223u; v = ((float)(s >> 8) / 8388608.0f) - 1.0f; }
+        std::vector<unsigned short> hX((size_t)(Ci / 32) * 3 * npix * 32), hW((size_t)nsteps * 3 * Co * 32);
+        unsigned short o[3];
+        for (int n = 0; n < npix; ++n)
+            for (int c = 0; c < Ci; ++c) {
+                split3(X[(size_t)n * Ci + c], o);
+                for (int pl = 0; pl < 3; ++pl) hX[(((size_t)(c / 32) * 3 + pl) * npix + n) * 32 + c % 32] = o[pl];
+            }
+        for (int m = 0; m < Co; ++m)
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < Ci; ++c) {
+                    split3(Wt[((size_t)m * 9 + t) * Ci + c], o);
+                    const int st = (c / 32) * 9 + t;
+                    for (int pl = 0; pl < 3; ++pl) hW[(((size_t)st * 3 + pl) * Co + m) * 32 + c % 32] = o[pl];
+                }
+        unsigned short *dX, *dW;
+        float* dD;
+        CK(hipMalloc(&dX, hX.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dD, (size_t)npix * Co * 4));
+        CK(hipMemcpy(dX, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+        P p{dW, dX, dD, imgs, H, W, Ci, Co, npix, nsteps, 0, 0};
+        std::vector<float> D((size_t)npix * Co);
+        std::vector<double> ref((size_t)npix * Co);
+        for (int n = 0; n < npix; ++n) {
+            const int img = n / (H * W), h = (n / W) % H, w = n % W;
+            for (int m = 0; m < Co; ++m) {
+                double a = 0;
+                for (int t = 0; t < 9; ++t) {
+                    const int ih = h + t / 3 - 1, iw = w + t % 3 - 1;
+                    if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                    const float* xr = &X[((size_t)(img * H + ih) * W + iw) * Ci];
+                    const float* wr = &Wt[((size_t)m * 9 + t) * Ci];
+                    for (int c = 0; c < Ci; ++c) a += (double)xr[c] * wr[c];
+                }
+                ref[(size_t)n * Co + m] = a;
+            }
+        }
+        for (int cfg = 0; cfg < 4; ++cfg) {
+            CK(hipMemset(dD, 0xff, (size_t)npix * Co * 4));
+            if (cfg == 0) run<4, 2, 4, 0>(p, 1); else if (cfg == 1) run<2, 4, 4, 0>(p, 1); else if (cfg == 2) run<2, 4, 2, 0>(p, 1); else run<2, 4, 4, 3>(p, 1);
+            CK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0, ref2 = 0, err2 = 0;
+            for (size_t i = 0; i < D.size(); ++i) {
+                const double d = D[i] - ref[i];
+                worst = fmax(worst, fabs(d)); ref2 += ref[i] * ref[i]; err2 += d * d;
+            }
+            printf("check cfg %d: rel L2 err %.3e, worst abs %.3e\n", cfg, sqrt(err2 / ref2), worst);
+        }
+        hipFree(dX); hipFree(dW); hipFree(dD);
+    }
+    // 2. timing on the 3x3 layers of ResNet-18 at 256 images (random planes: h ~ 1, m ~ 2^-8, l ~ 2^-16)
+    const int shapes[][3] = {{14, 256, 256}, {7, 512, 512}, {28, 128, 128}, {56, 64, 64}};   // H = W, Ci, Co
+    for (auto& sh : shapes) {
+        const int imgs = 256, H = sh[0], W = sh[0], Ci = sh[1], Co = sh[2], npix = imgs * H * W, nsteps = 9 * Ci / 32;
+        unsigned short *dX, *dW;
+        float* dD;
+        const size_t nX = (size_t)(Ci / 32) * 3 * npix * 32, nW = (size_t)nsteps * 3 * Co * 32;
+        CK(hipMalloc(&dX, nX * 2)); CK(hipMalloc(&dW, nW * 2)); CK(hipMalloc(&dD, (size_t)npix * Co * 4));
+        std::vector<unsigned short> h(nX > nW ? nX : nW);
+        auto fill = [&](unsigned short* d, size_t n, size_t rows, unsigned seed) {
+            unsigned s = seed;
+            for (size_t i = 0; i < n; ++i) {
+                s = s * 1664525u + 1013904223u;
+                const int plane = (int)((i / (rows * 32)) % 3);
+                const unsigned e = 126 - 8 * plane - ((s >> 28) & 3);
+                h[i] = (unsigned short)(((s >> 9) & 0x8000) | (e << 7) | ((s >> 16) & 0x7f));
+            }
+            CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+        };
+        fill(dX, nX, npix, 11);
+        fill(dW, nW, Co, 12);
+        P p{dW, dX, dD, imgs, H, W, Ci, Co, npix, nsteps, 0, 0};
+        const double fl = 2.0 * npix * Co * 9.0 * Ci;
+        const int reps = 20;
+        double t;
+#define LINE(NAME, CALL) t = CALL; printf("H%3d Ci%4d Co%4d  %-22s %8.1f us %7.1f TF\n", H, Ci, Co, NAME, t * 1e3, fl / t / 1e9);
+        if (Co >= 256) {
+            LINE("256x128 full", (run<4, 2, 4, 0>(p, reps)));
+            LINE("256x128 no-dma", (run<4, 2, 4, 1>(p, reps)));
+            LINE("256x128 mfma-only", (run<4, 2, 4, 2>(p, reps)));
+        }
+        if (Co >= 128) {
+            LINE("128x256 full", (run<2, 4, 4, 0>(p, reps)));
+            LINE("128x256 no-dma", (run<2, 4, 4, 1>(p, reps)));
+            LINE("128x256 full+prefetch", (run<2, 4, 4, 3>(p, reps)));
+            LINE("128x256 full, B in L2", (run<2, 4, 4, 4>(p, reps)));
+        }
+        LINE("64x256(FR2) full", (run<2, 4, 2, 0>(p, reps)));
+        LINE("64x256(FR2) no-dma", (run<2, 4, 2, 1>(p, reps)));
+        LINE("64x256(FR2) full+prefetch", (run<2, 4, 2, 3>(p, reps)));
+        LINE("64x256(FR2) full, B in L2", (run<2, 4, 2, 4>(p, reps)));
+        LINE("64x256(FR2) mfma-only", (run<2, 4, 2, 2>(p, reps)));
+        hipFree(dX); hipFree(dW); hipFree(dD);
+    }
+    return 0;
+}
