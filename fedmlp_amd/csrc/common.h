@@ -169,6 +169,13 @@ struct IgemmParams {
     // split-product form (split3.h), M >= 128: the bf16 planes of W made by k_split_weights, [M][nsteps of 32 k][3 planes][32]
     // (192 B per 32-k block, the k order inside a block as the kernel's lane groups take it); null = split W in the kernel
     const unsigned short* Wsp = nullptr;
+    // pconv.hip (both operands as block-major bf16 planes): Wsp then holds [nsteps = (channel block, tap)][3][M][32]; Xp the
+    // activation planes [Ci/32][3][xp_pix][32] of the WHOLE input tensor (xp_pix = its pixel count); Y may be null when only planes
+    // are wanted; Yp (eval epilogue, dense output): the output's planes [Co/32][3][yp_pix][32]
+    const unsigned short* Xp = nullptr;
+    long long xp_pix = 0;
+    unsigned short* Yp = nullptr;
+    long long yp_pix = 0;
     // floats per row of W when that is not nsteps * KS (the packed stem in 32-k stages: rows of 176 floats walked as 6 x 32 --
     // the 16 floats past a row's end meet the zero-page chunks of X); 0 = nsteps * KS
     int wrow = 0;
@@ -191,7 +198,26 @@ struct WgradParams {
     int sp = 0;           // product form of the launch (fm_engine::products): 0 fp32 matrix pipe, 6 / 9 bf16 partial products
 };
 
+// pwgrad.hip: the weight gradient with both operands as block-major bf16 planes (ResNet-18 planes mode)
+struct PwgradParams {
+    const unsigned short* dYp;   // [M/32][3][npix][32]: planes of the output gradient, npix = imgs*Ho*Wo
+    const unsigned short* Xp;    // [Ci/32][3][xpix][32]: planes of the conv input, xpix = imgs*Hi*Wi
+    float* slab;                 // [splits][M][Nw]
+    int M, Nw;                   // Nw = ksz*ksz*Ci, n = tap*Ci + ci
+    int Ho, Wo, Hi, Wi, Ci, stride, pad, ksz;
+    long long npix, xpix;
+    int pix_per_split;           // multiple of 32 (set by the launcher)
+    int tilesM, tilesN, nblk_n;  // set by the launcher
+    int sp;                      // product form: 6 / 9
+};
+int launch_pwgrad(PwgradParams p, size_t slab_floats, hipStream_t s);     // returns the slabs written (0 = nothing launched)
+bool pwgrad_takes(int M, int Ci, int ksz, long long npix, long long xpix, int Wi, int pad);
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);
+// pconv.hip: the same GEMM with both operands as block-major bf16 planes (p.Wsp, p.Xp); p.nsteps is set by the launcher
+void launch_pconv(IgemmParams p, int groups, hipStream_t s);
+bool pconv_takes(int M, int Ci, long long xp_pix, int Wi);
+int pconv_tile_m(int M);
+int pconv_tile_n();
 // small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
 bool conv1x1_stream_takes(int Ci, int M, int Co);     // would a stride-1 1x1 conv of this shape stream through conv1x1.hip?

@@ -54,6 +54,7 @@ struct DgradClass {
     int nsteps;
     float* wpack = nullptr;
     long long sp_off = -1;    // bf16 planes of wpack inside fm_engine::wsp_d (2-byte units), -1 = none
+    long long bm_off = -1;    // block-major planes of wpack inside fm_engine::wbm_d (pconv.hip), -1 = none
 };
 
 struct Conv {
@@ -72,6 +73,7 @@ struct Conv {
     DgradClass cls[4];
     int bn;                   // index of the BatchNorm that follows
     long long sp_off = -1;    // bf16 planes of the forward weights inside fm_engine::wsp_f / twsp_f (2-byte units), -1 = none
+    long long bm_off = -1;    // block-major planes of the forward weights inside fm_engine::wbm_f / twbm_f (pconv.hip), -1 = none
     long long wb_off = -1, wbt_off = -1;   // bf16 shadow of a 1x1 conv's weights [cout_p][cin_p] / transposed (bf16 mode)
     bool last_pro = false;    // the last conv_fwd of this conv carried an operand prologue (decides the bf16 statistics layout)
     double macs_per_img;      // algorithmic MACs (real k, real cin)
@@ -90,6 +92,8 @@ struct Block {
     float* z1 = nullptr;
     float* out = nullptr;
     float *t_z1 = nullptr, *t_out = nullptr, *t_dsy = nullptr;     // the side-stream teacher's set (see fm_engine::st2)
+    // planes mode: block-major bf16 planes of z1 / out (what the conv GEMMs read), and the teacher's set
+    unsigned short *z1p = nullptr, *outp = nullptr, *t_z1p = nullptr, *t_outp = nullptr;
 };
 
 struct MBConv {               // EfficientNet block (efficientnet-pytorch MBConvBlock)
@@ -190,6 +194,20 @@ struct fm_engine {
     // bf16 planes of the conv weights for the split-product GEMMs (split3.h; ResNet, fp32 mode): student forward, teacher
     // forward, student data-gradient packs; rebuilt with the packs (wpack_dirty) / the teacher shadows (twb_dirty)
     unsigned short *wsp_f = nullptr, *twsp_f = nullptr, *wsp_d = nullptr;
+    // planes mode (ResNet-18, split product forms): the 3x3 / 1x1 conv GEMMs take BOTH operands as block-major bf16 planes
+    // (pconv.hip); the activation planes are written by the kernels that produce the tensors
+    bool planes = false;
+    unsigned short *wbm_f = nullptr, *twbm_f = nullptr, *wbm_d = nullptr;
+    SplitJobBM *bm_f = nullptr, *bm_d = nullptr;
+    int n_bm_f = 0, n_bm_f_blocks = 0, n_bm_d = 0, n_bm_d_blocks = 0;
+    unsigned short *p0p = nullptr, *t_p0p = nullptr;                 // planes of the stem's pooled output
+    unsigned short *GBp = nullptr, *GCp = nullptr, *GDp = nullptr;   // planes of d y2, d y_ds, d y1 (what the data gradients read)
+    unsigned short *GB2p = nullptr, *GC2p = nullptr, *GD2p = nullptr;
+    unsigned short* xp_scratch = nullptr;       // planes of an fp32 operand nobody produced planes for (test hooks)
+    unsigned short* xp_scratch2 = nullptr;      // ... and of the second operand of a weight gradient
+    size_t xp_scratch_elems = 0;
+    const float* xp_scratch_src = nullptr;
+    long long xp_scratch_npix = 0;
     SplitJob *split_f = nullptr, *split_d = nullptr;
     int n_split_f = 0, n_split_f_blocks = 0, n_split_d = 0, n_split_d_blocks = 0;
     // RCCL (comm.hip)
@@ -322,6 +340,15 @@ int add_conv(fm_engine* e, int cin, int cout, int k, int stride, int pad, int hi
 
 int build_tables(fm_engine* e)
 {
+    if (e->planes) {
+        // planes mode needs every non-stem conv GEMM (forward and data gradient) inside pconv.hip's limits at max_images
+        for (auto& c : e->convs) {
+            if (c.cin == 3) continue;
+            if (!pconv_takes(c.cout_p, c.cin_p, (long long)e->maxB * c.hin * c.win, c.win) ||
+                !pconv_takes(c.cin_p, c.cout_p, (long long)e->maxB * c.hout * c.wout, c.wout))
+                e->planes = false;
+        }
+    }
     for (auto& c : e->convs) {
         if (c.Kw % 16 != 0) { g_err = "conv K not a multiple of 16"; return FM_ERR_ARG; }
         // forward / wgrad table: chunk q -> (kh, kw, ci0)
@@ -423,6 +450,45 @@ int build_tables(fm_engine* e)
                     bd += split_job_blocks(c.cin_p, K / 32);
                     off_d += (long long)c.cin_p * K * 3;
                 }
+        }
+        if (e->planes) {
+            // block-major planes (pconv.hip): every non-stem conv of ResNet-18 and every parity class of its data gradients
+            std::vector<SplitJobBM> bf_, bd_;
+            long long o_f = 0, o_d = 0;
+            int nbf = 0, nbd = 0;
+            for (auto& c : e->convs) {
+                if (c.cin == 3) continue;
+                if (c.cout_p % 64 == 0 && c.cin_p % 32 == 0) {
+                    c.bm_off = o_f;
+                    bf_.push_back({(long long)c.w_off, nullptr, o_f, c.cout_p, c.k * c.k, c.cin_p / 32, nbf});
+                    nbf += split_job_bm_blocks(c.cout_p, c.Kw / 32);
+                    o_f += (long long)c.cout_p * c.Kw * 3;
+                }
+                if (c.cin_p % 64 == 0 && c.cout_p % 32 == 0)
+                    for (int k = 0; k < c.ncls; ++k) {
+                        DgradClass& d = c.cls[k];
+                        const int K = d.taps.n * c.cout_p;
+                        d.bm_off = o_d;
+                        bd_.push_back({0, d.wpack, o_d, c.cin_p, d.taps.n, c.cout_p / 32, nbd});
+                        nbd += split_job_bm_blocks(c.cin_p, K / 32);
+                        o_d += (long long)c.cin_p * K * 3;
+                    }
+            }
+            float* t2 = nullptr;
+            if (o_f) {
+                DALLOC(t2, (size_t)(o_f + 1) / 2); e->wbm_f = reinterpret_cast<unsigned short*>(t2);
+                DALLOC(t2, (size_t)(o_f + 1) / 2); e->twbm_f = reinterpret_cast<unsigned short*>(t2);
+            }
+            if (o_d) { DALLOC(t2, (size_t)(o_d + 1) / 2); e->wbm_d = reinterpret_cast<unsigned short*>(t2); }
+            e->n_bm_f = (int)bf_.size(); e->n_bm_f_blocks = nbf; e->n_bm_d = (int)bd_.size(); e->n_bm_d_blocks = nbd;
+            if (!bf_.empty()) {
+                DALLOC(e->bm_f, bf_.size());
+                HIPCHK(hipMemcpy(e->bm_f, bf_.data(), bf_.size() * sizeof(SplitJobBM), hipMemcpyHostToDevice));
+            }
+            if (!bd_.empty()) {
+                DALLOC(e->bm_d, bd_.size());
+                HIPCHK(hipMemcpy(e->bm_d, bd_.data(), bd_.size() * sizeof(SplitJobBM), hipMemcpyHostToDevice));
+            }
         }
         float* tmp = nullptr;
         if (off_f) {
@@ -739,6 +805,34 @@ int alloc_workspaces(fm_engine* e)
     DALLOC(e->psum, (size_t)2 * e->C * e->D); DALLOC(e->pcnt, 2 * e->C); DALLOC(e->tcnt, e->C);
     DALLOC(e->sel_counts, 2); DALLOC(e->cls_dev, FM_MAX_CLASSES);
     DALLOC(e->zeros, 64);
+    if (e->planes) {
+        auto palloc = [&](unsigned short** pp, size_t elems) -> int {       // planes of `elems` fp32 values: 3 x 2 B each
+            float* t = nullptr;
+            DALLOC(t, (elems * 3 + 1) / 2);
+            *pp = reinterpret_cast<unsigned short*>(t);
+            return FM_OK;
+        };
+        const Conv& cs = e->convs[0];
+        const size_t pooled = B * (cs.hout / 2) * (cs.wout / 2) * 64;
+        if (palloc(&e->p0p, pooled) || palloc(&e->GBp, pooled) || palloc(&e->GCp, pooled) || palloc(&e->GDp, pooled)) return FM_ERR_HIP;
+        for (auto& blk : e->blocks) {
+            const Conv& c = e->convs[blk.c1];
+            const size_t n = B * c.hout * c.wout * c.cout;
+            if (palloc(&blk.z1p, n) || palloc(&blk.outp, n)) return FM_ERR_HIP;
+        }
+        // scratch planes for operands that arrive as fp32 (test hooks): the largest conv input / output-gradient tensor
+        size_t mx = 0;
+        for (auto& c : e->convs) {
+            if (c.cin == 3) continue;
+            mx = std::max(mx, std::max(B * c.hin * c.win * c.cin_p, B * c.hout * c.wout * c.cout_p));
+        }
+        e->xp_scratch_elems = mx * 3;
+        float* t3 = nullptr;
+        DALLOC(t3, (e->xp_scratch_elems + 1) / 2);
+        e->xp_scratch = reinterpret_cast<unsigned short*>(t3);
+        DALLOC(t3, (e->xp_scratch_elems + 1) / 2);
+        e->xp_scratch2 = reinterpret_cast<unsigned short*>(t3);
+    }
     DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);   // [blocks][2][BM*BN]
     DALLOC(e->sk_counters, (size_t)1 << 20);
     HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
@@ -756,6 +850,7 @@ int alloc_workspaces(fm_engine* e)
                 need += (size_t)(blk.ds >= 0 ? 3 : 2) * B * c.hout * c.wout * c.cout * 4;
             }
             need += (size_t)igemm_max_blocks() * 2 * 16384 * 4 + ((size_t)4 << 20);
+            if (e->planes) need += need * 3 / 2;       // the planes of the teacher's activations and of the second gradient set
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)4 << 30)) side = 0;
         }
         if (side) {
@@ -794,6 +889,25 @@ int alloc_workspaces(fm_engine* e)
                 }
             }
         }
+    }
+    if (e->planes) {       // the side stream's sets of planes (teacher activations, second gradient buffers)
+        auto palloc = [&](unsigned short** pp, size_t elems) -> int {
+            float* t = nullptr;
+            DALLOC(t, (elems * 3 + 1) / 2);
+            *pp = reinterpret_cast<unsigned short*>(t);
+            return FM_OK;
+        };
+        const Conv& cs = e->convs[0];
+        const size_t pooled = B * (cs.hout / 2) * (cs.wout / 2) * 64;
+        if (e->side_ok) {
+            if (palloc(&e->t_p0p, pooled)) return FM_ERR_HIP;
+            for (auto& blk : e->blocks) {
+                const Conv& c = e->convs[blk.c1];
+                const size_t n = B * c.hout * c.wout * c.cout;
+                if (palloc(&blk.t_z1p, n) || palloc(&blk.t_outp, n)) return FM_ERR_HIP;
+            }
+        }
+        if (e->side_w && (palloc(&e->GB2p, pooled) || palloc(&e->GC2p, pooled) || palloc(&e->GD2p, pooled))) return FM_ERR_HIP;
     }
     HIPCHK(hipMemset(e->zeros, 0, 64 * 4));
     return FM_OK;
@@ -852,11 +966,52 @@ struct Prologue { const float* psc; const float* psh; const float* gate; };
 
 const bf16* shadow_of(fm_engine* e, const float* S) { return S == e->tstate ? e->twb : e->wb; }
 
+// planes of an fp32 NHWC operand nobody produced planes for (test hooks): [C/32][3][npix][32] in the scratch buffer
+const unsigned short* scratch_planes(fm_engine* e, const float* x, long long npix, int C)
+{
+    if ((size_t)npix * C * 3 > e->xp_scratch_elems) { soft(e, hipErrorInvalidValue); return nullptr; }
+    // FM_DEBUG_REUSE_PLANES=1 (tools/probe_conv.py): time the GEMM alone -- the planes of the same operand are made once
+    static const bool reuse = getenv("FM_DEBUG_REUSE_PLANES") && atoi(getenv("FM_DEBUG_REUSE_PLANES")) != 0;
+    if (reuse && e->xp_scratch_src == x && e->xp_scratch_npix == npix) return e->xp_scratch;
+    k_split_planes(x, e->xp_scratch, npix, C, e->st);
+    e->xp_scratch_src = x; e->xp_scratch_npix = npix;
+    return e->xp_scratch;
+}
+bool conv_uses_pconv(const fm_engine* e, const Conv& c, int imgs)
+{
+    return e->planes && c.bm_off >= 0 && pconv_takes(c.cout_p, c.cin_p, (long long)imgs * c.hin * c.win, c.win);
+}
+
+// xp: the input's block-major planes (planes mode; null = made here from x); yp: also / only write the output's planes
+// (eval epilogue; y may then be null)
 void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, int imgs, int groups,
               const float* scale, const float* shift, const float* res, int relu, float* stats,
-              const Prologue* pro = nullptr)
+              const Prologue* pro = nullptr, const unsigned short* xp = nullptr, unsigned short* yp = nullptr)
 {
     Conv& c = e->convs[ci];
+    if (conv_uses_pconv(e, c, imgs)) {
+        IgemmParams p{};
+        p.xp_pix = (long long)imgs * c.hin * c.win;
+        p.Xp = xp ? xp : scratch_planes(e, x, p.xp_pix, c.cin_p);
+        p.Wsp = (S == e->tstate ? e->twbm_f : e->wbm_f) + c.bm_off;
+        p.Y = y; p.Yp = yp; p.yp_pix = (long long)imgs * c.hout * c.wout;
+        p.slab = e->sk_slab; p.counters = e->sk_counters; p.sp = e->products;
+        p.ntaps = c.k * c.k;
+        for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
+        p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
+        p.M = c.cout_p;
+        p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
+        p.Hg = c.hout; p.Wg = c.wout; p.sg = c.stride;
+        p.Ho = c.hout; p.Wo = c.wout; p.Co = c.cout_p;
+        p.os = 1; p.oh0 = 0; p.ow0 = 0;
+        p.imgs_per_group = imgs / groups;
+        p.tilesM = c.cout_p / pconv_tile_m(c.cout_p);
+        p.tilesN = (p.imgs_per_group * c.hout * c.wout + pconv_tile_n() - 1) / pconv_tile_n();
+        p.relu = relu;
+        ProfScope ps(e, c.cout_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs);
+        launch_pconv(p, groups, e->st);
+        return;
+    }
     const bool stem16 = e->precision && c.cin == 3;     // `x` is ignored: the operand is the im2col matrix
     if (e->precision && (c.k == 1 || stem16)) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
         PwParams q{};
@@ -913,6 +1068,7 @@ int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
     const Conv& c = e->convs[ci];
     if (e->precision && (c.k == 1 || c.cin == 3))
         return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro, c.hout * c.wout);
+    if (conv_uses_pconv(e, c, imgs_per_group * groups)) return (imgs_per_group * c.hout * c.wout + pconv_tile_n() - 1) / pconv_tile_n();
     const int bn = igemm_tile_n(c.cout_p, c.cin == 3);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
@@ -920,9 +1076,37 @@ int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
 // dx[imgs][hin][win][cin] = dgrad(dy[imgs][hout][wout][cout]); res: optional residual added
 // (for stride-2 convs `acc_cls0` adds the existing dx contents for parity class (0,0))
 void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx, int imgs, const float* res,
-                bool acc_cls0)
+                bool acc_cls0, const unsigned short* dyp = nullptr)
 {
     Conv& c = e->convs[ci];
+    if (e->planes && c.ncls > 0 && c.cls[0].bm_off >= 0 &&
+        pconv_takes(c.cin_p, c.cout_p, (long long)imgs * c.hout * c.wout, c.wout)) {
+        const long long xp_pix = (long long)imgs * c.hout * c.wout;
+        if (!dyp) dyp = scratch_planes(e, dy, xp_pix, c.cout_p);
+        for (int k = 0; k < c.ncls; ++k) {
+            DgradClass& d = c.cls[k];
+            IgemmParams p{};
+            p.Xp = dyp; p.xp_pix = xp_pix; p.Wsp = e->wbm_d + d.bm_off;
+            p.Y = dx; p.slab = e->sk_slab; p.counters = e->sk_counters; p.sp = e->products;
+            p.ntaps = d.taps.n;
+            for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
+            p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
+            p.M = c.cin_p;
+            p.Hi = c.hout; p.Wi = c.wout; p.Ci = c.cout_p;
+            p.Hg = (c.hin - d.ph + c.stride - 1) / c.stride;
+            p.Wg = (c.win - d.pw + c.stride - 1) / c.stride;
+            p.sg = 1;
+            p.Ho = c.hin; p.Wo = c.win; p.Co = c.cin_p;
+            p.os = c.stride; p.oh0 = d.ph; p.ow0 = d.pw;
+            p.imgs_per_group = imgs;
+            p.tilesM = c.cin_p / pconv_tile_m(c.cin_p);
+            p.tilesN = (imgs * p.Hg * p.Wg + pconv_tile_n() - 1) / pconv_tile_n();
+            p.relu = 0;
+            ProfScope ps(e, c.cin_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
+            launch_pconv(p, 1, e->st);
+        }
+        return;
+    }
     if (e->precision && c.k == 1) {          // dX = dY W: the same streaming kernel with the transposed bf16 shadow
         PwParams q{};
         q.zeros = e->zeros;
@@ -961,10 +1145,34 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
     }
 }
 
+// xp / dyp (planes mode): block-major planes of x / dy (null = made here from the fp32 tensors: test hooks)
 void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs, const Prologue* pro = nullptr,
-                int pix_per_group = 0)
+                int pix_per_group = 0, const unsigned short* xp = nullptr, const unsigned short* dyp = nullptr)
 {
     const Conv& c = e->convs[ci];
+    if (e->planes && c.cin != 3 &&
+        pwgrad_takes(c.cout_p, c.cin_p, c.k, (long long)imgs * c.hout * c.wout, (long long)imgs * c.hin * c.win, c.win, c.pad)) {
+        PwgradParams q{};
+        q.npix = (long long)imgs * c.hout * c.wout; q.xpix = (long long)imgs * c.hin * c.win;
+        if (!xp) xp = scratch_planes(e, x, q.xpix, c.cin_p);
+        if (!dyp) {
+            if ((size_t)q.npix * c.cout_p * 3 > e->xp_scratch_elems) { soft(e, hipErrorInvalidValue); return; }
+            k_split_planes(dy, e->xp_scratch2, q.npix, c.cout_p, e->st);
+            dyp = e->xp_scratch2;
+        }
+        q.dYp = dyp; q.Xp = xp; q.slab = e->ws_slab;
+        q.M = c.cout_p; q.Nw = c.Kw;
+        q.Ho = c.hout; q.Wo = c.wout; q.Hi = c.hin; q.Wi = c.win; q.Ci = c.cin_p; q.stride = c.stride; q.pad = c.pad; q.ksz = c.k;
+        q.sp = e->products;
+        int sk;
+        {
+            ProfScope ps(e, c.cout_p >= 128 ? 3 : 4, 2.0 * c.macs_per_img * imgs);
+            sk = launch_pwgrad(q, e->slab_floats, e->st);
+        }
+        if (sk > 0) k_reduce_slabs(e->ws_slab, e->grad + c.w_off, sk, (int64_t)c.w_numel, e->st);
+        else soft(e, hipErrorInvalidValue);
+        return;
+    }
     const bool stem16 = e->precision && c.cin == 3;
     if (e->precision && (c.k == 1 || stem16)) {
         PwWgradParams q{};
@@ -1035,8 +1243,9 @@ void bn_fwd_finalize(fm_engine* e, int ci, int groups, int imgs_per_group)
 // backward through BN bi: dz (+ optional relu mask source z) -> dy ; optional masked grad out
 // z_is_relu_of_bn: z = relu(bn(y)) of THIS BatchNorm with nothing added (bn1 of a basic block): the ReLU mask is then
 // recomputed from y, which both passes read anyway, and z is not read (FM_BN_MASK_FROM_Y=0 reads z as before)
+// dyp (planes mode): also write dy's block-major planes (what the data gradient reads)
 void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, float* dyh_out, int groups,
-            int imgs_per_group, bool z_is_relu_of_bn = false)
+            int imgs_per_group, bool z_is_relu_of_bn = false, unsigned short* dyp = nullptr)
 {
     const Conv& c = e->convs[bi];
     Bn& b = e->bns[bi];
@@ -1049,7 +1258,8 @@ void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, fl
     k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix), b.C, pix, e->state + e->off_gamma + b.ch_off, b.mean,
                       b.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b.ch_off,
                       e->grad + e->off_beta + b.ch_off, e->st);
-    k_bn_bwd_apply(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyh_out, groups, pix, b.C, e->st, msc, msh);
+    if (dyp) k_bn_bwd_apply_planes(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyp, dyh_out, groups, pix, b.C, e->st, msc, msh);
+    else k_bn_bwd_apply(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyh_out, groups, pix, b.C, e->st, msc, msh);
 }
 
 void to_nhwc4(fm_engine* e, const float* const* xs, int groups, int B)
@@ -1079,29 +1289,36 @@ void forward_train(fm_engine* e, int groups, int B)
     Conv& c0 = e->convs[0];
     conv_fwd(e, 0, S, e->x4, c0.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
     bn_fwd_finalize(e, 0, groups, B);
-    k_stem_pool(c0.y, e->bns[0].scale, e->bns[0].shift, e->p0, e->idx0, groups, B, c0.hout, c0.wout, 64, e->st);
+    const bool pm = e->planes;
+    if (pm) k_stem_pool_planes(c0.y, e->bns[0].scale, e->bns[0].shift, e->p0, e->idx0, e->p0p, groups, B, c0.hout, c0.wout, 64, e->st);
+    else k_stem_pool(c0.y, e->bns[0].scale, e->bns[0].shift, e->p0, e->idx0, groups, B, c0.hout, c0.wout, 64, e->st);
+    // BatchNorm apply: fp32 `out` for the elementwise consumers (residual, ReLU mask), planes `outp` for the conv GEMMs
+    auto apply = [&](const float* y, int b1, const float* res, const float* y2, int b2, float* out, unsigned short* outp, int pix, int C) {
+        const float *s2 = y2 ? e->bns[b2].scale : nullptr, *h2 = y2 ? e->bns[b2].shift : nullptr;
+        if (pm) k_bn_apply_planes(y, e->bns[b1].scale, e->bns[b1].shift, res, y2, s2, h2, out, outp, groups, pix, C, 1, e->st);
+        else k_bn_apply(y, e->bns[b1].scale, e->bns[b1].shift, res, y2, s2, h2, out, groups, pix, C, 1, e->st);
+    };
     const float* cur = e->p0;
+    const unsigned short* curp = e->p0p;
     for (auto& blk : e->blocks) {
         Conv& c1 = e->convs[blk.c1];
         Conv& c2 = e->convs[blk.c2];
         const int pix = B * c1.hout * c1.wout;
-        conv_fwd(e, blk.c1, S, cur, c1.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+        conv_fwd(e, blk.c1, S, cur, c1.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, nullptr, curp);
         bn_fwd_finalize(e, blk.c1, groups, B);
-        k_bn_apply(c1.y, e->bns[blk.c1].scale, e->bns[blk.c1].shift, nullptr, nullptr, nullptr, nullptr, blk.z1,
-                   groups, pix, c1.cout, 1, e->st);
-        conv_fwd(e, blk.c2, S, blk.z1, c2.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+        apply(c1.y, blk.c1, nullptr, nullptr, -1, blk.z1, blk.z1p, pix, c1.cout);
+        conv_fwd(e, blk.c2, S, blk.z1, c2.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, nullptr, blk.z1p);
         bn_fwd_finalize(e, blk.c2, groups, B);
         if (blk.ds >= 0) {
             Conv& cd = e->convs[blk.ds];
-            conv_fwd(e, blk.ds, S, cur, cd.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats);
+            conv_fwd(e, blk.ds, S, cur, cd.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, nullptr, curp);
             bn_fwd_finalize(e, blk.ds, groups, B);
-            k_bn_apply(c2.y, e->bns[blk.c2].scale, e->bns[blk.c2].shift, nullptr, cd.y, e->bns[blk.ds].scale,
-                       e->bns[blk.ds].shift, blk.out, groups, pix, c2.cout, 1, e->st);
+            apply(c2.y, blk.c2, nullptr, cd.y, blk.ds, blk.out, blk.outp, pix, c2.cout);
         } else {
-            k_bn_apply(c2.y, e->bns[blk.c2].scale, e->bns[blk.c2].shift, cur, nullptr, nullptr, nullptr, blk.out,
-                       groups, pix, c2.cout, 1, e->st);
+            apply(c2.y, blk.c2, cur, nullptr, -1, blk.out, blk.outp, pix, c2.cout);
         }
         cur = blk.out;
+        curp = blk.outp;
     }
     const Conv& cl = e->convs[e->blocks.back().c2];
     k_avgpool(cur, DT_F32, e->feat, imgs, cl.hout * cl.wout, 512, e->st);
@@ -1122,18 +1339,28 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
     auto sh = [&](int bi) { return evh + e->bns[bi].ch_off; };
     Conv& c0 = e->convs[0];
     conv_fwd(e, 0, S, e->x4, c0.y, imgs, 1, sc(0), sh(0), nullptr, 1, nullptr);
-    k_stem_pool(c0.y, nullptr, nullptr, e->p0, nullptr, 1, imgs, c0.hout, c0.wout, 64, e->st);
+    const bool pm = e->planes;
+    if (pm) k_stem_pool_planes(c0.y, nullptr, nullptr, e->p0, nullptr, e->p0p, 1, imgs, c0.hout, c0.wout, 64, e->st);
+    else k_stem_pool(c0.y, nullptr, nullptr, e->p0, nullptr, 1, imgs, c0.hout, c0.wout, 64, e->st);
     const float* cur = e->p0;
-    for (auto& blk : e->blocks) {
-        conv_fwd(e, blk.c1, S, cur, blk.z1, imgs, 1, sc(blk.c1), sh(blk.c1), nullptr, 1, nullptr);
+    const unsigned short* curp = e->p0p;
+    for (size_t bi = 0; bi < e->blocks.size(); ++bi) {
+        Block& blk = e->blocks[bi];
+        // planes mode: z1 is read by the next conv only -> planes only; `out` is the next block's residual (fp32) and conv input
+        // (planes; none for the last block, which feeds the average pool)
+        const bool last = bi + 1 == e->blocks.size();
+        conv_fwd(e, blk.c1, S, cur, pm ? nullptr : blk.z1, imgs, 1, sc(blk.c1), sh(blk.c1), nullptr, 1, nullptr, nullptr, curp,
+                 pm ? blk.z1p : nullptr);
         const float* idt = cur;
         if (blk.ds >= 0) {
             Conv& cd = e->convs[blk.ds];
-            conv_fwd(e, blk.ds, S, cur, cd.y, imgs, 1, sc(blk.ds), sh(blk.ds), nullptr, 0, nullptr);
+            conv_fwd(e, blk.ds, S, cur, cd.y, imgs, 1, sc(blk.ds), sh(blk.ds), nullptr, 0, nullptr, nullptr, curp);
             idt = cd.y;
         }
-        conv_fwd(e, blk.c2, S, blk.z1, blk.out, imgs, 1, sc(blk.c2), sh(blk.c2), idt, 1, nullptr);
+        conv_fwd(e, blk.c2, S, blk.z1, blk.out, imgs, 1, sc(blk.c2), sh(blk.c2), idt, 1, nullptr, nullptr, blk.z1p,
+                 (pm && !last) ? blk.outp : nullptr);
         cur = blk.out;
+        curp = blk.outp;
     }
     const Conv& cl = e->convs[e->blocks.back().c2];
     k_avgpool(cur, DT_F32, feat, imgs, cl.hout * cl.wout, 512, e->st);
@@ -1146,14 +1373,20 @@ void ensure_packed(fm_engine* e)
     if (!e->wpack_dirty) return;
     if (e->precision) launch_cast_weights(e->state, e->wb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
     else if (e->n_pack_jobs) k_pack_dgrad_all(e->state, e->pack_jobs, e->n_pack_jobs, e->n_pack_blocks, e->st);
-    k_split_weights(e->state, e->wsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
-    k_split_weights(nullptr, e->wsp_d, e->split_d, e->n_split_d, e->n_split_d_blocks, e->st);     // planes of the packs just made
+    if (e->planes) {
+        k_split_weights_bm(e->state, e->wbm_f, e->bm_f, e->n_bm_f, e->n_bm_f_blocks, e->st);
+        k_split_weights_bm(nullptr, e->wbm_d, e->bm_d, e->n_bm_d, e->n_bm_d_blocks, e->st);      // planes of the packs just made
+    } else {
+        k_split_weights(e->state, e->wsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
+        k_split_weights(nullptr, e->wsp_d, e->split_d, e->n_split_d, e->n_split_d_blocks, e->st);     // planes of the packs just made
+    }
     e->wpack_dirty = false;
 }
 void ensure_teacher_shadow(fm_engine* e)
 {
     if (!e->twb_dirty) return;
     if (e->precision) launch_cast_weights(e->tstate, e->twb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
+    else if (e->planes) k_split_weights_bm(e->tstate, e->twbm_f, e->bm_f, e->n_bm_f, e->n_bm_f_blocks, e->st);
     else k_split_weights(e->tstate, e->twsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
     e->twb_dirty = false;
 }
@@ -1183,6 +1416,10 @@ void backward_and_step(fm_engine* e, int groups, int B)
     float* GBp[2] = {e->GB, sw ? e->GB2 : e->GB};
     float* GCp[2] = {e->GC, sw ? e->GC2 : e->GC};
     float* GDp[2] = {e->GD, sw ? e->GD2 : e->GD};
+    const bool pm = e->planes;
+    unsigned short* PB[2] = {e->GBp, sw ? e->GB2p : e->GBp};
+    unsigned short* PC[2] = {e->GCp, sw ? e->GC2p : e->GCp};
+    unsigned short* PD[2] = {e->GDp, sw ? e->GD2p : e->GDp};
     hipStream_t main_st = e->st;
     auto side_begin = [&](int k, int par) {
         if (!sw) return;
@@ -1205,28 +1442,30 @@ void backward_and_step(fm_engine* e, int groups, int B)
         Block& blk = e->blocks[b];
         const int par = b & 1;
         float *GB = GBp[par], *GC = GCp[par], *GD = GDp[par];
+        unsigned short *gbp = pm ? PB[par] : nullptr, *gcp = pm ? PC[par] : nullptr, *gdp = pm ? PD[par] : nullptr;
         const float* in = b == 0 ? e->p0 : e->blocks[b - 1].out;
         // out = relu(bn2(y2) + identity): masked grad dyh goes to bn2 and to the identity path
         guard(0, par);
-        bn_bwd(e, blk.c2, ga, blk.out, GB, ga, groups, B);
-        if (blk.ds >= 0) { guard(1, par); bn_bwd(e, blk.ds, ga, nullptr, GC, nullptr, groups, B); }
+        bn_bwd(e, blk.c2, ga, blk.out, GB, ga, groups, B, false, gbp);
+        if (blk.ds >= 0) { guard(1, par); bn_bwd(e, blk.ds, ga, nullptr, GC, nullptr, groups, B, false, gcp); }
         side_begin(0, par);
-        conv_wgrad(e, blk.c2, blk.z1, GB, imgs);
+        conv_wgrad(e, blk.c2, blk.z1, GB, imgs, nullptr, 0, pm ? blk.z1p : nullptr, gbp);
         side_end(0, par);
         guard(2, par);
-        conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false);
-        bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true);
+        conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false, gbp);
+        bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true, gdp);
         side_begin(2, par);
-        conv_wgrad(e, blk.c1, in, GD, imgs);
+        const unsigned short* inp = pm ? (b == 0 ? e->p0p : e->blocks[b - 1].outp) : nullptr;
+        conv_wgrad(e, blk.c1, in, GD, imgs, nullptr, 0, inp, gdp);
         side_end(2, par);
         if (blk.ds >= 0) {
             side_begin(1, par);
-            conv_wgrad(e, blk.ds, in, GC, imgs);
+            conv_wgrad(e, blk.ds, in, GC, imgs, nullptr, 0, inp, gcp);
             side_end(1, par);
-            conv_dgrad(e, blk.ds, S, GC, ge, imgs, nullptr, false);   // writes parity class (0,0)
-            conv_dgrad(e, blk.c1, S, GD, ge, imgs, nullptr, true);    // all classes, (0,0) accumulates
+            conv_dgrad(e, blk.ds, S, GC, ge, imgs, nullptr, false, gcp);   // writes parity class (0,0)
+            conv_dgrad(e, blk.c1, S, GD, ge, imgs, nullptr, true, gdp);    // all classes, (0,0) accumulates
         } else {
-            conv_dgrad(e, blk.c1, S, GD, ge, imgs, ga, false);
+            conv_dgrad(e, blk.c1, S, GD, ge, imgs, ga, false, gdp);
         }
         std::swap(ga, ge);
     }
@@ -1636,9 +1875,10 @@ void swap_teacher_ws(fm_engine* e)
     }
     std::swap(e->sk_slab, e->sk_slab2); std::swap(e->sk_counters, e->sk_counters2);
     if (e->model == 0) {
-        std::swap(e->convs[0].y, e->t_c0y); std::swap(e->p0, e->t_p0);
+        std::swap(e->convs[0].y, e->t_c0y); std::swap(e->p0, e->t_p0); std::swap(e->p0p, e->t_p0p);
         for (auto& blk : e->blocks) {
             std::swap(blk.z1, blk.t_z1); std::swap(blk.out, blk.t_out);
+            std::swap(blk.z1p, blk.t_z1p); std::swap(blk.outp, blk.t_outp);
             if (blk.ds >= 0) std::swap(e->convs[blk.ds].y, blk.t_dsy);
         }
         return;
@@ -1699,6 +1939,8 @@ int fm_create(const fm_config* cfg, fm_engine** out)
     // the product form belongs to the handle: fixed here, carried to every launch in the kernels' parameter blocks.  0 resolves
     // to the library default, which the test-only FM_MFMA_SPLIT overrides (read once, here)
     e->products = cfg->reserved[2] == 1 ? 0 : (cfg->reserved[2] == 2 ? 9 : fm_mfma_split());
+    // planes mode: ResNet-18 in a split product form (FM_PLANES=0 keeps the fp32-operand kernels of igemm.hip: the A/B arm)
+    e->planes = cfg->model == 0 && cfg->reserved[0] == 0 && e->products != 0 && !(getenv("FM_PLANES") && atoi(getenv("FM_PLANES")) == 0);
     e->dt = e->precision ? DT_BF16 : DT_F32;
     e->fuse_gate = e->precision && !(getenv("FM_FUSE_GATE") && atoi(getenv("FM_FUSE_GATE")) == 0);
     e->cfg = *cfg;

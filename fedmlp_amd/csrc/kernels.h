@@ -35,6 +35,23 @@ int pack_job_blocks(int Co, int Ci, int ntaps);      // blocks of one job (32 x 
 struct SplitJob { long long src_off; const float* src; long long dst_off; int M, nkb, blk0; };
 void k_split_weights(const float* src_base, unsigned short* dst_base, const SplitJob* jobs, int njobs, int nblocks, hipStream_t s);
 int split_job_blocks(int M, int nkb);
+// block-major planes for pconv.hip: dst[K block s = (channel block, tap), tap-minor][3 planes][M][32] from W[M][ntaps][cib * 32]
+struct SplitJobBM { long long src_off; const float* src; long long dst_off; int M, ntaps, cib, blk0; };
+void k_split_weights_bm(const float* src_base, unsigned short* dst_base, const SplitJobBM* jobs, int njobs, int nblocks, hipStream_t s);
+int split_job_bm_blocks(int M, int nsteps);
+// block-major planes [C/32][3][npix][32] of an fp32 NHWC tensor [npix][C] (C % 32 == 0), and back (x = (h + m) + l, exact)
+void k_split_planes(const float* x, unsigned short* dst, long long npix, int C, hipStream_t s);
+void k_planes_to_f32(const unsigned short* src, float* x, long long npix, int C, hipStream_t s);
+// planes_ew.hip: k_bn_apply / k_stem_pool / k_bn_bwd_apply writing their result as block-major planes `...p` [C/32][3][groups*pix][32]
+// (C % 32 == 0) and, where the fp32 pointer is not null, as fp32 too
+void k_bn_apply_planes(const float* y, const float* scale, const float* shift, const float* res, const float* y2, const float* scale2,
+                       const float* shift2, float* out, unsigned short* outp, int groups, int pix_per_group, int C, int relu,
+                       hipStream_t s);
+void k_stem_pool_planes(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx, unsigned short* pooledp,
+                        int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);
+void k_bn_bwd_apply_planes(const float* dz, const float* z, const float* y, const float* ca, const float* cb, const float* cc, float* dy,
+                           unsigned short* dyp, float* dyh_out, int groups, int pix_per_group, int C, hipStream_t s,
+                           const float* mask_scale = nullptr, const float* mask_shift = nullptr);
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
 // utils/FedAvg.py:7-14 over K engine-layout states on one GPU: out = ((s0*n0 + s1*n1) + ...) / tot, the reference's
 // left-to-right order with separately rounded products, sums and an IEEE division (bit-identical on fp32 entries)

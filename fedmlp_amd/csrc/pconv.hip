@@ -1,0 +1,531 @@
+// Implicit-GEMM convolution (forward + data gradient) whose BOTH operands arrive as bf16 planes, gfx950.
+//
+// Reference op replaced: every nn.Conv2d forward inside net(images) (utils/local_training.py:657, 937-947, 983, 1030, 1178) and
+// its input gradient inside loss.backward() (:674, 965, 1191) for the 3x3 / 1x1 convolutions of torchvision's resnet18
+// (model/all_models.py:53-54).  Same arithmetic as igemm.hip's split form (split3.h): operands, accumulators and stored
+// tensors are fp32 values; every fp32 product is formed as six (SP = 6) or nine exact bf16 partial products on
+// v_mfma_f32_16x16x32_bf16 and accumulated in fp32.  What differs is WHO splits: here nobody does in this kernel.  The weight
+// planes are made once per optimizer step (k_split_weights_bm), the activation planes by the kernel that PRODUCES the tensor
+// (BatchNorm apply, max-pool, BatchNorm-backward apply, this kernel's own eval epilogue): x = h + m + l exactly, three bf16.
+//
+// Operand layout, "block-major planes":  P[K block of 32 channels][plane h|m|l][row][32] bf16 -- 64-B rows, 16 rows = 1 KB
+// contiguous.  row = output channel for the weights (K block = (channel block, tap), tap-minor) and = NHWC pixel for the
+// activations.  Inside a 32-channel block the 16-B chunk g holds channels 4g..4g+3 and 16+4g..16+4g+3 (both operands, so
+// the contraction does not care; it is the order in which an MFMA output lane holds two row tiles, so this kernel's epilogue
+// writes planes without a shuffle).
+//
+// Roofline: bf16 MFMA dense peak 2 500 TFLOP/s / SP products = 416.7 TFLOP/s of fp32 products (SP = 6).
+// Structure (tools/pconv_probe.hip measured it in isolation against the one it replaces):
+//  * ONE 8-wave block per CU (two waves per SIMD), block tile (32 FR) x 256: 128 x 256 for M >= 128, 64 x 256 for M = 64;
+//    wave tile (16 FR) x 64.
+//  * LDS: two stages of [A planes | B planes] = 2 x 3 x (BM + 256) x 64 B (144 KB / 120 KB), filled by LDS-DMA
+//    (buffer_load_dwordx4 ... lds, one instruction = 16 rows of one plane) through buffer descriptors: the per-lane part of an
+//    address is ONE 32-bit offset per 16-row group, computed once per tile; everything that changes per step is a scalar
+//    offset; padding / tail rows are an out-of-range offset, which the hardware answers with zeros.  Bank swizzle
+//    slot = chunk ^ ((row>>1)&3) on the SOURCE side and on the read (conflict-free ds_read_b128 on 64-B rows).
+//  * A wave's A fragments are double-buffered in REGISTERS: step s+1's are read during step s; the B fragments roll column
+//    by column one column ahead.  No VALU in the loop besides the padding select of the DMA offsets.
+//  * ONE barrier per K-step of 32, placed before the step's LAST column of MFMAs: by then every wave holds all the
+//    fragments the two stages can still be asked for, so the DMA of the steps after next starts there and has a whole step to land.
+//  * LDS reads are inline asm with explicit waits (issued at the head of a column's 6 FR MFMAs, waited for at its end): the
+//    compiler's own placement put them right in front of their first use.
+//  * Stream-K (as igemm.hip): the (tile, K-step) space is cut into equal contiguous ranges, one per block; partial tiles meet
+//    in a slab, the last arriver sums them in segment order (deterministic) and runs the epilogue.  ResNet's pixel counts are
+//    49 * 2^k: one-tile-per-block grids leave 23 % of the CUs idle on three of the four layers.
+//  * Epilogues: raw fp32 + BatchNorm partial sums (train forward), folded eval BatchNorm + residual + ReLU with fp32 and /
+//    or plane output (eval forward), raw + residual with strided placement (data gradient, parity classes of stride 2).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+#include "split3.h"
+
+#if __HIP_DEVICE_COMPILE__
+template <int IMM> __device__ __forceinline__ sp_u32x4 pc_lds_read128(unsigned addr)
+{
+    sp_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3], const sp_u32x4 (&b)[3], f32x4 v)
+{
+    return mfma_split<SP>(a[0], a[1], a[2], b[0], b[1], b[2], v);
+}
+#endif
+
+template <int FR, int SP>
+__global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
+{
+#if __HIP_DEVICE_COMPILE__
+    constexpr int WN = 4, FC = 4;
+    constexpr int BM = 32 * FR, BN = 256;
+    constexpr int SA = 3 * BM * 64, SB = 3 * BN * 64;          // bytes per stage
+    constexpr int GA = BM / 16, GB = BN / 16;                  // 16-row groups per operand tile
+    constexpr int JA = (3 * GA + 7) / 8;                       // A DMA instructions per wave per stage (3 or 2 of 1.5)
+    constexpr int RGB = GB / 8;                                // B row groups per wave (2), each x 3 planes
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)smem;              // LDS byte address of the dynamic segment
+    const unsigned As = lds0, Bs = lds0 + 2 * SA;              // [2][3][BM][64], [2][3][BN][64]
+
+    const int nsteps = p.nsteps;                               // K-steps of 32: (channel block, tap), tap-minor
+    const int ntaps = p.ntaps;
+    const int HWg = p.Hg * p.Wg;
+    const int npix = p.imgs_per_group * HWg;
+    const int tiles_pg = p.tilesM * p.tilesN;
+    const int Wi = p.Wi;
+
+    // XCD-aware bijective remap of the block id to a range index
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7;
+    const int rbk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const long long S = p.steps_per_block;
+    long long w = (long long)rbk * S;
+    const long long wend = min(p.total_steps, w + S);
+
+    // buffer descriptors.  X: the base sits (Wi + 1) pixels BELOW the tensor, so that the tap offsets (dh + 1) * Wi + (dw + 1)
+    // are never negative (the launcher keeps the planes below 2 GB: 0x80000000 is out of range for every descriptor)
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.Wsp), 0, (unsigned)((size_t)nsteps * 3 * p.M * 64), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.Xp) - (size_t)(Wi + 1) * 64), 0,
+        (unsigned)(((size_t)(p.Ci >> 5) * 3 * p.xp_pix + (size_t)(Wi + 1)) * 64), 0x00020000);
+    const int drow = lane >> 2, chunk = (lane & 3) ^ ((lane >> 3) & 3);
+    // fragment reads: row 16r + li of the wave's rows, chunk lg sits in slot lg ^ ((li>>1)&3)
+    const unsigned fro = li * 64 + ((lg ^ ((li >> 1) & 3)) << 4);
+    const unsigned Af0 = As + wm * (16 * FR) * 64 + fro, Af1 = Af0 + SA;
+    const unsigned Bf0 = Bs + wn * 64 * 64 + fro, Bf1 = Bf0 + SB;
+
+    while (w < wend) {
+        const int tile = (int)(w / nsteps);
+        const int k0 = (int)(w - (long long)tile * nsteps);
+        const int k1 = min(nsteps, k0 + (int)(wend - w));
+        const bool seg_first_of_block = (w == (long long)rbk * S);
+        w += k1 - k0;
+        const int grp = tile / tiles_pg;
+        const int tl = tile - grp * tiles_pg;
+        const int tm = p.tn_fast ? tl / p.tilesN : tl % p.tilesM;
+        const int tn = p.tn_fast ? tl % p.tilesN : tl / p.tilesM;
+        const int m0 = tm * BM, n0 = tn * BN;
+
+        // ---- LDS-DMA sources of this tile -------------------------------------------------------------------------------
+        // A job j = plane j / GA, row group j % GA; wave takes j = wave + 8 q.  Rows past M never occur (M % BM == 0).
+        const unsigned voffA = (unsigned)((m0 + drow) * 64 + chunk * 16);
+        // B: row group g = wave + 8 i holds output pixels n0 + 16 g + drow of the group's virtual grid
+        unsigned voffB[RGB], vmask[RGB];
+#pragma unroll
+        for (int i = 0; i < RGB; ++i) {
+            const int n = n0 + 16 * (wave + 8 * i) + drow;
+            const bool rv = n < npix;
+            const int nn = rv ? n : 0;
+            const int img = nn / HWg, rem = nn - img * HWg;
+            const int hg = rem / p.Wg, wg = rem - hg * p.Wg;
+            const int ih0 = hg * p.sg, iw0 = wg * p.sg;
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const unsigned f = (unsigned)(p.tapcode >> (4 * t)) & 15u;
+                const int ih = ih0 + (int)(f & 3u) - 1, iw = iw0 + (int)(f >> 2) - 1;
+                if (t < ntaps && rv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)Wi) vm |= 1u << t;
+            }
+            vmask[i] = vm;
+            voffB[i] = (unsigned)((((grp * p.imgs_per_group + img) * p.Hi + ih0) * Wi + iw0) * 64 + chunk * 16);
+        }
+        auto issueA = [&](int s, int slot) {
+#pragma unroll
+            for (int q = 0; q < JA; ++q) {
+                const int j = wave + 8 * q;
+                if ((3 * GA) % 8 != 0 && j >= 3 * GA) break;
+                const int plane = j / GA, gr = j % GA;
+                const unsigned so = (unsigned)(((s * 3 + plane) * p.M + 16 * gr) * 64);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(size_t)(As + slot * SA + j * 1024), 16, voffA, so, 0, 0);
+            }
+        };
+        // B steps are issued strictly in order k0, k0 + 1, ...: the (channel block, tap) cursor advances with them
+        int icc_b = k0 / ntaps, it_b = k0 - icc_b * ntaps;
+        auto issueB = [&](int slot) {
+            const unsigned f = (unsigned)(p.tapcode >> (4 * it_b)) & 15u;
+            const unsigned tapo = ((f & 3u) * (unsigned)Wi + (f >> 2)) * 64u;           // (dh + 1) * Wi + (dw + 1) pixels
+#pragma unroll
+            for (int i = 0; i < RGB; ++i) {
+                const unsigned vo = ((vmask[i] >> it_b) & 1u) ? voffB[i] : OOB;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned so = (unsigned)((size_t)(icc_b * 3 + pl) * p.xp_pix * 64) + tapo;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(size_t)(Bs + slot * SB + (pl * GB + wave + 8 * i) * 1024), 16,
+                                                             vo, so, 0, 0);
+                }
+            }
+            if (++it_b == ntaps) { it_b = 0; ++icc_b; }
+        };
+
+        f32x4 acc[FR][FC];
+#pragma unroll
+        for (int r = 0; r < FR; ++r)
+#pragma unroll
+            for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sp_u32x4 A0[FR][3], A1[FR][3], Bb[2][3];
+#define PC_READA(SLOT, R, DST)                                                                  \
+    {                                                                                           \
+        DST[0] = pc_lds_read128<(0 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                  \
+        DST[1] = pc_lds_read128<(1 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                  \
+        DST[2] = pc_lds_read128<(2 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                  \
+    }
+#define PC_READB(SLOT, C, DST)                                                                  \
+    {                                                                                           \
+        DST[0] = pc_lds_read128<(0 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
+        DST[1] = pc_lds_read128<(1 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
+        DST[2] = pc_lds_read128<(2 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
+    }
+#define PC_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+        // ---- prologue: slots are indexed by the step's parity relative to k0 ------------------------------------------------
+        issueA(k0, 0);
+        issueB(0);
+        if (k0 + 1 < k1) issueA(k0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (k0 + 1 < k1) issueB(1);
+        PC_READA(0, 0, A0[0]);
+        PC_READA(0, 1, A0[1]);
+        if constexpr (FR == 4) { PC_READA(0, 2, A0[2]); PC_READA(0, 3, A0[3]); }
+        PC_READB(0, 0, Bb[0]);
+        PC_LGKM0();
+        __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + 2)
+        asm volatile("" ::: "memory");
+        if (k0 + 2 < k1) issueA(k0 + 2, 0);
+
+        // one K-step (slot parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
+        // FULL: steps s+1, s+2, s+3 exist (the main loop: no branch inside); otherwise the conditions are tested
+        auto step = [&](auto par_c, auto full_c, int s, sp_u32x4 (&Ac)[FR][3], sp_u32x4 (&An)[FR][3]) {
+            constexpr int PAR = decltype(par_c)::value;
+            constexpr bool FULL = decltype(full_c)::value;
+            // columns 0 .. 2: the next column's B fragments and a share of the next step's A fragments go out at the head of
+            // the column's MFMAs and are waited for at its end
+#define PC_COLUMN(C)                                                                                             \
+            {                                                                                                    \
+                PC_READB(PAR, (C) + 1, Bb[((C) + 1) & 1]);                                                       \
+                if (FULL || s + 1 < k1) {                                                                        \
+                    if constexpr (FR == 4) {                                                                     \
+                        if constexpr ((C) == 0) { PC_READA(PAR ^ 1, 0, An[0]); PC_READA(PAR ^ 1, 1, An[1]); }    \
+                        if constexpr ((C) == 1) { PC_READA(PAR ^ 1, 2, An[2]); }                                 \
+                        if constexpr ((C) == 2) { PC_READA(PAR ^ 1, 3, An[3]); }                                 \
+                    } else {                                                                                     \
+                        if constexpr ((C) == 0) { PC_READA(PAR ^ 1, 0, An[0]); }                                 \
+                        if constexpr ((C) == 1) { PC_READA(PAR ^ 1, 1, An[1]); }                                 \
+                    }                                                                                            \
+                }                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[(C) & 1], acc[r][C]); \
+                PC_LGKM0();                                                                                      \
+            }
+            PC_COLUMN(0)
+            PC_COLUMN(1)
+            PC_COLUMN(2)
+#undef PC_COLUMN
+            // last column: every wave holds all of this step's fragments and step s+1's A fragments: both read slots are free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (FULL || s + 1 < k1) PC_READB(PAR ^ 1, 0, Bb[0]);
+            if (FULL || s + 2 < k1) issueB(PAR);
+            if (FULL || s + 3 < k1) issueA(s + 3, PAR ^ 1);
+#pragma unroll
+            for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[(FC - 1) & 1], acc[r][FC - 1]);
+            PC_LGKM0();
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        int s = k0;
+        for (; s + 5 <= k1; s += 2) {          // steps s and s + 1 are FULL: s + 1 + 3 < k1
+            step(I0{}, std::true_type{}, s, A0, A1);
+            step(I1{}, std::true_type{}, s + 1, A1, A0);
+        }
+        for (; s < k1; s += 2) {
+            step(I0{}, std::false_type{}, s, A0, A1);
+            if (s + 1 < k1) step(I1{}, std::false_type{}, s + 1, A1, A0);
+        }
+#undef PC_READA
+#undef PC_READB
+#undef PC_LGKM0
+        __syncthreads();       // all LDS reads done (and no DMA in flight) before the fix-up / epilogue reuse the LDS
+
+        // ---- stream-K fix-up: partial tiles meet in the slab ------------------------
+        float* fsmem = reinterpret_cast<float*>(smem);
+        if (k0 != 0 || k1 != nsteps) {
+            // slot 0: the block's first segment, slot 1: its last one (middle ones are whole tiles)
+            float* mine = p.slab + (size_t)(rbk * 2 + (seg_first_of_block ? 0 : 1)) * (BM * BN);
+#pragma unroll
+            for (int r = 0; r < FR; ++r)
+#pragma unroll
+                for (int c = 0; c < FC; ++c)
+                    *reinterpret_cast<f32x4*>(mine + ((r * FC + c) * 512 + tid) * 4) = acc[r][c];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+            __syncthreads();
+            const long long t0 = (long long)tile * nsteps;
+            const int b_first = (int)(t0 / S), b_last = (int)((t0 + nsteps - 1) / S);
+            int* flag = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep: the fence's own wait may be dropped
+                const int old = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == b_last - b_first;
+                if (last) {
+                    __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            const bool last = *flag != 0;
+            __syncthreads();                                          // flag word is reused as LDS below
+            if (!last) continue;
+            // last arriver: sum every segment of this tile in segment order (incl. its own, from the slab) -> the result is
+            // independent of which block arrived last
+#pragma unroll
+            for (int r = 0; r < FR; ++r)
+#pragma unroll
+                for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int bb = b_first; bb <= b_last; ++bb) {
+                const long long sstart = max(t0, (long long)bb * S);
+                const float* src = p.slab + (size_t)(bb * 2 + (sstart == (long long)bb * S ? 0 : 1)) * (BM * BN);
+#pragma unroll
+                for (int r = 0; r < FR; ++r)
+#pragma unroll
+                    for (int c = 0; c < FC; ++c)
+                        acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * FC + c) * 512 + tid) * 4);
+            }
+        }
+
+        // ---- epilogue -------------------------------------------------------------
+        // acc[r][c][q] = D[m = m0 + wm*16FR + 16r + 4*lg + q][n = n0 + wn*64 + 16c + li]
+        const int mbase = m0 + wm * (16 * FR) + 4 * lg;
+        if (p.stats) {
+            float* red = fsmem;            // [WN][BM][2]
+#pragma unroll
+            for (int r = 0; r < FR; ++r) {
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < FC; ++c) {
+                    s1 += acc[r][c];
+                    s2 += acc[r][c] * acc[r][c];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float u = s1[q], v = s2[q];
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) {
+                        u += __shfl_xor(u, d);
+                        v += __shfl_xor(v, d);
+                    }
+                    if (li == 0) {
+                        const int ml = wm * (16 * FR) + 16 * r + 4 * lg + q;
+                        red[(wn * BM + ml) * 2 + 0] = u;
+                        red[(wn * BM + ml) * 2 + 1] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int ch = tid; ch < BM; ch += 512) {
+                float u = 0.f, v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < WN; ++ww) {
+                    u += red[(ww * BM + ch) * 2 + 0];
+                    v += red[(ww * BM + ch) * 2 + 1];
+                }
+                float* st = p.stats + (size_t)(grp * p.tilesN + tn) * 2 * p.M;
+                st[m0 + ch] = u;
+                st[p.M + m0 + ch] = v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < FC; ++c) {
+            const int n = n0 + wn * 64 + 16 * c + li;
+            if (n >= npix) continue;
+            const int img = n / HWg;
+            const int rem = n - img * HWg;
+            const int hg = rem / p.Wg;
+            const int wg = rem - hg * p.Wg;
+            const size_t opix = (size_t)((grp * p.imgs_per_group + img) * p.Ho + hg * p.os + p.oh0) * p.Wo + (wg * p.os + p.ow0);
+            const size_t o = opix * p.Co;
+            f32x4 v[FR];
+#pragma unroll
+            for (int r = 0; r < FR; ++r) {
+                const int m = mbase + 16 * r;
+                v[r] = acc[r][c];
+                if (p.scale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + m);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + m);
+                    v[r] = v[r] * sc + sh;
+                }
+                if (p.res) v[r] += *reinterpret_cast<const f32x4*>(p.res + o + m);
+                if (p.relu == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[r][q] = fmaxf(v[r][q], 0.f);
+                }
+                if (p.Y) *reinterpret_cast<f32x4*>(p.Y + o + m) = v[r];
+            }
+            if (p.Yp) {
+                // planes of the output: rows r, r + 1 of this lane are chunk lg of the 32-channel block (m0 + wm*16FR + 16r) / 32
+#pragma unroll
+                for (int r = 0; r < FR; r += 2) {
+                    sp_u32x4 H, M, L;
+                    split3(v[r], v[r + 1], H, M, L);
+                    const size_t cb = (size_t)(m0 + wm * (16 * FR) + 16 * r) >> 5;
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(p.Yp) + ((cb * 3) * (size_t)p.yp_pix + opix) * 64 + lg * 16;
+                    *reinterpret_cast<sp_u32x4*>(dst) = H;
+                    *reinterpret_cast<sp_u32x4*>(dst + (size_t)p.yp_pix * 64) = M;
+                    *reinterpret_cast<sp_u32x4*>(dst + (size_t)p.yp_pix * 128) = L;
+                }
+            }
+        }
+        __syncthreads();       // LDS (stats scratch) is re-staged by the next segment
+    }
+#endif
+}
+
+// ---- weight planes, block-major: dst[K block s = (channel block, tap)][3][M][32] from fp32 W[M][ntaps][Ci] ------------------
+// One thread = one 8-value chunk (channels 4g..4g+3, 16+4g..16+4g+3 of a 32-channel block): two 16-B reads 64 B apart, three
+// 16-B writes (4 threads = 64 B of one row of one plane).  Thread order: (s, m, g) with g fastest, then m: writes are contiguous.
+__global__ __launch_bounds__(256) void split_weights_bm_kernel(const float* __restrict__ src_base, unsigned short* __restrict__ dst_base,
+                                                               const SplitJobBM* __restrict__ jobs, int njobs)
+{
+#if __HIP_DEVICE_COMPILE__
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+    const SplitJobBM jb = jobs[j];
+    const long long idx = (long long)((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+    const int nsteps = jb.ntaps * jb.cib;
+    if (idx >= (long long)nsteps * jb.M * 4) return;
+    const int g = (int)(idx & 3);
+    const int m = (int)((idx >> 2) % jb.M);
+    const int s = (int)((idx >> 2) / jb.M);
+    const int icc = s / jb.ntaps, it = s - icc * jb.ntaps;
+    const float* src = (jb.src ? jb.src : src_base + jb.src_off) + ((size_t)m * jb.ntaps + it) * (jb.cib * 32) + icc * 32;
+    sp_u32x4 H, M, L;
+    split3(ld4(src + 4 * g), ld4(src + 16 + 4 * g), H, M, L);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(dst_base + jb.dst_off) + (((size_t)s * 3) * jb.M + m) * 64 + g * 16;
+    *reinterpret_cast<sp_u32x4*>(dst) = H;
+    *reinterpret_cast<sp_u32x4*>(dst + (size_t)jb.M * 64) = M;
+    *reinterpret_cast<sp_u32x4*>(dst + (size_t)jb.M * 128) = L;
+#endif
+}
+int split_job_bm_blocks(int M, int nsteps) { return (int)(((long long)M * nsteps * 4 + 255) / 256); }
+void k_split_weights_bm(const float* src_base, unsigned short* dst_base, const SplitJobBM* jobs, int njobs, int nblocks, hipStream_t s)
+{
+    if (njobs > 0) hipLaunchKernelGGL(split_weights_bm_kernel, dim3(nblocks), dim3(256), 0, s, src_base, dst_base, jobs, njobs);
+}
+
+// ---- activation planes of an fp32 NHWC tensor (test hooks, the stem's pooled output when no producer made them) ----------
+// dst[C/32][3][npix][32]; one thread = one 8-value chunk of one pixel
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ dst, long long npix,
+                                                           int C)
+{
+#if __HIP_DEVICE_COMPILE__
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cpp = C >> 3;                    // chunks per pixel
+    if (idx >= npix * cpp) return;
+    const long long pix = idx / cpp;
+    const int q = (int)(idx - pix * cpp), cb = q >> 2, g = q & 3;
+    const float* src = x + pix * C + cb * 32;
+    sp_u32x4 H, M, L;
+    split3(ld4(src + 4 * g), ld4(src + 16 + 4 * g), H, M, L);
+    unsigned char* d = reinterpret_cast<unsigned char*>(dst) + (((size_t)cb * 3) * npix + pix) * 64 + g * 16;
+    *reinterpret_cast<sp_u32x4*>(d) = H;
+    *reinterpret_cast<sp_u32x4*>(d + (size_t)npix * 64) = M;
+    *reinterpret_cast<sp_u32x4*>(d + (size_t)npix * 128) = L;
+#endif
+}
+void k_split_planes(const float* x, unsigned short* dst, long long npix, int C, hipStream_t s)
+{
+    const long long n = npix * (C >> 3);
+    if (n > 0) hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, dst, npix, C);
+}
+
+int pconv_tile_m(int M) { return M >= 128 ? 128 : 64; }
+int pconv_tile_n() { return 256; }
+int pconv_max_blocks() { return 256; }     // ONE block per CU (120 - 144 KB of LDS)
+// does the planes kernel take this GEMM?  whole M tiles, whole 32-channel blocks, taps within [-1, 1], planes below 2 GB
+bool pconv_takes(int M, int Ci, long long xp_pix, int Wi)
+{
+    if (M % 64 != 0 || (M > 64 && M % 128 != 0) || Ci % 32 != 0) return false;
+    return ((long long)(Ci >> 5) * 3 * xp_pix + Wi + 1) * 64 < 0x7ff00000LL;
+}
+
+void launch_pconv(IgemmParams p, int groups, hipStream_t s)
+{
+    static bool attr_done = false;
+    constexpr int LDS_L = 2 * 3 * (128 + 256) * 64;      // 144 KB
+    constexpr int LDS_S = 2 * 3 * (64 + 256) * 64;       // 120 KB
+    if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 6>), LDS_L, "pconv_kernel<4, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 9>), LDS_L, "pconv_kernel<4, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 6>), LDS_S, "pconv_kernel<2, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 9>), LDS_S, "pconv_kernel<2, 9>");
+        attr_done = true;
+    }
+    p.nsteps = p.ntaps * (p.Ci >> 5);
+    const long long T = (long long)p.tilesM * p.tilesN * groups;
+    p.total_steps = T * p.nsteps;
+    p.tapcode = 0;
+    for (int t = 0; t < p.ntaps; ++t)      // taps of 3x3 / 1x1 convs and of their dgrad parity classes lie in [-1, 1]
+        p.tapcode |= (unsigned long long)(((p.dh[t] + 1) & 3) | (((p.dw[t] + 1) & 3) << 2)) << (4 * t);
+    // weights of one M-tile: BM rows x K x 6 B; beyond ~1 MB per M-tile the all-M-tiles working set no longer fits L2
+    static const int tn_fast = fm_tune("FM_TN_FAST", 2);
+    p.tn_fast = tn_fast == 1 ? 1 : (tn_fast == 2 ? (p.tilesM > 1 && (long long)p.M * p.nsteps * 192 > (3LL << 20)) : 0);
+    // persistent grid: every CU whenever there are >= 4 K-steps for each of them, otherwise one tile per block.
+    // FM_IGEMM_BLOCKS overrides the grid (tests force odd splits so that every fix-up path runs on small shapes).
+    static const int forced = getenv("FM_IGEMM_BLOCKS") ? atoi(getenv("FM_IGEMM_BLOCKS")) : 0;
+    int nblk = p.total_steps >= 4LL * pconv_max_blocks() ? pconv_max_blocks() : (int)std::min<long long>(pconv_max_blocks(), T);
+    if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, pconv_max_blocks()), p.total_steps);
+    p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
+    dim3 grid(nblk);
+    if (p.M >= 128) {
+        if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 9>), grid, dim3(512), LDS_L, s, p);
+        else hipLaunchKernelGGL((pconv_kernel<4, 6>), grid, dim3(512), LDS_L, s, p);
+    } else {
+        if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<2, 9>), grid, dim3(512), LDS_S, s, p);
+        else hipLaunchKernelGGL((pconv_kernel<2, 6>), grid, dim3(512), LDS_S, s, p);
+    }
+}
+
+// fp32 values back from their planes: x = (h + m) + l, both additions exact (test hooks read activations that are only kept as planes)
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ x, long long npix, int C)
+{
+#if __HIP_DEVICE_COMPILE__
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cpp = C >> 3;
+    if (idx >= npix * cpp) return;
+    const long long pix = idx / cpp;
+    const int q = (int)(idx - pix * cpp), cb = q >> 2, g = q & 3;
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(src) + (((size_t)cb * 3) * npix + pix) * 64 + g * 16;
+    const sp_u32x4 H = *reinterpret_cast<const sp_u32x4*>(s);
+    const sp_u32x4 M = *reinterpret_cast<const sp_u32x4*>(s + (size_t)npix * 64);
+    const sp_u32x4 L = *reinterpret_cast<const sp_u32x4*>(s + (size_t)npix * 128);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = (__builtin_bit_cast(float, H[i] << 16) + __builtin_bit_cast(float, M[i] << 16)) + __builtin_bit_cast(float, L[i] << 16);
+        v[2 * i + 1] = (__builtin_bit_cast(float, H[i] & 0xffff0000u) + __builtin_bit_cast(float, M[i] & 0xffff0000u)) +
+                       __builtin_bit_cast(float, L[i] & 0xffff0000u);
+    }
+    float* d = x + pix * C + cb * 32;
+    *reinterpret_cast<f32x4*>(d + 4 * g) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(d + 16 + 4 * g) = f32x4{v[4], v[5], v[6], v[7]};
+#endif
+}
+void k_planes_to_f32(const unsigned short* src, float* x, long long npix, int C, hipStream_t s)
+{
+    const long long n = npix * (C >> 3);
+    if (n > 0) hipLaunchKernelGGL(planes_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, x, npix, C);
+}

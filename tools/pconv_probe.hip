@@ -175,13 +175,13 @@ __global__ __launch_bounds__(512, 2) void pconv(const P p)
         for (int pl = 0; pl < 3; ++pl) Bb[0][pl] = Bb[1][pl] = u32x4{0x3f803f80u, (unsigned)lane * 0x3f803f80u, 0x3f003f00u, 0x3e803e80u};
     }
 #define READA(SLOT, R, DST)                                                                              \
-    if constexpr (MODE <= 1) {                                                                           \
+    if constexpr (MODE != 2) {                                                                           \
         DST[0] = lds_read128<(0 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                              \
         DST[1] = lds_read128<(1 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                              \
         DST[2] = lds_read128<(2 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                              \
     }
 #define READB(SLOT, C, DST)                                                                              \
-    if constexpr (MODE <= 1) {                                                                           \
+    if constexpr (MODE != 2) {                                                                           \
         DST[0] = lds_read128<(0 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                              \
         DST[1] = lds_read128<(1 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                              \
         DST[2] = lds_read128<(2 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                              \
