@@ -176,6 +176,7 @@ struct IgemmParams {
     long long xp_pix = 0;
     unsigned short* Yp = nullptr;
     long long yp_pix = 0;
+    const unsigned short* resp = nullptr;   // the residual as planes [Co/32][3][yp_pix][32] (dense output only), instead of `res`
     // floats per row of W when that is not nsteps * KS (the packed stem in 32-k stages: rows of 176 floats walked as 6 x 32 --
     // the 16 floats past a row's end meet the zero-page chunks of X); 0 = nsteps * KS
     int wrow = 0;

@@ -675,7 +675,8 @@ __device__ __forceinline__ f32x4 relu_mask_from_y(f32x4 d, f32x4 yy, f32x4 sc, f
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                      const float* __restrict__ y, const float* __restrict__ mean,
                                      const float* __restrict__ istd, float* __restrict__ part, int pix_per_group,
-                                     int C, const float* __restrict__ msc, const float* __restrict__ msh)
+                                     int C, const float* __restrict__ msc, const float* __restrict__ msh,
+                                     const unsigned short* __restrict__ zh, long long zP)
 {
     __shared__ f32x4 red[2][256];
     const int g = blockIdx.y, nblk = gridDim.x;
@@ -703,6 +704,17 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[k] = zz[k] > 0.f ? d[k] : 0.f;
         }
+        if (zh) {
+            // planes mode: z lives only as block-major planes; its sign is the sign of the h plane (z > 0 <=> bf16(z) > 0 for every
+            // normal float).  Channels 4 cq .. 4 cq + 3: chunk (c & 15) >> 2 of block c >> 5, second half of the chunk when c & 16
+            const int c = cq * 4;
+            const uint2 hb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(zh) +
+                ((size_t)(c >> 5) * 3 * zP + (size_t)g * pix_per_group + p) * 64 + ((c & 15) >> 2) * 16 + ((c >> 4) & 1) * 8);
+            d[0] = (short)(hb.x & 0xffffu) > 0 ? d[0] : 0.f;
+            d[1] = (short)(hb.x >> 16) > 0 ? d[1] : 0.f;
+            d[2] = (short)(hb.y & 0xffffu) > 0 ? d[2] : 0.f;
+            d[3] = (short)(hb.y >> 16) > 0 ? d[3] : 0.f;
+        }
         const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
         if (msc) d = relu_mask_from_y(d, yy, sc, sh);
         const f32x4 xh = (yy - mu) * is;
@@ -724,11 +736,11 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* 
 }
 void k_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* istd,
                      float* part, int groups, int pix_per_group, int C, hipStream_t s, const float* mask_scale,
-                     const float* mask_shift)
+                     const float* mask_shift, const unsigned short* zh)
 {
     dim3 grid(bn_bwd_blocks(pix_per_group), groups);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, s, dz, z, y, mean, istd, part, pix_per_group, C,
-                       mask_scale, mask_shift);
+                       mask_scale, mask_shift, zh, (long long)groups * pix_per_group);
 }
 
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int groups, int nblk, int C, int count,

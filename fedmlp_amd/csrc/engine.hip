@@ -986,7 +986,8 @@ bool conv_uses_pconv(const fm_engine* e, const Conv& c, int imgs)
 // (eval epilogue; y may then be null)
 void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, int imgs, int groups,
               const float* scale, const float* shift, const float* res, int relu, float* stats,
-              const Prologue* pro = nullptr, const unsigned short* xp = nullptr, unsigned short* yp = nullptr)
+              const Prologue* pro = nullptr, const unsigned short* xp = nullptr, unsigned short* yp = nullptr,
+              const unsigned short* resp = nullptr)
 {
     Conv& c = e->convs[ci];
     if (conv_uses_pconv(e, c, imgs)) {
@@ -998,7 +999,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         p.slab = e->sk_slab; p.counters = e->sk_counters; p.sp = e->products;
         p.ntaps = c.k * c.k;
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
-        p.res = res; p.scale = scale; p.shift = shift; p.stats = stats;
+        p.res = res; p.resp = resp; p.scale = scale; p.shift = shift; p.stats = stats;
         p.M = c.cout_p;
         p.Hi = c.hin; p.Wi = c.win; p.Ci = c.cin_p;
         p.Hg = c.hout; p.Wg = c.wout; p.sg = c.stride;
@@ -1244,8 +1245,9 @@ void bn_fwd_finalize(fm_engine* e, int ci, int groups, int imgs_per_group)
 // z_is_relu_of_bn: z = relu(bn(y)) of THIS BatchNorm with nothing added (bn1 of a basic block): the ReLU mask is then
 // recomputed from y, which both passes read anyway, and z is not read (FM_BN_MASK_FROM_Y=0 reads z as before)
 // dyp (planes mode): also write dy's block-major planes (what the data gradient reads)
+// zh (planes mode): z is kept only as planes: the mask is the sign of its h plane (z is then null)
 void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, float* dyh_out, int groups,
-            int imgs_per_group, bool z_is_relu_of_bn = false, unsigned short* dyp = nullptr)
+            int imgs_per_group, bool z_is_relu_of_bn = false, unsigned short* dyp = nullptr, const unsigned short* zh = nullptr)
 {
     const Conv& c = e->convs[bi];
     Bn& b = e->bns[bi];
@@ -1253,12 +1255,12 @@ void bn_bwd(fm_engine* e, int bi, const float* dz, const float* z, float* dy, fl
     const char* fy = getenv("FM_BN_MASK_FROM_Y");          // read per call: tests compare both forms in one process
     const int from_y = fy ? atoi(fy) : 1;
     const float *msc = nullptr, *msh = nullptr;
-    if (z_is_relu_of_bn && z && from_y) { msc = b.scale; msh = b.shift; z = nullptr; }
-    k_bn_bwd_reduce(dz, z, c.y, b.mean, b.istd, e->ws_part, groups, pix, b.C, e->st, msc, msh);
+    if (z_is_relu_of_bn && (z || zh) && (from_y || !z)) { msc = b.scale; msh = b.shift; z = nullptr; zh = nullptr; }
+    k_bn_bwd_reduce(dz, z, c.y, b.mean, b.istd, e->ws_part, groups, pix, b.C, e->st, msc, msh, zh);
     k_bn_bwd_finalize(e->ws_part, groups, bn_bwd_blocks(pix), b.C, pix, e->state + e->off_gamma + b.ch_off, b.mean,
                       b.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b.ch_off,
                       e->grad + e->off_beta + b.ch_off, e->st);
-    if (dyp) k_bn_bwd_apply_planes(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyp, dyh_out, groups, pix, b.C, e->st, msc, msh);
+    if (dyp) k_bn_bwd_apply_planes(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyp, dyh_out, groups, pix, b.C, e->st, msc, msh, zh);
     else k_bn_bwd_apply(dz, z, c.y, e->ca, e->cb, e->cc, dy, dyh_out, groups, pix, b.C, e->st, msc, msh);
 }
 
@@ -1292,33 +1294,49 @@ void forward_train(fm_engine* e, int groups, int B)
     const bool pm = e->planes;
     if (pm) k_stem_pool_planes(c0.y, e->bns[0].scale, e->bns[0].shift, e->p0, e->idx0, e->p0p, groups, B, c0.hout, c0.wout, 64, e->st);
     else k_stem_pool(c0.y, e->bns[0].scale, e->bns[0].shift, e->p0, e->idx0, groups, B, c0.hout, c0.wout, 64, e->st);
-    // BatchNorm apply: fp32 `out` for the elementwise consumers (residual, ReLU mask), planes `outp` for the conv GEMMs
-    auto apply = [&](const float* y, int b1, const float* res, const float* y2, int b2, float* out, unsigned short* outp, int pix, int C) {
+    // BatchNorm apply.  Planes mode: the activations z1 / out exist ONLY as planes (what the conv GEMMs read; the residual add
+    // and the ReLU masks of the backward re-form the fp32 value / its sign from them) -- except the last block's `out`, which
+    // feeds the average pool: fp32 only
+    auto apply = [&](const float* y, int b1, const float* res, const unsigned short* resp, const float* y2, int b2, float* out,
+                     unsigned short* outp, int pix, int C) {
         const float *s2 = y2 ? e->bns[b2].scale : nullptr, *h2 = y2 ? e->bns[b2].shift : nullptr;
-        if (pm) k_bn_apply_planes(y, e->bns[b1].scale, e->bns[b1].shift, res, y2, s2, h2, out, outp, groups, pix, C, 1, e->st);
-        else k_bn_apply(y, e->bns[b1].scale, e->bns[b1].shift, res, y2, s2, h2, out, groups, pix, C, 1, e->st);
+        if (pm && outp)
+            k_bn_apply_planes(y, e->bns[b1].scale, e->bns[b1].shift, res, y2, s2, h2, nullptr, outp, groups, pix, C, 1, e->st, resp);
+        else
+            k_bn_apply(y, e->bns[b1].scale, e->bns[b1].shift, res, y2, s2, h2, out, groups, pix, C, 1, e->st);
     };
     const float* cur = e->p0;
     const unsigned short* curp = e->p0p;
-    for (auto& blk : e->blocks) {
+    bool cur_f32 = true;                 // is `cur` valid as fp32?  (p0 is written both ways)
+    for (size_t bi = 0; bi < e->blocks.size(); ++bi) {
+        Block& blk = e->blocks[bi];
         Conv& c1 = e->convs[blk.c1];
         Conv& c2 = e->convs[blk.c2];
         const int pix = B * c1.hout * c1.wout;
+        const bool last = bi + 1 == e->blocks.size();
         conv_fwd(e, blk.c1, S, cur, c1.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, nullptr, curp);
         bn_fwd_finalize(e, blk.c1, groups, B);
-        apply(c1.y, blk.c1, nullptr, nullptr, -1, blk.z1, blk.z1p, pix, c1.cout);
+        apply(c1.y, blk.c1, nullptr, nullptr, nullptr, -1, blk.z1, blk.z1p, pix, c1.cout);
         conv_fwd(e, blk.c2, S, blk.z1, c2.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, nullptr, blk.z1p);
         bn_fwd_finalize(e, blk.c2, groups, B);
+        unsigned short* outp = (pm && !last) ? blk.outp : nullptr;
         if (blk.ds >= 0) {
             Conv& cd = e->convs[blk.ds];
             conv_fwd(e, blk.ds, S, cur, cd.y, imgs, groups, nullptr, nullptr, nullptr, 0, e->ws_stats, nullptr, curp);
             bn_fwd_finalize(e, blk.ds, groups, B);
-            apply(c2.y, blk.c2, nullptr, cd.y, blk.ds, blk.out, blk.outp, pix, c2.cout);
+            apply(c2.y, blk.c2, nullptr, nullptr, cd.y, blk.ds, blk.out, outp, pix, c2.cout);
+        } else if (pm && !cur_f32) {
+            if (last) {      // the last block adds a planes-only residual into an fp32 output: re-form the residual first
+                k_planes_to_f32(curp, e->blocks[bi - 1].out, (long long)imgs * c1.hin * c1.win, c1.cin, e->st);
+                apply(c2.y, blk.c2, e->blocks[bi - 1].out, nullptr, nullptr, -1, blk.out, nullptr, pix, c2.cout);
+            } else
+                apply(c2.y, blk.c2, nullptr, curp, nullptr, -1, blk.out, outp, pix, c2.cout);
         } else {
-            apply(c2.y, blk.c2, cur, nullptr, -1, blk.out, blk.outp, pix, c2.cout);
+            apply(c2.y, blk.c2, cur, nullptr, nullptr, -1, blk.out, outp, pix, c2.cout);
         }
         cur = blk.out;
         curp = blk.outp;
+        cur_f32 = !(pm && !last);
     }
     const Conv& cl = e->convs[e->blocks.back().c2];
     k_avgpool(cur, DT_F32, e->feat, imgs, cl.hout * cl.wout, 512, e->st);
@@ -1344,23 +1362,27 @@ void forward_eval(fm_engine* e, const float* S, float* evs, float* evh, bool& di
     else k_stem_pool(c0.y, nullptr, nullptr, e->p0, nullptr, 1, imgs, c0.hout, c0.wout, 64, e->st);
     const float* cur = e->p0;
     const unsigned short* curp = e->p0p;
+    bool cur_f32 = true;
     for (size_t bi = 0; bi < e->blocks.size(); ++bi) {
         Block& blk = e->blocks[bi];
-        // planes mode: z1 is read by the next conv only -> planes only; `out` is the next block's residual (fp32) and conv input
-        // (planes; none for the last block, which feeds the average pool)
+        // planes mode: z1 and `out` exist only as planes (the next convs read them; the next block's residual add re-forms the fp32
+        // values in the epilogue) -- except the last block's `out`, which feeds the average pool: fp32 only
         const bool last = bi + 1 == e->blocks.size();
         conv_fwd(e, blk.c1, S, cur, pm ? nullptr : blk.z1, imgs, 1, sc(blk.c1), sh(blk.c1), nullptr, 1, nullptr, nullptr, curp,
                  pm ? blk.z1p : nullptr);
         const float* idt = cur;
+        const unsigned short* idtp = nullptr;
         if (blk.ds >= 0) {
             Conv& cd = e->convs[blk.ds];
             conv_fwd(e, blk.ds, S, cur, cd.y, imgs, 1, sc(blk.ds), sh(blk.ds), nullptr, 0, nullptr, nullptr, curp);
             idt = cd.y;
-        }
-        conv_fwd(e, blk.c2, S, blk.z1, blk.out, imgs, 1, sc(blk.c2), sh(blk.c2), idt, 1, nullptr, nullptr, blk.z1p,
-                 (pm && !last) ? blk.outp : nullptr);
+        } else if (!cur_f32) { idt = nullptr; idtp = curp; }
+        const bool planes_only = pm && !last;
+        conv_fwd(e, blk.c2, S, blk.z1, planes_only ? nullptr : blk.out, imgs, 1, sc(blk.c2), sh(blk.c2), idt, 1, nullptr, nullptr,
+                 blk.z1p, planes_only ? blk.outp : nullptr, idtp);
         cur = blk.out;
         curp = blk.outp;
+        cur_f32 = !planes_only;
     }
     const Conv& cl = e->convs[e->blocks.back().c2];
     k_avgpool(cur, DT_F32, feat, imgs, cl.hout * cl.wout, 512, e->st);
@@ -1445,15 +1467,20 @@ void backward_and_step(fm_engine* e, int groups, int B)
         unsigned short *gbp = pm ? PB[par] : nullptr, *gcp = pm ? PC[par] : nullptr, *gdp = pm ? PD[par] : nullptr;
         const float* in = b == 0 ? e->p0 : e->blocks[b - 1].out;
         // out = relu(bn2(y2) + identity): masked grad dyh goes to bn2 and to the identity path
+        // planes mode: d y2 / d y_ds / d y1 exist only as planes (read by the data gradients and the weight gradients); the ReLU
+        // mask of `out` is the sign of its h plane (the last block's `out` is fp32: it feeds the average pool)
+        const bool last = b + 1 == (int)e->blocks.size();
         guard(0, par);
-        bn_bwd(e, blk.c2, ga, blk.out, GB, ga, groups, B, false, gbp);
-        if (blk.ds >= 0) { guard(1, par); bn_bwd(e, blk.ds, ga, nullptr, GC, nullptr, groups, B, false, gcp); }
+        if (pm && !last) bn_bwd(e, blk.c2, ga, nullptr, nullptr, ga, groups, B, false, gbp, blk.outp);
+        else bn_bwd(e, blk.c2, ga, blk.out, pm ? nullptr : GB, ga, groups, B, false, gbp);
+        if (blk.ds >= 0) { guard(1, par); bn_bwd(e, blk.ds, ga, nullptr, pm ? nullptr : GC, nullptr, groups, B, false, gcp); }
         side_begin(0, par);
         conv_wgrad(e, blk.c2, blk.z1, GB, imgs, nullptr, 0, pm ? blk.z1p : nullptr, gbp);
         side_end(0, par);
         guard(2, par);
         conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false, gbp);
-        bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true, gdp);
+        if (pm) bn_bwd(e, blk.c1, GD, nullptr, nullptr, nullptr, groups, B, true, gdp, blk.z1p);      // mask from y1 (z1 = relu(bn1(y1)))
+        else bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true);
         side_begin(2, par);
         const unsigned short* inp = pm ? (b == 0 ? e->p0p : e->blocks[b - 1].outp) : nullptr;
         conv_wgrad(e, blk.c1, in, GD, imgs, nullptr, 0, inp, gdp);
@@ -2684,6 +2711,9 @@ int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs,
     const Conv& c = e->convs[b.c1];
     dims4[0] = imgs; dims4[1] = c.hout; dims4[2] = c.wout; dims4[3] = c.cout;
     if (host_nhwc) {
+        // planes mode: z1 / out (all blocks but the last) live only as planes: re-form the fp32 values in the idle fp32 buffer
+        if (e->planes && (kind == 0 || block + 1 < (int)e->blocks.size()))
+            k_planes_to_f32(kind == 0 ? b.z1p : b.outp, kind == 0 ? b.z1 : b.out, (long long)imgs * c.hout * c.wout, c.cout, e->st);
         HIPCHK(hipMemcpyAsync(host_nhwc, kind == 0 ? b.z1 : b.out, (size_t)imgs * c.hout * c.wout * c.cout * 4,
                               hipMemcpyDeviceToHost, e->st));
         HIPCHK(hipStreamSynchronize(e->st));

@@ -44,14 +44,15 @@ void k_split_planes(const float* x, unsigned short* dst, long long npix, int C, 
 void k_planes_to_f32(const unsigned short* src, float* x, long long npix, int C, hipStream_t s);
 // planes_ew.hip: k_bn_apply / k_stem_pool / k_bn_bwd_apply writing their result as block-major planes `...p` [C/32][3][groups*pix][32]
 // (C % 32 == 0) and, where the fp32 pointer is not null, as fp32 too
+// resp: the residual as planes (res then null); out: null = planes only
 void k_bn_apply_planes(const float* y, const float* scale, const float* shift, const float* res, const float* y2, const float* scale2,
                        const float* shift2, float* out, unsigned short* outp, int groups, int pix_per_group, int C, int relu,
-                       hipStream_t s);
+                       hipStream_t s, const unsigned short* resp = nullptr);
 void k_stem_pool_planes(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx, unsigned short* pooledp,
                         int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);
 void k_bn_bwd_apply_planes(const float* dz, const float* z, const float* y, const float* ca, const float* cb, const float* cc, float* dy,
                            unsigned short* dyp, float* dyh_out, int groups, int pix_per_group, int C, hipStream_t s,
-                           const float* mask_scale = nullptr, const float* mask_shift = nullptr);
+                           const float* mask_scale = nullptr, const float* mask_shift = nullptr, const unsigned short* zh = nullptr);
 void k_scale(float* x, float w, int64_t n, hipStream_t s);
 // utils/FedAvg.py:7-14 over K engine-layout states on one GPU: out = ((s0*n0 + s1*n1) + ...) / tot, the reference's
 // left-to-right order with separately rounded products, sums and an IEEE division (bit-identical on fp32 entries)
@@ -98,9 +99,10 @@ void k_stem_pool_bn_apply(const float* dpooled, const float* pooled, const uint8
 // backward: partial sums of dyh = dz*(z>0) and dyh*xhat -> part[groups][nblk][2][C]
 int bn_bwd_blocks(int pix_per_group);
 // ReLU mask of dz: z > 0 (z = stored post-activation), or, with z null and mask_scale / mask_shift given, y*scale+shift > 0
+// zh (planes mode): z exists only as block-major planes [C/32][3][groups*pix][32]: the mask is the sign of its h plane
 void k_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* istd,
                      float* part, int groups, int pix_per_group, int C, hipStream_t s,
-                     const float* mask_scale = nullptr, const float* mask_shift = nullptr);
+                     const float* mask_scale = nullptr, const float* mask_shift = nullptr, const unsigned short* zh = nullptr);
 // coefficients ca,cb,cc [groups][C]; dgamma/dbeta written (summed over groups)
 void k_bn_bwd_finalize(const float* part, int groups, int nblk, int C, int count, const float* gamma,
                        const float* mean, const float* istd, float* ca, float* cb, float* cc,

@@ -369,6 +369,31 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                     v[r] = v[r] * sc + sh;
                 }
                 if (p.res) v[r] += *reinterpret_cast<const f32x4*>(p.res + o + m);
+            }
+            if (p.resp) {
+                // residual kept only as planes: rows r, r + 1 of this lane are chunk lg of a 32-channel block; x = (h + m) + l exactly
+#pragma unroll
+                for (int r = 0; r < FR; r += 2) {
+                    const size_t cb = (size_t)(m0 + wm * (16 * FR) + 16 * r) >> 5;
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.resp) + ((cb * 3) * (size_t)p.yp_pix + opix) * 64 + lg * 16;
+                    const sp_u32x4 H = *reinterpret_cast<const sp_u32x4*>(src);
+                    const sp_u32x4 M = *reinterpret_cast<const sp_u32x4*>(src + (size_t)p.yp_pix * 64);
+                    const sp_u32x4 L = *reinterpret_cast<const sp_u32x4*>(src + (size_t)p.yp_pix * 128);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float lo = (__builtin_bit_cast(float, H[i] << 16) + __builtin_bit_cast(float, M[i] << 16)) +
+                                         __builtin_bit_cast(float, L[i] << 16);
+                        const float hi = (__builtin_bit_cast(float, H[i] & 0xffff0000u) + __builtin_bit_cast(float, M[i] & 0xffff0000u)) +
+                                         __builtin_bit_cast(float, L[i] & 0xffff0000u);
+                        // words 0, 1 = the first row tile's channels 4 lg .. 4 lg + 3, words 2, 3 = the second's
+                        v[r + (i >> 1)][2 * (i & 1)] += lo;
+                        v[r + (i >> 1)][2 * (i & 1) + 1] += hi;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < FR; ++r) {
+                const int m = mbase + 16 * r;
                 if (p.relu == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[r][q] = fmaxf(v[r][q], 0.f);

@@ -24,6 +24,23 @@ __device__ __forceinline__ void pe_store_planes(unsigned short* planes, int64_t 
     *reinterpret_cast<sp_u32x4*>(d + (size_t)P * 64) = M;
     *reinterpret_cast<sp_u32x4*>(d + (size_t)P * 128) = L;
 }
+// the fp32 values back: x = (h + m) + l, both additions exact
+__device__ __forceinline__ void pe_load_planes(const unsigned short* planes, int64_t P, int cb, int64_t pix, int g, f32x4& v0, f32x4& v1)
+{
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(planes) + (((size_t)cb * 3) * P + pix) * 64 + g * 16;
+    const sp_u32x4 H = *reinterpret_cast<const sp_u32x4*>(s);
+    const sp_u32x4 M = *reinterpret_cast<const sp_u32x4*>(s + (size_t)P * 64);
+    const sp_u32x4 L = *reinterpret_cast<const sp_u32x4*>(s + (size_t)P * 128);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = (__builtin_bit_cast(float, H[i] << 16) + __builtin_bit_cast(float, M[i] << 16)) + __builtin_bit_cast(float, L[i] << 16);
+        v[2 * i + 1] = (__builtin_bit_cast(float, H[i] & 0xffff0000u) + __builtin_bit_cast(float, M[i] & 0xffff0000u)) +
+                       __builtin_bit_cast(float, L[i] & 0xffff0000u);
+    }
+    v0 = f32x4{v[0], v[1], v[2], v[3]};
+    v1 = f32x4{v[4], v[5], v[6], v[7]};
+}
 #endif
 
 // out = [relu]( y*scale+shift [+ res] [+ y2*scale2+shift2] ), per group (elementwise.hip bn_apply_kernel)
@@ -31,7 +48,8 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
                                                               const float* __restrict__ shift, const float* __restrict__ res,
                                                               const float* __restrict__ y2, const float* __restrict__ scale2,
                                                               const float* __restrict__ shift2, float* __restrict__ out,
-                                                              unsigned short* __restrict__ outp, int pix_per_group, int C, int relu)
+                                                              unsigned short* __restrict__ outp, int pix_per_group, int C, int relu,
+                                                              const unsigned short* __restrict__ resp)
 {
 #if __HIP_DEVICE_COMPILE__
     const int grp = blockIdx.y;
@@ -44,12 +62,14 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
     const int64_t P = (int64_t)gridDim.y * pix_per_group;
     const int c0 = cb * 32 + 4 * g;
     const size_t o = (size_t)pix * C + c0;
-    f32x4 v[2];
+    f32x4 v[2], rp[2];
+    if (resp) pe_load_planes(resp, P, cb, pix, g, rp[0], rp[1]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = c0 + 16 * h;
         v[h] = ld4(y + o + 16 * h) * ld4(scale + grp * C + c) + ld4(shift + grp * C + c);
         if (res) v[h] += ld4(res + o + 16 * h);
+        if (resp) v[h] += rp[h];
         if (y2) v[h] += ld4(y2 + o + 16 * h) * ld4(scale2 + grp * C + c) + ld4(shift2 + grp * C + c);
         if (relu) {
 #pragma unroll
@@ -62,11 +82,11 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
 }
 void k_bn_apply_planes(const float* y, const float* scale, const float* shift, const float* res, const float* y2, const float* scale2,
                        const float* shift2, float* out, unsigned short* outp, int groups, int pix_per_group, int C, int relu,
-                       hipStream_t s)
+                       hipStream_t s, const unsigned short* resp)
 {
     const int64_t n = (int64_t)pix_per_group * (C / 8);
     hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(pe_cdiv(n, 256), groups), dim3(256), 0, s, y, scale, shift, res, y2, scale2,
-                       shift2, out, outp, pix_per_group, C, relu);
+                       shift2, out, outp, pix_per_group, C, relu, resp);
 }
 
 // stem: pooled = maxpool3x3s2p1(relu(y*scale+shift)) (+ argmax code); scale == null -> plain max-pool (elementwise.hip stem_pool_kernel)
@@ -141,7 +161,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
                                                                   const float* __restrict__ y, const float* __restrict__ ca,
                                                                   const float* __restrict__ cb_, const float* __restrict__ cc, float* dy,
                                                                   unsigned short* __restrict__ dyp, float* dyh_out, int pix_per_group,
-                                                                  int C, const float* __restrict__ msc, const float* __restrict__ msh)
+                                                                  int C, const float* __restrict__ msc, const float* __restrict__ msh,
+                                                                  const unsigned short* __restrict__ zh)
 {
 #if __HIP_DEVICE_COMPILE__
     const int grp = blockIdx.y;
@@ -155,10 +176,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
     const int c0 = cb * 32 + 4 * g;
     const size_t o = (size_t)pix * C + c0;
     f32x4 r[2];
+    // planes mode: the ReLU mask of a tensor kept only as planes is the sign of its h plane (this thread's chunk: 8 bf16)
+    sp_u32x4 hb = {0u, 0u, 0u, 0u};
+    if (zh) hb = *reinterpret_cast<const sp_u32x4*>(reinterpret_cast<const unsigned char*>(zh) + (((size_t)cb * 3) * P + pix) * 64 + g * 16);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = c0 + 16 * h;
         f32x4 d = ld4(dz + o + 16 * h);
+        if (zh) {
+            d[0] = (short)(hb[2 * h] & 0xffffu) > 0 ? d[0] : 0.f;
+            d[1] = (short)(hb[2 * h] >> 16) > 0 ? d[1] : 0.f;
+            d[2] = (short)(hb[2 * h + 1] & 0xffffu) > 0 ? d[2] : 0.f;
+            d[3] = (short)(hb[2 * h + 1] >> 16) > 0 ? d[3] : 0.f;
+        }
         if (z) {
             const f32x4 zz = ld4(z + o + 16 * h);
 #pragma unroll
@@ -179,9 +209,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
 }
 void k_bn_bwd_apply_planes(const float* dz, const float* z, const float* y, const float* ca, const float* cb, const float* cc, float* dy,
                            unsigned short* dyp, float* dyh_out, int groups, int pix_per_group, int C, hipStream_t s,
-                           const float* mask_scale, const float* mask_shift)
+                           const float* mask_scale, const float* mask_shift, const unsigned short* zh)
 {
     const int64_t n = (int64_t)pix_per_group * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(pe_cdiv(n, 256), groups), dim3(256), 0, s, dz, z, y, ca, cb, cc, dy, dyp,
-                       dyh_out, pix_per_group, C, mask_scale, mask_shift);
+                       dyh_out, pix_per_group, C, mask_scale, mask_shift, zh);
 }

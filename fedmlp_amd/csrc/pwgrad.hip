@@ -182,7 +182,10 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
         else PW_READ(DST, Bf, b_w, (SLOT) * SB, (C) + 1)                                           \
     }
 #define PW_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PW_MFMA(R, C, AC) acc[R][C] = mfma_split<SP>(Bb[(C) & 1][0], Bb[(C) & 1][1], Bb[(C) & 1][2], AC[R][0], AC[R][1], AC[R][2], acc[R][C])
+    // the rolling X buffers: column c of a step of parity PAR sits in Bb[(c + PAR * FC) & 1] (FC = 3: the parity of the first column
+    // alternates from step to step, so that the next step's column 0 never lands on the column still in use)
+#define PW_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
+#define PW_MFMA(R, C, AC, BI_) acc[R][C] = mfma_split<SP>(Bb[BI_][0], Bb[BI_][1], Bb[BI_][2], AC[R][0], AC[R][1], AC[R][2], acc[R][C])
 
     if (nsteps > 0) {
         // ---- prologue ----------------------------------------------------------------------------------------------------
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
             constexpr bool FULL = decltype(full_c)::value;
 #define PW_COLUMN(C)                                                                                             \
             {                                                                                                    \
-                PW_READB(PAR, (C) + 1, Bb[((C) + 1) & 1]);                                                       \
+                PW_READB(PAR, (C) + 1, Bb[PW_BI((C) + 1, PAR)]);                                                 \
                 if (FULL || s + 1 < nsteps) {                                                                    \
                     if constexpr (FR == 4 && FC == 4) {                                                          \
                         if constexpr ((C) == 0) { PW_READA(PAR ^ 1, 0, An[0]); PW_READA(PAR ^ 1, 1, An[1]); }    \
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
                     }                                                                                            \
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
-                _Pragma("unroll") for (int r = 0; r < FR; ++r) PW_MFMA(r, C, Ac);                                \
+                _Pragma("unroll") for (int r = 0; r < FR; ++r) PW_MFMA(r, C, Ac, PW_BI(C, PAR));                 \
                 PW_LGKM0();                                                                                      \
             }
             PW_COLUMN(0)
@@ -233,11 +236,11 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (FULL || s + 1 < nsteps) PW_READB(PAR ^ 1, 0, Bb[0]);
+            if (FULL || s + 1 < nsteps) PW_READB(PAR ^ 1, 0, Bb[PW_BI(0, PAR ^ 1)]);
             if (FULL || s + 2 < nsteps) issueB(PAR);
             if (FULL || s + 3 < nsteps) issueA(PAR ^ 1);
 #pragma unroll
-            for (int r = 0; r < FR; ++r) PW_MFMA(r, FC - 1, Ac);
+            for (int r = 0; r < FR; ++r) PW_MFMA(r, FC - 1, Ac, PW_BI(FC - 1, PAR));
             PW_LGKM0();
         };
         using I0 = std::integral_constant<int, 0>;
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
 #undef PW_READB
 #undef PW_LGKM0
 #undef PW_MFMA
+#undef PW_BI
 
     // ---- epilogue: acc[r][c][q] = dW[m of (m tile wm*FR + r, position li)][n of (n tile wn*FC + c, positions 4 lg + q)]
     // position j of a 32-channel block -> channel: chunk g = j >> 3 holds channels 4g..4g+3 (j & 7 < 4) and 16+4g..16+4g+3
