@@ -68,10 +68,13 @@ def mfma_products(args=None):
     return int(_lib.load().fm_mfma_products())
 
 
-def kernel_names(sp=None):
+def kernel_names(sp=None, planes=False):
     """kernel families of fm_profile_read, named as rocprofv3 prints them for the ResNet-18 workload (every non-stem conv has
     Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes)."""
     sp = mfma_products() if sp is None else sp
+    if planes and sp:      # planes mode (csrc/pconv.hip, pwgrad.hip): both GEMM operands arrive as bf16 planes
+        return {0: f"pconv_kernel<4,{sp}>", 1: f"pconv_kernel<2,{sp}>", 2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>",
+                3: f"pwgrad_kernel<4,*,{sp}>", 4: f"pwgrad_kernel<2,*,{sp}>", 5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
     wp = 1 if sp else 0
     return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},{wp}>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},{wp}>",
             2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>" if sp else "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
@@ -334,6 +337,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
     eng = Engine(args.model, C, args.hw, args.hw, views * B, device=str(dev), precision=args.precision,
                  streams=1 if args.one_stream else 0, products=getattr(args, "products", None))
     sp = eng.products
+    planes = eng.planes
     flat, cnt = spec.init_state(args.model, C, 1037)
     eng.set_state(flat, cnt)
     eng.teacher_snapshot()
@@ -482,7 +486,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
         pmc_file = pmc_doc(args)[1]
         allk = None
         if fams is not None:
-            allk = {kernel_names(sp)[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
+            allk = {kernel_names(sp, planes)[f]: {"launches": fams[f][0], "ms": round(fams[f][1], 3),
                                       "tflops": round(fams[f][2] / max(fams[f][1], 1e-9) / 1e9, 3)}
                     for f in range(NFAM)}
         if args.model == "Efficient_b0":
@@ -512,7 +516,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
             else:
                 dom = max(range(NFAM), key=lambda f: fams[f][1])
                 n, ms, fl = fams[dom]
-                name = kernel_names(sp)[dom]
+                name = kernel_names(sp, planes)[dom]
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak, peak_note = mfma_peak(sp)
             roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": peak, "unit": "TFLOP/s", "peak_basis": peak_note,

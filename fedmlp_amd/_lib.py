@@ -47,6 +47,7 @@ SYMBOLS = {
     "fm_stream_mode": (C.c_int, [_P]),
     "fm_mfma_products": (C.c_int, []),
     "fm_products": (C.c_int, [_P]),
+    "fm_planes_mode": (C.c_int, [_P]),
     "fm_teacher_snapshot": (C.c_int, [_P]),
     "fm_adam_reset": (C.c_int, [_P, C.POINTER(FmAdam)]),
     "fm_forward_eval": (C.c_int, [_P, _P, _I32, _I32, _P, _P]),

@@ -2105,6 +2105,7 @@ int fm_stream_mode(fm_engine* e)
 
 int fm_mfma_products(void) { return fm_mfma_split(); }
 int fm_products(fm_engine* e) { return e ? e->products : FM_ERR_ARG; }
+int fm_planes_mode(fm_engine* e) { return e ? (e->planes ? 1 : 0) : FM_ERR_ARG; }
 
 int fm_fedavg_fold(fm_engine* e, const float* const* states_dev, const float* n_host, int32_t K, float* out_dev)
 {

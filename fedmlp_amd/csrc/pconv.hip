@@ -104,26 +104,30 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const unsigned Af0 = As + wm * (16 * FR) * 64 + fro, Af1 = Af0 + SA;
     const unsigned Bf0 = Bs + wn * 64 * 64 + fro, Bf1 = Bf0 + SB;
 
-    while (w < wend) {
-        const int tile = (int)(w / nsteps);
-        const int k0 = (int)(w - (long long)tile * nsteps);
-        const int k1 = min(nsteps, k0 + (int)(wend - w));
-        const bool seg_first_of_block = (w == (long long)rbk * S);
-        w += k1 - k0;
-        const int grp = tile / tiles_pg;
-        const int tl = tile - grp * tiles_pg;
+    // A segment = the K-steps [k0, k1) of one tile that this block's range covers, with the per-lane DMA state of the tile
+    struct Seg {
+        int tile, k0, k1, grp, tn, m0, n0;
+        bool first;                              // the block's first segment (slab slot 0)
+        unsigned voffA, voffB[RGB], vmask[RGB];
+        int icc_b, it_b;                         // (channel block, tap) cursor of the next B step to be issued
+    };
+    auto decode = [&](Seg& g) {                  // takes the next segment off the block's range [w, wend)
+        g.tile = (int)(w / nsteps);
+        g.k0 = (int)(w - (long long)g.tile * nsteps);
+        g.k1 = min(nsteps, g.k0 + (int)(wend - w));
+        g.first = (w == (long long)rbk * S);
+        w += g.k1 - g.k0;
+        g.grp = g.tile / tiles_pg;
+        const int tl = g.tile - g.grp * tiles_pg;
         const int tm = p.tn_fast ? tl / p.tilesN : tl % p.tilesM;
-        const int tn = p.tn_fast ? tl % p.tilesN : tl / p.tilesM;
-        const int m0 = tm * BM, n0 = tn * BN;
-
-        // ---- LDS-DMA sources of this tile -------------------------------------------------------------------------------
+        g.tn = p.tn_fast ? tl % p.tilesN : tl / p.tilesM;
+        g.m0 = tm * BM; g.n0 = g.tn * BN;
         // A job j = plane j / GA, row group j % GA; wave takes j = wave + 8 q.  Rows past M never occur (M % BM == 0).
-        const unsigned voffA = (unsigned)((m0 + drow) * 64 + chunk * 16);
-        // B: row group g = wave + 8 i holds output pixels n0 + 16 g + drow of the group's virtual grid
-        unsigned voffB[RGB], vmask[RGB];
+        g.voffA = (unsigned)((g.m0 + drow) * 64 + chunk * 16);
+        // B: row group gi = wave + 8 i holds output pixels n0 + 16 gi + drow of the group's virtual grid
 #pragma unroll
         for (int i = 0; i < RGB; ++i) {
-            const int n = n0 + 16 * (wave + 8 * i) + drow;
+            const int n = g.n0 + 16 * (wave + 8 * i) + drow;
             const bool rv = n < npix;
             const int nn = rv ? n : 0;
             const int img = nn / HWg, rem = nn - img * HWg;
@@ -136,37 +140,53 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 const int ih = ih0 + (int)(f & 3u) - 1, iw = iw0 + (int)(f >> 2) - 1;
                 if (t < ntaps && rv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)Wi) vm |= 1u << t;
             }
-            vmask[i] = vm;
-            voffB[i] = (unsigned)((((grp * p.imgs_per_group + img) * p.Hi + ih0) * Wi + iw0) * 64 + chunk * 16);
+            g.vmask[i] = vm;
+            g.voffB[i] = (unsigned)((((g.grp * p.imgs_per_group + img) * p.Hi + ih0) * Wi + iw0) * 64 + chunk * 16);
         }
-        auto issueA = [&](int s, int slot) {
+        g.icc_b = g.k0 / ntaps;
+        g.it_b = g.k0 - g.icc_b * ntaps;
+    };
+    auto issueA = [&](const Seg& g, int s, int slot) {
 #pragma unroll
-            for (int q = 0; q < JA; ++q) {
-                const int j = wave + 8 * q;
-                if ((3 * GA) % 8 != 0 && j >= 3 * GA) break;
-                const int plane = j / GA, gr = j % GA;
-                const unsigned so = (unsigned)(((s * 3 + plane) * p.M + 16 * gr) * 64);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(size_t)(As + slot * SA + j * 1024), 16, voffA, so, 0, 0);
+        for (int q = 0; q < JA; ++q) {
+            const int j = wave + 8 * q;
+            if ((3 * GA) % 8 != 0 && j >= 3 * GA) break;
+            const int plane = j / GA, gr = j % GA;
+            const unsigned so = (unsigned)(((s * 3 + plane) * p.M + 16 * gr) * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(size_t)(As + slot * SA + j * 1024), 16, g.voffA, so, 0, 0);
+        }
+    };
+    // B steps are issued strictly in order k0, k0 + 1, ...: the (channel block, tap) cursor advances with them
+    auto issueB = [&](Seg& g, int slot) {
+        const unsigned f = (unsigned)(p.tapcode >> (4 * g.it_b)) & 15u;
+        const unsigned tapo = ((f & 3u) * (unsigned)Wi + (f >> 2)) * 64u;           // (dh + 1) * Wi + (dw + 1) pixels
+#pragma unroll
+        for (int i = 0; i < RGB; ++i) {
+            const unsigned vo = ((g.vmask[i] >> g.it_b) & 1u) ? g.voffB[i] : OOB;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const unsigned so = (unsigned)((size_t)(g.icc_b * 3 + pl) * p.xp_pix * 64) + tapo;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(size_t)(Bs + slot * SB + (pl * GB + wave + 8 * i) * 1024), 16,
+                                                         vo, so, 0, 0);
             }
-        };
-        // B steps are issued strictly in order k0, k0 + 1, ...: the (channel block, tap) cursor advances with them
-        int icc_b = k0 / ntaps, it_b = k0 - icc_b * ntaps;
-        auto issueB = [&](int slot) {
-            const unsigned f = (unsigned)(p.tapcode >> (4 * it_b)) & 15u;
-            const unsigned tapo = ((f & 3u) * (unsigned)Wi + (f >> 2)) * 64u;           // (dh + 1) * Wi + (dw + 1) pixels
-#pragma unroll
-            for (int i = 0; i < RGB; ++i) {
-                const unsigned vo = ((vmask[i] >> it_b) & 1u) ? voffB[i] : OOB;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const unsigned so = (unsigned)((size_t)(icc_b * 3 + pl) * p.xp_pix * 64) + tapo;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(size_t)(Bs + slot * SB + (pl * GB + wave + 8 * i) * 1024), 16,
-                                                             vo, so, 0, 0);
-                }
-            }
-            if (++it_b == ntaps) { it_b = 0; ++icc_b; }
-        };
+        }
+        if (++g.it_b == ntaps) { g.it_b = 0; ++g.icc_b; }
+    };
+    // the DMA a segment starts with: steps k0 (both operands) and k0 + 1 (A).  Issued for the NEXT segment before the current
+    // one's fix-up / epilogue runs: a tile's pipeline fill hides behind its predecessor's stores (tiles of 2 - 18 K-steps --
+    // the 64-channel layers, the 1x1 convs -- spent a third of their time in it)
+    auto lead = [&](Seg& g) {
+        issueA(g, g.k0, 0);
+        issueB(g, 0);
+        if (g.k0 + 1 < g.k1) issueA(g, g.k0 + 1, 1);
+    };
 
+    if (w >= wend) return;                       // (a block whose range is empty: the grid was rounded up)
+    Seg cur;
+    decode(cur);
+    lead(cur);
+    for (;;) {
+        const int k0 = cur.k0, k1 = cur.k1;
         f32x4 acc[FR][FC];
 #pragma unroll
         for (int r = 0; r < FR; ++r)
@@ -186,15 +206,14 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         DST[2] = pc_lds_read128<(2 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
     }
 #define PC_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // workgroup barrier that orders LDS accesses only: a __syncthreads() would also wait for the LDS-DMA in flight
+#define PC_SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
         // ---- prologue: slots are indexed by the step's parity relative to k0 ------------------------------------------------
-        issueA(k0, 0);
-        issueB(0);
-        if (k0 + 1 < k1) issueA(k0 + 1, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment's lead DMA (issued by lead())
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (k0 + 1 < k1) issueB(1);
+        if (k0 + 1 < k1) issueB(cur, 1);
         PC_READA(0, 0, A0[0]);
         PC_READA(0, 1, A0[1]);
         if constexpr (FR == 4) { PC_READA(0, 2, A0[2]); PC_READA(0, 3, A0[3]); }
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         PC_LGKM0();
         __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + 2)
         asm volatile("" ::: "memory");
-        if (k0 + 2 < k1) issueA(k0 + 2, 0);
+        if (k0 + 2 < k1) issueA(cur, k0 + 2, 0);
 
         // one K-step (slot parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
         // FULL: steps s+1, s+2, s+3 exist (the main loop: no branch inside); otherwise the conditions are tested
@@ -237,8 +256,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (FULL || s + 1 < k1) PC_READB(PAR ^ 1, 0, Bb[0]);
-            if (FULL || s + 2 < k1) issueB(PAR);
-            if (FULL || s + 3 < k1) issueA(s + 3, PAR ^ 1);
+            if (FULL || s + 2 < k1) issueB(cur, PAR);
+            if (FULL || s + 3 < k1) issueA(cur, s + 3, PAR ^ 1);
 #pragma unroll
             for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[(FC - 1) & 1], acc[r][FC - 1]);
             PC_LGKM0();
@@ -257,13 +276,24 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #undef PC_READA
 #undef PC_READB
 #undef PC_LGKM0
-        __syncthreads();       // all LDS reads done (and no DMA in flight) before the fix-up / epilogue reuse the LDS
+        PC_SYNC_LDS();         // every wave is done reading both stages: they can take the next segment's lead DMA
+
+        // ---- the next segment's pipeline fill starts now, behind this segment's fix-up / epilogue --------------------------------
+        const bool more = w < wend;
+        Seg nx;
+        if (more) {
+            decode(nx);
+            lead(nx);
+        }
+        const int tile = cur.tile, grp = cur.grp, tn = cur.tn, m0 = cur.m0, n0 = cur.n0;
+        // the fix-up / epilogue scratch sits BEHIND the stages (they are being refilled)
+        float* fsmem = reinterpret_cast<float*>(smem + 2 * SA + 2 * SB);
+        bool do_epilogue = true;
 
         // ---- stream-K fix-up: partial tiles meet in the slab ------------------------
-        float* fsmem = reinterpret_cast<float*>(smem);
         if (k0 != 0 || k1 != nsteps) {
             // slot 0: the block's first segment, slot 1: its last one (middle ones are whole tiles)
-            float* mine = p.slab + (size_t)(rbk * 2 + (seg_first_of_block ? 0 : 1)) * (BM * BN);
+            float* mine = p.slab + (size_t)(rbk * 2 + (cur.first ? 0 : 1)) * (BM * BN);
 #pragma unroll
             for (int r = 0; r < FR; ++r)
 #pragma unroll
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             __syncthreads();
             const long long t0 = (long long)tile * nsteps;
             const int b_first = (int)(t0 / S), b_last = (int)((t0 + nsteps - 1) / S);
-            int* flag = reinterpret_cast<int*>(smem);
+            int* flag = reinterpret_cast<int*>(fsmem);
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep: the fence's own wait may be dropped
@@ -289,24 +319,27 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             __syncthreads();
             const bool last = *flag != 0;
             __syncthreads();                                          // flag word is reused as LDS below
-            if (!last) continue;
-            // last arriver: sum every segment of this tile in segment order (incl. its own, from the slab) -> the result is
-            // independent of which block arrived last
-#pragma unroll
-            for (int r = 0; r < FR; ++r)
-#pragma unroll
-                for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int bb = b_first; bb <= b_last; ++bb) {
-                const long long sstart = max(t0, (long long)bb * S);
-                const float* src = p.slab + (size_t)(bb * 2 + (sstart == (long long)bb * S ? 0 : 1)) * (BM * BN);
+            do_epilogue = last;
+            if (last) {
+                // last arriver: sum every segment of this tile in segment order (incl. its own, from the slab) -> the result
+                // is independent of which block arrived last
 #pragma unroll
                 for (int r = 0; r < FR; ++r)
 #pragma unroll
-                    for (int c = 0; c < FC; ++c)
-                        acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * FC + c) * 512 + tid) * 4);
+                    for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int bb = b_first; bb <= b_last; ++bb) {
+                    const long long sstart = max(t0, (long long)bb * S);
+                    const float* src = p.slab + (size_t)(bb * 2 + (sstart == (long long)bb * S ? 0 : 1)) * (BM * BN);
+#pragma unroll
+                    for (int r = 0; r < FR; ++r)
+#pragma unroll
+                        for (int c = 0; c < FC; ++c)
+                            acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * FC + c) * 512 + tid) * 4);
+                }
             }
         }
 
+        if (do_epilogue) {
         // ---- epilogue -------------------------------------------------------------
         // acc[r][c][q] = D[m = m0 + wm*16FR + 16r + 4*lg + q][n = n0 + wn*64 + 16c + li]
         const int mbase = m0 + wm * (16 * FR) + 4 * lg;
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                     }
                 }
             }
-            __syncthreads();
+            PC_SYNC_LDS();
             for (int ch = tid; ch < BM; ch += 512) {
                 float u = 0.f, v = 0.f;
 #pragma unroll
@@ -414,8 +447,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 }
             }
         }
-        __syncthreads();       // LDS (stats scratch) is re-staged by the next segment
+        }
+        if (!more) break;
+        PC_SYNC_LDS();         // the scratch (statistics, flag) is reused by the next segment's epilogue
+        cur = nx;
     }
+#undef PC_SYNC_LDS
 #endif
 }
 
@@ -490,8 +527,9 @@ bool pconv_takes(int M, int Ci, long long xp_pix, int Wi)
 void launch_pconv(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
-    constexpr int LDS_L = 2 * 3 * (128 + 256) * 64;      // 144 KB
-    constexpr int LDS_S = 2 * 3 * (64 + 256) * 64;       // 120 KB
+    // two stages + the fix-up / epilogue scratch behind them (statistics partials [4][BM][2] floats, the last-arriver flag)
+    constexpr int LDS_L = 2 * 3 * (128 + 256) * 64 + 4 * 128 * 2 * 4;      // 148 KB
+    constexpr int LDS_S = 2 * 3 * (64 + 256) * 64 + 4 * 128 * 2 * 4;       // 124 KB
     if (!attr_done) {
         set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 6>), LDS_L, "pconv_kernel<4, 6>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 9>), LDS_L, "pconv_kernel<4, 9>");

@@ -1,13 +1,16 @@
-// Producers of activation planes (ResNet-18 planes mode, pconv.hip): the BatchNorm apply, max-pool and BatchNorm-backward apply
-// passes of elementwise.hip, writing their result as block-major bf16 planes P[C/32][3][pixels][32] (x = h + m + l exactly,
-// split3.h) for the conv GEMMs that consume it -- and as fp32 only where an elementwise consumer needs the tensor (residual
-// adds, ReLU masks of a later backward, pooling).  Same arithmetic, expression for expression, as the fp32 kernels they stand
-// in for (the reference ops: BatchNorm2d / ReLU / MaxPool2d forward and backward inside net(images) and loss.backward(),
+// Producers of activation planes (ResNet-18 planes mode, pconv.hip / pwgrad.hip): the BatchNorm apply, max-pool and
+// BatchNorm-backward apply passes of elementwise.hip, writing their result as block-major bf16 planes
+// P[C/32][3][pixels][32] (x = h + m + l exactly, split3.h) for the conv GEMMs that consume it -- and as fp32 only where a
+// caller still wants the tensor that way.  Same arithmetic, expression for expression, as the fp32 kernels they stand in for
+// (the reference ops: BatchNorm2d / ReLU / MaxPool2d forward and backward inside net(images) and loss.backward(),
 // utils/local_training.py:657, 674, 937-947, 965; torchvision resnet18, model/all_models.py:53-54).
 //
-// HBM-bound.  One thread = one 8-channel chunk of one pixel: channels 4g..4g+3 and 16+4g..16+4g+3 of a 32-channel block (the chunk
-// order of the planes), i.e. two 16-B reads 64 B apart per fp32 operand and three 16-B plane writes.  Threads are ordered
-// (channel block, pixel, g): four lanes read one 128-B line, a wave writes 1 KB contiguous of each plane.
+// HBM-bound.  Thread mapping = the fp32 kernels': one thread = 4 consecutive channels of one pixel (one 16-B access per
+// operand, 16+ consecutive lanes = one pixel's channels: whole 128-B lines per wave instruction).  A plane chunk is 8
+// channels, 4g..4g+3 and 16+4g..16+4g+3 of a 32-channel block: lanes cq and cq + 4 of a pixel hold its two halves; the lower
+// lane fetches the upper one's values by a lane shift, splits the 8 values and writes the three 16-B plane chunks (four such
+// lanes = 64 contiguous bytes of each plane).  Tensors kept ONLY as planes are read back the same way: a thread re-forms its 4
+// channels from 8 bytes of each plane (x = (h + m) + l, both additions exact), a ReLU mask needs the h plane's sign only.
 #include "common.h"
 #include "kernels.h"
 #include "split3.h"
@@ -15,31 +18,49 @@
 static inline int pe_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #if __HIP_DEVICE_COMPILE__
-__device__ __forceinline__ void pe_store_planes(unsigned short* planes, int64_t P, int cb, int64_t pix, int g, f32x4 v0, f32x4 v1)
+// byte offset of channels c .. c + 3 (c % 4 == 0) of pixel `pix` inside plane 0 of a planes tensor of P pixels
+__device__ __forceinline__ size_t pe_off(int c, int64_t pix, int64_t P)
 {
-    sp_u32x4 H, M, L;
-    split3(v0, v1, H, M, L);
-    unsigned char* d = reinterpret_cast<unsigned char*>(planes) + (((size_t)cb * 3) * P + pix) * 64 + g * 16;
-    *reinterpret_cast<sp_u32x4*>(d) = H;
-    *reinterpret_cast<sp_u32x4*>(d + (size_t)P * 64) = M;
-    *reinterpret_cast<sp_u32x4*>(d + (size_t)P * 128) = L;
+    return (((size_t)(c >> 5) * 3) * P + pix) * 64 + ((c & 15) >> 2) * 16 + ((c >> 4) & 1) * 8;
 }
-// the fp32 values back: x = (h + m) + l, both additions exact
-__device__ __forceinline__ void pe_load_planes(const unsigned short* planes, int64_t P, int cb, int64_t pix, int g, f32x4& v0, f32x4& v1)
+// v = this thread's channels c .. c + 3; every lane of the wave calls this (the exchange is a wave operation)
+__device__ __forceinline__ void pe_store_planes(unsigned short* planes, int64_t P, int c, int64_t pix, f32x4 v, bool active)
 {
-    const unsigned char* s = reinterpret_cast<const unsigned char*>(planes) + (((size_t)cb * 3) * P + pix) * 64 + g * 16;
-    const sp_u32x4 H = *reinterpret_cast<const sp_u32x4*>(s);
-    const sp_u32x4 M = *reinterpret_cast<const sp_u32x4*>(s + (size_t)P * 64);
-    const sp_u32x4 L = *reinterpret_cast<const sp_u32x4*>(s + (size_t)P * 128);
-    float v[8];
+    f32x4 up;          // the values of lane + 4: channels c + 16 .. c + 19 of the same pixel
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[2 * i] = (__builtin_bit_cast(float, H[i] << 16) + __builtin_bit_cast(float, M[i] << 16)) + __builtin_bit_cast(float, L[i] << 16);
-        v[2 * i + 1] = (__builtin_bit_cast(float, H[i] & 0xffff0000u) + __builtin_bit_cast(float, M[i] & 0xffff0000u)) +
-                       __builtin_bit_cast(float, L[i] & 0xffff0000u);
+    for (int k = 0; k < 4; ++k) up[k] = __shfl_down(v[k], 4);
+    if (active && (c & 16) == 0) {
+        sp_u32x4 H, M, L;
+        split3(v, up, H, M, L);
+        unsigned char* d = reinterpret_cast<unsigned char*>(planes) + (((size_t)(c >> 5) * 3) * P + pix) * 64 + ((c & 15) >> 2) * 16;
+        *reinterpret_cast<sp_u32x4*>(d) = H;
+        *reinterpret_cast<sp_u32x4*>(d + (size_t)P * 64) = M;
+        *reinterpret_cast<sp_u32x4*>(d + (size_t)P * 128) = L;
     }
-    v0 = f32x4{v[0], v[1], v[2], v[3]};
-    v1 = f32x4{v[4], v[5], v[6], v[7]};
+}
+// channels c .. c + 3 back from the planes: x = (h + m) + l
+__device__ __forceinline__ f32x4 pe_load_planes(const unsigned short* planes, int64_t P, int c, int64_t pix)
+{
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(planes) + pe_off(c, pix, P);
+    const uint2 H = *reinterpret_cast<const uint2*>(s);
+    const uint2 M = *reinterpret_cast<const uint2*>(s + (size_t)P * 64);
+    const uint2 L = *reinterpret_cast<const uint2*>(s + (size_t)P * 128);
+    f32x4 v;
+    v[0] = (__builtin_bit_cast(float, H.x << 16) + __builtin_bit_cast(float, M.x << 16)) + __builtin_bit_cast(float, L.x << 16);
+    v[1] = (__builtin_bit_cast(float, H.x & 0xffff0000u) + __builtin_bit_cast(float, M.x & 0xffff0000u)) + __builtin_bit_cast(float, L.x & 0xffff0000u);
+    v[2] = (__builtin_bit_cast(float, H.y << 16) + __builtin_bit_cast(float, M.y << 16)) + __builtin_bit_cast(float, L.y << 16);
+    v[3] = (__builtin_bit_cast(float, H.y & 0xffff0000u) + __builtin_bit_cast(float, M.y & 0xffff0000u)) + __builtin_bit_cast(float, L.y & 0xffff0000u);
+    return v;
+}
+// d masked by z > 0 where z is kept only as planes: the sign of its h plane (z > 0 <=> bf16(z) > 0 for every normal float)
+__device__ __forceinline__ f32x4 pe_mask_h(f32x4 d, const unsigned short* zh, int64_t P, int c, int64_t pix)
+{
+    const uint2 hb = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(zh) + pe_off(c, pix, P));
+    d[0] = (short)(hb.x & 0xffffu) > 0 ? d[0] : 0.f;
+    d[1] = (short)(hb.x >> 16) > 0 ? d[1] : 0.f;
+    d[2] = (short)(hb.y & 0xffffu) > 0 ? d[2] : 0.f;
+    d[3] = (short)(hb.y >> 16) > 0 ? d[3] : 0.f;
+    return d;
 }
 #endif
 
@@ -53,39 +74,33 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
 {
 #if __HIP_DEVICE_COMPILE__
     const int grp = blockIdx.y;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int g = (int)(idx & 3);
-    const int64_t t = idx >> 2;
-    const int cb = (int)(t / pix_per_group);
-    if (cb >= (C >> 5)) return;
-    const int64_t pix = (int64_t)grp * pix_per_group + (t - (int64_t)cb * pix_per_group);
+    const int Q = C >> 2;
+    const int64_t n4 = (int64_t)pix_per_group * Q;
     const int64_t P = (int64_t)gridDim.y * pix_per_group;
-    const int c0 = cb * 32 + 4 * g;
-    const size_t o = (size_t)pix * C + c0;
-    f32x4 v[2], rp[2];
-    if (resp) pe_load_planes(resp, P, cb, pix, g, rp[0], rp[1]);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n4;
+    const int64_t ii = active ? i : 0;
+    const int c = (int)(ii % Q) * 4;
+    const int64_t pix = (int64_t)grp * pix_per_group + ii / Q;
+    const size_t o = (size_t)pix * C + c;
+    f32x4 v = ld4(y + o) * ld4(scale + grp * C + c) + ld4(shift + grp * C + c);
+    if (res) v += ld4(res + o);
+    if (resp) v += pe_load_planes(resp, P, c, pix);
+    if (y2) v += ld4(y2 + o) * ld4(scale2 + grp * C + c) + ld4(shift2 + grp * C + c);
+    if (relu) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = c0 + 16 * h;
-        v[h] = ld4(y + o + 16 * h) * ld4(scale + grp * C + c) + ld4(shift + grp * C + c);
-        if (res) v[h] += ld4(res + o + 16 * h);
-        if (resp) v[h] += rp[h];
-        if (y2) v[h] += ld4(y2 + o + 16 * h) * ld4(scale2 + grp * C + c) + ld4(shift2 + grp * C + c);
-        if (relu) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[h][k] = fmaxf(v[h][k], 0.f);
-        }
-        if (out) st4(out + o + 16 * h, v[h]);
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
     }
-    pe_store_planes(outp, P, cb, pix, g, v[0], v[1]);
+    if (out && active) st4(out + o, v);
+    pe_store_planes(outp, P, c, pix, v, active);
 #endif
 }
 void k_bn_apply_planes(const float* y, const float* scale, const float* shift, const float* res, const float* y2, const float* scale2,
                        const float* shift2, float* out, unsigned short* outp, int groups, int pix_per_group, int C, int relu,
                        hipStream_t s, const unsigned short* resp)
 {
-    const int64_t n = (int64_t)pix_per_group * (C / 8);
-    hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(pe_cdiv(n, 256), groups), dim3(256), 0, s, y, scale, shift, res, y2, scale2,
+    const int64_t n4 = (int64_t)pix_per_group * (C / 4);
+    hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(pe_cdiv(n4, 256), groups), dim3(256), 0, s, y, scale, shift, res, y2, scale2,
                        shift2, out, outp, pix_per_group, C, relu, resp);
 }
 
@@ -97,66 +112,61 @@ __global__ __launch_bounds__(256) void stem_pool_planes_kernel(const float* __re
 {
 #if __HIP_DEVICE_COMPILE__
     const int grp = blockIdx.y;
-    const int Hp = H / 2, Wp = W / 2;
+    const int Hp = H / 2, Wp = W / 2, Q = C >> 2;
     const int64_t ppg = (int64_t)imgs_per_group * Hp * Wp;          // pooled pixels per group
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int g = (int)(i & 3);
-    const int64_t t = i >> 2;
-    const int cb = (int)(t / ppg);
-    if (cb >= (C >> 5)) return;
-    int64_t r = t - (int64_t)cb * ppg;
-    const int64_t pixg = r;
-    const int ow = (int)(r % Wp); r /= Wp;
-    const int oh = (int)(r % Hp);
-    const int img = grp * imgs_per_group + (int)(r / Hp);
-    const int c0 = cb * 32 + 4 * g;
-    f32x4 best[2];
-    int code[2][4];
+    const int64_t n = ppg * Q;
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i0 < n;
+    const int64_t i = active ? i0 : 0;
+    const int cq = (int)(i % Q), c = cq * 4;
+    const int64_t pixg = i / Q;
+    int64_t t = pixg;
+    const int ow = (int)(t % Wp); t /= Wp;
+    const int oh = (int)(t % Hp);
+    const int img = grp * imgs_per_group + (int)(t / Hp);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) { sc = ld4(scale + grp * C + c); sh = ld4(shift + grp * C + c); }
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int code[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = c0 + 16 * h;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (scale) { sc = ld4(scale + grp * C + c); sh = ld4(shift + grp * C + c); }
-        best[h] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if ((unsigned)ih >= (unsigned)H) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) code[h][k] = 0;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 - 1 + kw;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            f32x4 v = ld4(y + ((size_t)(img * H + ih) * W + iw) * C + c);
+            if (scale) {
+                v = v * sc + sh;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = oh * 2 - 1 + kh;
-            if ((unsigned)ih >= (unsigned)H) continue;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = ow * 2 - 1 + kw;
-                if ((unsigned)iw >= (unsigned)W) continue;
-                f32x4 v = ld4(y + ((size_t)(img * H + ih) * W + iw) * C + c);
-                if (scale) {
-                    v = v * sc + sh;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (v[k] > best[h][k]) { best[h][k] = v[k]; code[h][k] = kh * 3 + kw; }
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] > best[k]) { best[k] = v[k]; code[k] = kh * 3 + kw; }
         }
-        const size_t o = ((size_t)(img * Hp + oh) * Wp + ow) * C + c;
-        if (pooled) st4(pooled + o, best[h]);
-        if (idx)
-            *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((unsigned char)code[h][0], (unsigned char)code[h][1],
-                                                              (unsigned char)code[h][2], (unsigned char)code[h][3]);
     }
-    pe_store_planes(pooledp, (int64_t)gridDim.y * ppg, cb, (int64_t)grp * ppg + pixg, g, best[0], best[1]);
+    const size_t o = ((size_t)(img * Hp + oh) * Wp + ow) * C + c;
+    if (active) {
+        if (pooled) st4(pooled + o, best);
+        if (idx)
+            *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((unsigned char)code[0], (unsigned char)code[1], (unsigned char)code[2],
+                                                              (unsigned char)code[3]);
+    }
+    pe_store_planes(pooledp, (int64_t)gridDim.y * ppg, c, (int64_t)grp * ppg + pixg, best, active);
 #endif
 }
 void k_stem_pool_planes(const float* y, const float* scale, const float* shift, float* pooled, uint8_t* idx, unsigned short* pooledp,
                         int groups, int imgs_per_group, int H, int W, int C, hipStream_t s)
 {
-    const int64_t n = (int64_t)imgs_per_group * (H / 2) * (W / 2) * (C / 8);
+    const int64_t n = (int64_t)imgs_per_group * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(stem_pool_planes_kernel, dim3(pe_cdiv(n, 256), groups), dim3(256), 0, s, y, scale, shift, pooled, idx, pooledp,
                        imgs_per_group, H, W, C);
 }
 
-// dy = ca*dyh + cb*y + cc, dyh = dz masked by z > 0 (or by y*msc+msh > 0); optionally store dyh (elementwise.hip bn_bwd_apply_kernel)
+// dy = ca*dyh + cb*y + cc, dyh = dz masked by z > 0 (z fp32, or the h plane zh of a planes-only z, or y*msc+msh > 0); optionally
+// store dyh (elementwise.hip bn_bwd_apply_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                                   const float* __restrict__ y, const float* __restrict__ ca,
                                                                   const float* __restrict__ cb_, const float* __restrict__ cc, float* dy,
@@ -166,52 +176,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
 {
 #if __HIP_DEVICE_COMPILE__
     const int grp = blockIdx.y;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int g = (int)(idx & 3);
-    const int64_t t = idx >> 2;
-    const int cb = (int)(t / pix_per_group);
-    if (cb >= (C >> 5)) return;
-    const int64_t pix = (int64_t)grp * pix_per_group + (t - (int64_t)cb * pix_per_group);
+    const int Q = C >> 2;
+    const int64_t n4 = (int64_t)pix_per_group * Q;
     const int64_t P = (int64_t)gridDim.y * pix_per_group;
-    const int c0 = cb * 32 + 4 * g;
-    const size_t o = (size_t)pix * C + c0;
-    f32x4 r[2];
-    // planes mode: the ReLU mask of a tensor kept only as planes is the sign of its h plane (this thread's chunk: 8 bf16)
-    sp_u32x4 hb = {0u, 0u, 0u, 0u};
-    if (zh) hb = *reinterpret_cast<const sp_u32x4*>(reinterpret_cast<const unsigned char*>(zh) + (((size_t)cb * 3) * P + pix) * 64 + g * 16);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n4;
+    const int64_t ii = active ? i : 0;
+    const int c = (int)(ii % Q) * 4;
+    const int64_t pix = (int64_t)grp * pix_per_group + ii / Q;
+    const size_t o = (size_t)pix * C + c;
+    f32x4 d = ld4(dz + o);
+    if (zh) d = pe_mask_h(d, zh, P, c, pix);
+    if (z) {
+        const f32x4 zz = ld4(z + o);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = c0 + 16 * h;
-        f32x4 d = ld4(dz + o + 16 * h);
-        if (zh) {
-            d[0] = (short)(hb[2 * h] & 0xffffu) > 0 ? d[0] : 0.f;
-            d[1] = (short)(hb[2 * h] >> 16) > 0 ? d[1] : 0.f;
-            d[2] = (short)(hb[2 * h + 1] & 0xffffu) > 0 ? d[2] : 0.f;
-            d[3] = (short)(hb[2 * h + 1] >> 16) > 0 ? d[3] : 0.f;
-        }
-        if (z) {
-            const f32x4 zz = ld4(z + o + 16 * h);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = zz[k] > 0.f ? d[k] : 0.f;
-        }
-        const f32x4 yy = ld4(y + o + 16 * h);
-        if (msc) {
-            const f32x4 sc = ld4(msc + grp * C + c), sh = ld4(msh + grp * C + c);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(yy[k], sc[k], sh[k]) > 0.f ? d[k] : 0.f;
-        }
-        r[h] = ld4(ca + grp * C + c) * d + ld4(cb_ + grp * C + c) * yy + ld4(cc + grp * C + c);
-        if (dyh_out) st4(dyh_out + o + 16 * h, d);
-        if (dy) st4(dy + o + 16 * h, r[h]);
+        for (int k = 0; k < 4; ++k) d[k] = zz[k] > 0.f ? d[k] : 0.f;
     }
-    pe_store_planes(dyp, P, cb, pix, g, r[0], r[1]);
+    const f32x4 yy = ld4(y + o);
+    if (msc) {
+        const f32x4 sc = ld4(msc + grp * C + c), sh = ld4(msh + grp * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = __builtin_fmaf(yy[k], sc[k], sh[k]) > 0.f ? d[k] : 0.f;
+    }
+    const f32x4 r = ld4(ca + grp * C + c) * d + ld4(cb_ + grp * C + c) * yy + ld4(cc + grp * C + c);
+    if (active) {
+        if (dyh_out) st4(dyh_out + o, d);
+        if (dy) st4(dy + o, r);
+    }
+    pe_store_planes(dyp, P, c, pix, r, active);
 #endif
 }
 void k_bn_bwd_apply_planes(const float* dz, const float* z, const float* y, const float* ca, const float* cb, const float* cc, float* dy,
                            unsigned short* dyp, float* dyh_out, int groups, int pix_per_group, int C, hipStream_t s,
                            const float* mask_scale, const float* mask_shift, const unsigned short* zh)
 {
-    const int64_t n = (int64_t)pix_per_group * (C / 8);
-    hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(pe_cdiv(n, 256), groups), dim3(256), 0, s, dz, z, y, ca, cb, cc, dy, dyp,
+    const int64_t n4 = (int64_t)pix_per_group * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(pe_cdiv(n4, 256), groups), dim3(256), 0, s, dz, z, y, ca, cb, cc, dy, dyp,
                        dyh_out, pix_per_group, C, mask_scale, mask_shift, zh);
 }

@@ -66,6 +66,7 @@ class Engine:
         # what fm_create actually set up (it keeps one stream when the second buffer set does not fit in free memory)
         self.stream_mode = int(self.lib.fm_stream_mode(self.h))
         self.products = int(self.lib.fm_products(self.h))      # 0 fp32 matrix pipe, 6 / 9 bf16 partial products
+        self.planes = bool(self.lib.fm_planes_mode(self.h))    # conv GEMMs read bf16 planes written by the producing kernels
         # Efficient_b0: draw drop-connect / dropout multipliers before every train step, like the
         # reference's model does inside net(images) in train mode.  Parity tests switch it off and
         # install their own draws with set_stochastic().

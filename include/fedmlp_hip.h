@@ -264,6 +264,10 @@ int fm_stream_mode(fm_engine* e);
  * its own algorithm behind nn.Conv2d (model/all_models.py:53-54). */
 int fm_mfma_products(void);
 int fm_products(fm_engine* e);
+/* 1 when the handle's conv GEMMs read their operands as bf16 planes written by the producing kernels (ResNet-18 in a split
+ * product form: csrc/pconv.hip, pwgrad.hip, planes_ew.hip; activations between convs then exist only as planes), 0 when they
+ * read fp32 tensors (csrc/igemm.hip, wgrad.hip: EfficientNet-B0, the fp32 matrix pipe, FM_PLANES=0).  Same arithmetic either way. */
+int fm_planes_mode(fm_engine* e);
 
 /* ---- measurement hooks (bench.py roofline leg) ---------------------------- */
 /* When enabled, HIP events bracket every convolution GEMM launch on the
