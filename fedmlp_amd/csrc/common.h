@@ -218,7 +218,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 void launch_pconv(IgemmParams p, int groups, hipStream_t s);
 bool pconv_takes(int M, int Ci, long long xp_pix, int Wi);
 int pconv_tile_m(int M);
-int pconv_tile_n();
+int pconv_tile_n(int M);
 // small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
 bool conv1x1_stream_takes(int Ci, int M, int Co);     // would a stride-1 1x1 conv of this shape stream through conv1x1.hip?

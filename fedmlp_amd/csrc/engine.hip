@@ -1007,7 +1007,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         p.os = 1; p.oh0 = 0; p.ow0 = 0;
         p.imgs_per_group = imgs / groups;
         p.tilesM = c.cout_p / pconv_tile_m(c.cout_p);
-        p.tilesN = (p.imgs_per_group * c.hout * c.wout + pconv_tile_n() - 1) / pconv_tile_n();
+        p.tilesN = (p.imgs_per_group * c.hout * c.wout + pconv_tile_n(c.cout_p) - 1) / pconv_tile_n(c.cout_p);
         p.relu = relu;
         ProfScope ps(e, c.cout_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs);
         launch_pconv(p, groups, e->st);
@@ -1069,7 +1069,7 @@ int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
     const Conv& c = e->convs[ci];
     if (e->precision && (c.k == 1 || c.cin == 3))
         return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro, c.hout * c.wout);
-    if (conv_uses_pconv(e, c, imgs_per_group * groups)) return (imgs_per_group * c.hout * c.wout + pconv_tile_n() - 1) / pconv_tile_n();
+    if (conv_uses_pconv(e, c, imgs_per_group * groups)) return (imgs_per_group * c.hout * c.wout + pconv_tile_n(c.cout_p) - 1) / pconv_tile_n(c.cout_p);
     const int bn = igemm_tile_n(c.cout_p, c.cin == 3);
     return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
 }
@@ -1101,7 +1101,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
             p.os = c.stride; p.oh0 = d.ph; p.ow0 = d.pw;
             p.imgs_per_group = imgs;
             p.tilesM = c.cin_p / pconv_tile_m(c.cin_p);
-            p.tilesN = (imgs * p.Hg * p.Wg + pconv_tile_n() - 1) / pconv_tile_n();
+            p.tilesN = (imgs * p.Hg * p.Wg + pconv_tile_n(c.cin_p) - 1) / pconv_tile_n(c.cin_p);
             p.relu = 0;
             ProfScope ps(e, c.cin_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
             launch_pconv(p, 1, e->st);

@@ -56,16 +56,21 @@ template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3
 }
 #endif
 
-template <int FR, int SP>
+// FR x FC: 16 x 16 MFMA tiles per wave (wave tile 16 FR x 16 FC); block tile 32 FR x 64 FC.  NS: LDS stages (the DMA runs NS - 1
+// steps ahead).  Instantiated: <4, 4, 2> = 128 x 256 (M >= 128) and <2, 4, 2> = 64 x 256 for the 64-channel layers.  Measured and not
+// kept for those: <2, 3, 3> = 64 x 192 with three stages (two steps of DMA lookahead): 315 vs 294 us per 56 x 56 x 64 layer at 256
+// images -- the layer is bound by LDS traffic per MFMA (every B row serves 64 output channels only), not by DMA latency
+template <int FR, int FC, int NS, int SP>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__
-    constexpr int WN = 4, FC = 4;
-    constexpr int BM = 32 * FR, BN = 256;
+    constexpr int WN = 4;
+    constexpr int BM = 32 * FR, BN = 64 * FC;
     constexpr int SA = 3 * BM * 64, SB = 3 * BN * 64;          // bytes per stage
     constexpr int GA = BM / 16, GB = BN / 16;                  // 16-row groups per operand tile
-    constexpr int JA = (3 * GA + 7) / 8;                       // A DMA instructions per wave per stage (3 or 2 of 1.5)
-    constexpr int RGB = GB / 8;                                // B row groups per wave (2), each x 3 planes
+    constexpr int JA = (3 * GA + 7) / 8;                       // A DMA instructions per wave per stage (waves past 3 GA - 8 (JA - 1): one fewer)
+    constexpr int RGB = (GB + 7) / 8;                          // B row groups per wave (wave + 8 i < GB), each x 3 planes
+    static_assert(NS == 2 || NS == 3, "two or three LDS stages");
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)smem;              // LDS byte address of the dynamic segment
-    const unsigned As = lds0, Bs = lds0 + 2 * SA;              // [2][3][BM][64], [2][3][BN][64]
+    const unsigned As = lds0, Bs = lds0 + NS * SA;             // [NS][3][BM][64], [NS][3][BN][64]
 
     const int nsteps = p.nsteps;                               // K-steps of 32: (channel block, tap), tap-minor
     const int ntaps = p.ntaps;
@@ -101,8 +106,13 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const int drow = lane >> 2, chunk = (lane & 3) ^ ((lane >> 3) & 3);
     // fragment reads: row 16r + li of the wave's rows, chunk lg sits in slot lg ^ ((li>>1)&3)
     const unsigned fro = li * 64 + ((lg ^ ((li >> 1) & 3)) << 4);
-    const unsigned Af0 = As + wm * (16 * FR) * 64 + fro, Af1 = Af0 + SA;
-    const unsigned Bf0 = Bs + wn * 64 * 64 + fro, Bf1 = Bf0 + SB;
+    const unsigned Af0 = As + wm * (16 * FR) * 64 + fro;
+    const unsigned Bf0 = Bs + wn * (16 * FC) * 64 + fro;
+    // DMA instructions this wave issues per K-step (A jobs + 3 planes x its B row groups): the counted vmcnt of NS = 3
+    const int ngrpB = (wave + 8 * (RGB - 1) < GB) ? RGB : RGB - 1;
+    constexpr int NW_HI = JA + 3 * RGB;                                            // waves that hold the full share
+    constexpr int NW_LO = ((3 * GA) % 8 ? JA - 1 : JA) + 3 * (GB % 8 ? RGB - 1 : RGB);   // waves 4 .. 7 when the job counts are odd multiples of 4
+    static_assert(NS == 2 || ((3 * GA) % 8 == 0 || (3 * GA) % 8 == 4) && (GB % 8 == 0 || GB % 8 == 4), "job split by wave < 4");
 
     // A segment = the K-steps [k0, k1) of one tile that this block's range covers, with the per-lane DMA state of the tile
     struct Seg {
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #pragma unroll
         for (int i = 0; i < RGB; ++i) {
             const int n = g.n0 + 16 * (wave + 8 * i) + drow;
-            const bool rv = n < npix;
+            const bool rv = n < npix && i < ngrpB;
             const int nn = rv ? n : 0;
             const int img = nn / HWg, rem = nn - img * HWg;
             const int hg = rem / p.Wg, wg = rem - hg * p.Wg;
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         const unsigned tapo = ((f & 3u) * (unsigned)Wi + (f >> 2)) * 64u;           // (dh + 1) * Wi + (dw + 1) pixels
 #pragma unroll
         for (int i = 0; i < RGB; ++i) {
+            if (GB % 8 != 0 && i >= ngrpB) break;
             const unsigned vo = ((g.vmask[i] >> g.it_b) & 1u) ? g.voffB[i] : OOB;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
@@ -193,79 +204,102 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #pragma unroll
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         sp_u32x4 A0[FR][3], A1[FR][3], Bb[2][3];
-#define PC_READA(SLOT, R, DST)                                                                  \
+    // BASE = the fragment base address of the stage slot the read takes (Af0 + slot * SA, Bf0 + slot * SB)
+#define PC_READA(BASE, R, DST)                                                                  \
     {                                                                                           \
-        DST[0] = pc_lds_read128<(0 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                  \
-        DST[1] = pc_lds_read128<(1 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                  \
-        DST[2] = pc_lds_read128<(2 * BM + 16 * (R)) * 64>((SLOT) ? Af1 : Af0);                  \
+        DST[0] = pc_lds_read128<(0 * BM + 16 * (R)) * 64>(BASE);                                \
+        DST[1] = pc_lds_read128<(1 * BM + 16 * (R)) * 64>(BASE);                                \
+        DST[2] = pc_lds_read128<(2 * BM + 16 * (R)) * 64>(BASE);                                \
     }
-#define PC_READB(SLOT, C, DST)                                                                  \
+#define PC_READB(BASE, C, DST)                                                                  \
     {                                                                                           \
-        DST[0] = pc_lds_read128<(0 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
-        DST[1] = pc_lds_read128<(1 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
-        DST[2] = pc_lds_read128<(2 * BN + 16 * (C)) * 64>((SLOT) ? Bf1 : Bf0);                  \
+        DST[0] = pc_lds_read128<(0 * BN + 16 * (C)) * 64>(BASE);                                \
+        DST[1] = pc_lds_read128<(1 * BN + 16 * (C)) * 64>(BASE);                                \
+        DST[2] = pc_lds_read128<(2 * BN + 16 * (C)) * 64>(BASE);                                \
     }
+    // the rolling B buffers: column c of a step of register parity PAR sits in Bb[(c + PAR * FC) & 1] (odd FC: the parity of the
+    // first column alternates from step to step, so the next step's column 0 never lands on the column still in use)
+#define PC_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
 #define PC_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     // workgroup barrier that orders LDS accesses only: a __syncthreads() would also wait for the LDS-DMA in flight
 #define PC_SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-        // ---- prologue: slots are indexed by the step's parity relative to k0 ------------------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment's lead DMA (issued by lead())
+        // ---- prologue.  Stage slot of step s = (s - k0) % NS.  Invariant at the start of step s: B(s), A(s + 1) have landed
+        // (A(s) is in registers), B(s + 1 .. s + NS - 1) and A(s + 2 .. s + NS) are issued ----------------------------------------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment's lead DMA: A(k0), B(k0), A(k0 + 1)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (k0 + 1 < k1) issueB(cur, 1);
-        PC_READA(0, 0, A0[0]);
-        PC_READA(0, 1, A0[1]);
-        if constexpr (FR == 4) { PC_READA(0, 2, A0[2]); PC_READA(0, 3, A0[3]); }
-        PC_READB(0, 0, Bb[0]);
+        if constexpr (NS == 3) {
+            if (k0 + 2 < k1) issueA(cur, k0 + 2, 2);
+            if (k0 + 2 < k1) issueB(cur, 2);
+        }
+        PC_READA(Af0, 0, A0[0]);
+        PC_READA(Af0, 1, A0[1]);
+        if constexpr (FR == 4) { PC_READA(Af0, 2, A0[2]); PC_READA(Af0, 3, A0[3]); }
+        PC_READB(Bf0, 0, Bb[0]);
         PC_LGKM0();
-        __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + 2)
+        __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + NS)
         asm volatile("" ::: "memory");
-        if (k0 + 2 < k1) issueA(cur, k0 + 2, 0);
+        if (k0 + NS < k1) issueA(cur, k0 + NS, 0);
 
-        // one K-step (slot parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
-        // FULL: steps s+1, s+2, s+3 exist (the main loop: no branch inside); otherwise the conditions are tested
+        int ib = 0;                            // stage slot of the current step
+        // one K-step (register parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
+        // FULL: steps up to s + NS + 1 exist (the main loop: no branch inside, counted vmcnt); otherwise the conditions are tested
         auto step = [&](auto par_c, auto full_c, int s, sp_u32x4 (&Ac)[FR][3], sp_u32x4 (&An)[FR][3]) {
             constexpr int PAR = decltype(par_c)::value;
             constexpr bool FULL = decltype(full_c)::value;
-            // columns 0 .. 2: the next column's B fragments and a share of the next step's A fragments go out at the head of
-            // the column's MFMAs and are waited for at its end
+            const int ib1 = (ib + 1 == NS) ? 0 : ib + 1;
+            const unsigned b_cur = Bf0 + ib * SB, b_nxt = Bf0 + ib1 * SB, a_nxt = Af0 + ib1 * SA;
+            // columns 0 .. FC - 2: the next column's B fragments and a share of the next step's A fragments go out at the head
+            // of the column's MFMAs and are waited for at its end
 #define PC_COLUMN(C)                                                                                             \
             {                                                                                                    \
-                PC_READB(PAR, (C) + 1, Bb[((C) + 1) & 1]);                                                       \
+                PC_READB(b_cur, (C) + 1, Bb[PC_BI((C) + 1, PAR)]);                                               \
                 if (FULL || s + 1 < k1) {                                                                        \
-                    if constexpr (FR == 4) {                                                                     \
-                        if constexpr ((C) == 0) { PC_READA(PAR ^ 1, 0, An[0]); PC_READA(PAR ^ 1, 1, An[1]); }    \
-                        if constexpr ((C) == 1) { PC_READA(PAR ^ 1, 2, An[2]); }                                 \
-                        if constexpr ((C) == 2) { PC_READA(PAR ^ 1, 3, An[3]); }                                 \
+                    if constexpr (FR == 4 && FC == 4) {                                                          \
+                        if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }        \
+                        if constexpr ((C) == 1) { PC_READA(a_nxt, 2, An[2]); }                                   \
+                        if constexpr ((C) == 2) { PC_READA(a_nxt, 3, An[3]); }                                   \
+                    } else if constexpr (FR == 4) {                                                              \
+                        if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }        \
+                        if constexpr ((C) == 1) { PC_READA(a_nxt, 2, An[2]); PC_READA(a_nxt, 3, An[3]); }        \
                     } else {                                                                                     \
-                        if constexpr ((C) == 0) { PC_READA(PAR ^ 1, 0, An[0]); }                                 \
-                        if constexpr ((C) == 1) { PC_READA(PAR ^ 1, 1, An[1]); }                                 \
+                        if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); }                                   \
+                        if constexpr ((C) == 1) { PC_READA(a_nxt, 1, An[1]); }                                   \
                     }                                                                                            \
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
-                _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[(C) & 1], acc[r][C]); \
+                _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[PC_BI(C, PAR)], acc[r][C]); \
                 PC_LGKM0();                                                                                      \
             }
             PC_COLUMN(0)
             PC_COLUMN(1)
-            PC_COLUMN(2)
+            if constexpr (FC == 4) PC_COLUMN(2)
 #undef PC_COLUMN
-            // last column: every wave holds all of this step's fragments and step s+1's A fragments: both read slots are free
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // last column: every wave holds all of this step's fragments and step s+1's A fragments: slot ib of B and slot ib1 of A
+            // are free.  B(s + 1) and A(s + 2) must have landed: with three stages the youngest group of DMA (B(s + 2), A(s + 3),
+            // issued one step ago) may stay in flight
+            if constexpr (NS == 3 && FULL) {
+                if constexpr (NW_HI == NW_LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
+                else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_LO) : "memory");
+            } else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (FULL || s + 1 < k1) PC_READB(PAR ^ 1, 0, Bb[0]);
-            if (FULL || s + 2 < k1) issueB(cur, PAR);
-            if (FULL || s + 3 < k1) issueA(cur, s + 3, PAR ^ 1);
+            if (FULL || s + 1 < k1) PC_READB(b_nxt, 0, Bb[PC_BI(0, PAR ^ 1)]);
+            if (FULL || s + NS < k1) issueB(cur, ib);
+            if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
 #pragma unroll
-            for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[(FC - 1) & 1], acc[r][FC - 1]);
+            for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[PC_BI(FC - 1, PAR)], acc[r][FC - 1]);
             PC_LGKM0();
+            ib = ib1;
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         int s = k0;
-        for (; s + 5 <= k1; s += 2) {          // steps s and s + 1 are FULL: s + 1 + 3 < k1
+        for (; s + NS + 3 <= k1; s += 2) {     // steps s and s + 1 are FULL: s + 1 + NS + 1 < k1
             step(I0{}, std::true_type{}, s, A0, A1);
             step(I1{}, std::true_type{}, s + 1, A1, A0);
         }
@@ -276,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #undef PC_READA
 #undef PC_READB
 #undef PC_LGKM0
+#undef PC_BI
         PC_SYNC_LDS();         // every wave is done reading both stages: they can take the next segment's lead DMA
 
         // ---- the next segment's pipeline fill starts now, behind this segment's fix-up / epilogue --------------------------------
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         }
         const int tile = cur.tile, grp = cur.grp, tn = cur.tn, m0 = cur.m0, n0 = cur.n0;
         // the fix-up / epilogue scratch sits BEHIND the stages (they are being refilled)
-        float* fsmem = reinterpret_cast<float*>(smem + 2 * SA + 2 * SB);
+        float* fsmem = reinterpret_cast<float*>(smem + NS * SA + NS * SB);
         bool do_epilogue = true;
 
         // ---- stream-K fix-up: partial tiles meet in the slab ------------------------
@@ -383,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         }
 #pragma unroll
         for (int c = 0; c < FC; ++c) {
-            const int n = n0 + wn * 64 + 16 * c + li;
+            const int n = n0 + wn * (16 * FC) + 16 * c + li;
             if (n >= npix) continue;
             const int img = n / HWg;
             const int rem = n - img * HWg;
@@ -515,7 +550,7 @@ void k_split_planes(const float* x, unsigned short* dst, long long npix, int C, 
 }
 
 int pconv_tile_m(int M) { return M >= 128 ? 128 : 64; }
-int pconv_tile_n() { return 256; }
+int pconv_tile_n(int M) { (void)M; return 256; }
 int pconv_max_blocks() { return 256; }     // ONE block per CU (120 - 144 KB of LDS)
 // does the planes kernel take this GEMM?  whole M tiles, whole 32-channel blocks, taps within [-1, 1], planes below 2 GB
 bool pconv_takes(int M, int Ci, long long xp_pix, int Wi)
@@ -528,13 +563,14 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
     // two stages + the fix-up / epilogue scratch behind them (statistics partials [4][BM][2] floats, the last-arriver flag)
-    constexpr int LDS_L = 2 * 3 * (128 + 256) * 64 + 4 * 128 * 2 * 4;      // 148 KB
-    constexpr int LDS_S = 2 * 3 * (64 + 256) * 64 + 4 * 128 * 2 * 4;       // 124 KB
+    // the stages + the fix-up / epilogue scratch behind them (statistics partials [4][BM][2] floats, the last-arriver flag)
+    constexpr int LDS_L = 2 * 3 * (128 + 256) * 64 + 4 * 128 * 2 * 4;      // 148 KB: 128 x 256, two stages
+    constexpr int LDS_S = 2 * 3 * (64 + 256) * 64 + 4 * 128 * 2 * 4;       // 124 KB: 64 x 256, two stages
     if (!attr_done) {
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 6>), LDS_L, "pconv_kernel<4, 6>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 9>), LDS_L, "pconv_kernel<4, 9>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 6>), LDS_S, "pconv_kernel<2, 6>");
-        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 9>), LDS_S, "pconv_kernel<2, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 6>), LDS_L, "pconv_kernel<4, 4, 2, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 9>), LDS_L, "pconv_kernel<4, 4, 2, 9>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 4, 2, 6>), LDS_S, "pconv_kernel<2, 4, 2, 6>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 4, 2, 9>), LDS_S, "pconv_kernel<2, 4, 2, 9>");
         attr_done = true;
     }
     p.nsteps = p.ntaps * (p.Ci >> 5);
@@ -554,11 +590,11 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
     dim3 grid(nblk);
     if (p.M >= 128) {
-        if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 9>), grid, dim3(512), LDS_L, s, p);
-        else hipLaunchKernelGGL((pconv_kernel<4, 6>), grid, dim3(512), LDS_L, s, p);
+        if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 9>), grid, dim3(512), LDS_L, s, p);
+        else hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 6>), grid, dim3(512), LDS_L, s, p);
     } else {
-        if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<2, 9>), grid, dim3(512), LDS_S, s, p);
-        else hipLaunchKernelGGL((pconv_kernel<2, 6>), grid, dim3(512), LDS_S, s, p);
+        if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<2, 4, 2, 9>), grid, dim3(512), LDS_S, s, p);
+        else hipLaunchKernelGGL((pconv_kernel<2, 4, 2, 6>), grid, dim3(512), LDS_S, s, p);
     }
 }
 
