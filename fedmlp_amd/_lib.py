@@ -61,6 +61,8 @@ SYMBOLS = {
     "fm_cos_tag": (C.c_int, [_P, _P, _I64, _P, C.POINTER(_I32), _I32, _P]),
     "fm_select_topk": (C.c_int, [_P, _P, _I64, C.c_double, C.c_double, _I32, C.POINTER(_I32),
                                  C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "fm_select_topk_rows": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(_I32), C.POINTER(_I32), _I32, C.c_double, C.c_double, _I32,
+                                      C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "fm_augment": (C.c_int, [_P, _P, _P, _P, _I32, _F, _F, _P]),
     "fm_forward_train": (C.c_int, [_P, _P, _P, _I32, _P, _P]),
     "fm_backward_step": (C.c_int, [_P, _P]),

@@ -171,6 +171,8 @@ struct fm_engine {
     int* sk_counters = nullptr;
     int *sel_counts = nullptr, *sel_top = nullptr, *sel_bot = nullptr, *cls_dev = nullptr;
     int sel_cap = 0;
+    int* tag_buf = nullptr;           // fm_select_topk_rows: [pool sizes ncls | counts 2 ncls | top ncls*cap | bot ncls*cap | rows ncls*stride]
+    size_t tag_buf_ints = 0;
     // profiling
     bool prof = false, prof_fail = false;
     hipError_t soft_err = hipSuccess;      // first failed event record / stream wait of the current step (soft())
@@ -2422,6 +2424,48 @@ int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_t
     if (kb) HIPCHK(hipMemcpyAsync(bot_host, e->sel_bot, (size_t)kb * 4, hipMemcpyDeviceToHost, e->st));
     HIPCHK(hipStreamSynchronize(e->st));
     *n_top = kt; *n_bot = kb;
+    return FM_OK;
+}
+
+int fm_select_topk_rows(fm_engine* e, const float* sim_dev, int64_t N, int32_t n_cls, const int32_t* pool_rows_host,
+                        const int32_t* pool_n_host, int32_t stride, double clean_thr, double noise_thr, int32_t cap,
+                        int32_t* top_host, int32_t* n_top, int32_t* bot_host, int32_t* n_bot)
+{
+    ARGCHK(e && pool_n_host && top_host && n_top && bot_host && n_bot, "null");
+    ARGCHK(n_cls >= 0 && n_cls <= FM_MAX_CLASSES && cap >= 1, "n_cls / cap");
+    for (int k = 0; k < n_cls; ++k) n_top[k] = n_bot[k] = 0;
+    if (n_cls == 0 || N == 0) return FM_OK;
+    ARGCHK(sim_dev, "null sim_dev");
+    int maxn = 0;
+    for (int k = 0; k < n_cls; ++k) {
+        ARGCHK(pool_n_host[k] >= 0 && pool_n_host[k] <= (pool_rows_host ? stride : N), "pool size");
+        maxn = std::max(maxn, pool_n_host[k]);
+    }
+    const size_t rows_ints = pool_rows_host ? (size_t)n_cls * stride : 0;
+    const size_t need = (size_t)n_cls * (3 + 2 * (size_t)cap) + rows_ints;
+    if (e->tag_buf_ints < need) {
+        e->tag_buf_ints = need + need / 2;
+        DALLOC(e->tag_buf, e->tag_buf_ints);
+    }
+    int* d_pn = e->tag_buf;
+    int* d_counts = d_pn + n_cls;
+    int* d_top = d_counts + 2 * n_cls;
+    int* d_bot = d_top + (size_t)n_cls * cap;
+    int* d_rows = pool_rows_host ? d_bot + (size_t)n_cls * cap : nullptr;
+    HIPCHK(hipMemcpyAsync(d_pn, pool_n_host, (size_t)n_cls * 4, hipMemcpyHostToDevice, e->st));
+    if (d_rows) HIPCHK(hipMemcpyAsync(d_rows, pool_rows_host, rows_ints * 4, hipMemcpyHostToDevice, e->st));
+    k_select_rows(sim_dev, N, n_cls, d_rows, d_pn, stride, maxn, clean_thr, noise_thr, cap, d_counts, d_top, d_bot, e->st);
+    // ONE device-to-host read: the counts and both pick tables
+    std::vector<int> h((size_t)n_cls * (2 + 2 * (size_t)cap));
+    HIPCHK(hipMemcpyAsync(h.data(), d_counts, h.size() * 4, hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    for (int k = 0; k < n_cls; ++k) {
+        const int kt = (int)(1 * clean_thr * h[2 * k]), kb = (int)(1 * noise_thr * h[2 * k + 1]);     // int() truncation as in :1069-1070
+        ARGCHK(kt <= cap && kb <= cap, "selection exceeds cap");
+        n_top[k] = kt; n_bot[k] = kb;
+        memcpy(top_host + (size_t)k * cap, h.data() + 2 * n_cls + (size_t)k * cap, (size_t)kt * 4);
+        memcpy(bot_host + (size_t)k * cap, h.data() + 2 * n_cls + (size_t)n_cls * cap + (size_t)k * cap, (size_t)kb * 4);
+    }
     return FM_OK;
 }
 

@@ -376,6 +376,58 @@ __global__ void rank_select_kernel(const float* __restrict__ sim, int64_t N, int
     if (rd < ktop) top[rd] = (int)i;
     if (ra < kbot) bot[ra] = (int)i;
 }
+// ---- every missing class of a round in one launch pair (fm_select_topk_rows) ----------------------------------------------
+// sim [ncls][N]; class k's pool = rows[k*stride .. + pn[k]) (positions into its sim row, pool order), or all N rows when rows
+// is null.  counts[k] = (#(sim >= 0), #(sim < 0)) over the pool (NaN in neither, like utils/local_training.py:1061-1066)
+__global__ void count_sign_rows_kernel(const float* __restrict__ sim, int64_t N, const int* __restrict__ rows,
+                                       const int* __restrict__ pn, int stride, int* __restrict__ counts)
+{
+    __shared__ float sh[4];
+    const int k = blockIdx.x;
+    const int n = pn[k];
+    const float* sr = sim + (size_t)k * N;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = sr[rows ? rows[(size_t)k * stride + i] : i];
+        a += v >= 0.f ? 1.f : 0.f;
+        b += v < 0.f ? 1.f : 0.f;
+    }
+    a = block_sum(a, sh);
+    b = block_sum(b, sh);
+    if (threadIdx.x == 0) { counts[2 * k] = (int)a; counts[2 * k + 1] = (int)b; }
+}
+// stable ranks inside each pool; ktop / kbot = int(thr * count) with the reference's double arithmetic and truncation (:1069-1070)
+__global__ void rank_select_rows_kernel(const float* __restrict__ sim, int64_t N, const int* __restrict__ rows,
+                                        const int* __restrict__ pn, int stride, const int* __restrict__ counts, double clean_thr,
+                                        double noise_thr, int cap, int* __restrict__ top, int* __restrict__ bot)
+{
+    const int k = blockIdx.y;
+    const int n = pn[k];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ktop = (int)(1 * clean_thr * counts[2 * k]), kbot = (int)(1 * noise_thr * counts[2 * k + 1]);
+    if (ktop == 0 && kbot == 0) return;
+    const float* sr = sim + (size_t)k * N;
+    const int* rk = rows ? rows + (size_t)k * stride : nullptr;
+    const float v = sr[rk ? rk[i] : i];
+    int rd = 0, ra = 0;
+    for (int j = 0; j < n; ++j) {
+        const float u = sr[rk ? rk[j] : j];
+        rd += (u > v) || (u == v && j < i);
+        ra += (u < v) || (u == v && j < i);
+    }
+    if (rd < ktop && rd < cap) top[(size_t)k * cap + rd] = i;
+    if (ra < kbot && ra < cap) bot[(size_t)k * cap + ra] = i;
+}
+void k_select_rows(const float* sim, int64_t N, int ncls, const int* rows, const int* pn, int stride, int maxn, double clean_thr,
+                   double noise_thr, int cap, int* counts, int* top, int* bot, hipStream_t s)
+{
+    hipLaunchKernelGGL(count_sign_rows_kernel, dim3(ncls), dim3(256), 0, s, sim, N, rows, pn, stride, counts);
+    if (maxn > 0)
+        hipLaunchKernelGGL(rank_select_rows_kernel, dim3(cdiv(maxn, 256), ncls), dim3(256), 0, s, sim, N, rows, pn, stride, counts,
+                           clean_thr, noise_thr, cap, top, bot);
+}
+
 void k_rank_select(const float* sim, int64_t N, int ktop, int kbot, int* top, int* bot, hipStream_t s)
 {
     hipLaunchKernelGGL(rank_select_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, sim, N, ktop, kbot, top, bot);

@@ -199,3 +199,6 @@ void k_cos_tag(const float* feat, int64_t N, int D, const float* proto, const in
 void k_count_sign(const float* sim, int64_t N, int* counts /*[2]: >=0, <0*/, hipStream_t s);
 // stable ranks: top[rank_desc] = pos if rank_desc < ktop ; bot[rank_asc] = pos if rank_asc < kbot
 void k_rank_select(const float* sim, int64_t N, int ktop, int kbot, int* top, int* bot, hipStream_t s);
+// all classes of a round: counts [ncls][2], top / bot [ncls][cap] (positions inside each class's pool); rows null = whole rows
+void k_select_rows(const float* sim, int64_t N, int ncls, const int* rows, const int* pn, int stride, int maxn, double clean_thr,
+                   double noise_thr, int cap, int* counts, int* top, int* bot, hipStream_t s);

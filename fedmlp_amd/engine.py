@@ -311,6 +311,31 @@ class Engine:
                                            C.byref(nb)))
         return list(top[:nt.value]), list(bot[:nb.value])
 
+    def select_topk_rows(self, sims, pools, clean_thr, noise_thr):
+        """Every class of a round at once: sims [n_cls, N] (cos_tag's output), pools[k] = the positions of class k's pool inside
+        its similarity row, in pool order (None = every row).  -> [(top, bot)] per class, as positions INSIDE the pool.  One
+        launch pair and one device-to-host read (fm_select_topk_rows)."""
+        n_cls, N = int(sims.shape[0]), int(sims.shape[1])
+        if n_cls == 0:
+            return []
+        sizes = [N if p is None else len(p) for p in pools]
+        whole = all(p is None for p in pools)
+        stride = max(max(sizes), 1)
+        rows = None
+        if not whole:
+            flat = np.zeros((n_cls, stride), dtype=np.int32)
+            for k, p in enumerate(pools):
+                flat[k, :sizes[k]] = np.arange(N, dtype=np.int32) if p is None else np.asarray(p, dtype=np.int32)
+            rows = flat.ctypes.data_as(C.POINTER(C.c_int32))
+            self._keep = flat
+        cap = int(max(clean_thr, noise_thr, 0.0) * max(sizes)) + 1
+        pn = (C.c_int32 * n_cls)(*sizes)
+        top, bot = (C.c_int32 * (n_cls * cap))(), (C.c_int32 * (n_cls * cap))()
+        nt, nb = (C.c_int32 * n_cls)(), (C.c_int32 * n_cls)()
+        _lib.check(self.lib.fm_select_topk_rows(self.h, _ptr(sims), N, n_cls, rows, pn, stride, float(clean_thr),
+                                                float(noise_thr), cap, top, nt, bot, nb))
+        return [(list(top[k * cap:k * cap + nt[k]]), list(bot[k * cap:k * cap + nb[k]])) for k in range(n_cls)]
+
     # ---- input pipeline ---------------------------------------------------------------
     def augment(self, cache_u8, idx, params, mean, std):
         """uint8 cache [N,3,H,W] + sample indices [B] (int32) + fixed-point affine/flip records [B,8] (int32,

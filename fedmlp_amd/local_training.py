@@ -367,6 +367,34 @@ class LocalUpdate(object):
         """cos(f, P0) - cos(f, P1) of every pool sample, on the device (CosineSimilarityFast :1417-1435)"""
         return eng.cos_tag(pool_f.contiguous(), proto_dev, [cls])[0]
 
+    def _log_similarity(self, rnd, cls, pool_idx, sim_of_pool):
+        """hook: the similarities of one class's pool, in pool order (a callable returning the device tensor; tests record it)"""
+
+    def _select_all(self, eng, rnd, classes, f, ds_idx, pools, proto_dev):
+        """Every missing class of the round: ONE cosine-tagging launch over all local features, one selection launch pair and one
+        device-to-host read (fm_cos_tag + fm_select_topk_rows).  pools[k] = rows of f forming class k's pool, in pool order
+        (None = all).  -> [(clean, noise)] dataset indices per class, with _select()'s semantics."""
+        if not len(classes):
+            return []
+        sims = eng.cos_tag(f.contiguous(), proto_dev, list(classes))
+        picks = eng.select_topk_rows(sims, pools, self.args.clean_threshold, self.args.noise_threshold)
+        out = []
+        for k, cls in enumerate(classes):
+            rows = range(len(ds_idx)) if pools[k] is None else pools[k]
+            pool_idx = [ds_idx[r] for r in rows]
+            if pools[k] is None:
+                self._log_similarity(rnd, cls, pool_idx, lambda k=k: sims[k])
+            else:
+                self._log_similarity(rnd, cls, pool_idx, lambda k=k, rows=rows: sims[k].index_select(
+                    0, torch.as_tensor(list(rows), device=eng.device, dtype=torch.long)))
+            top, bot = picks[k]
+            if not len(top):
+                # the reference's first branch tests the CLEAN list twice (`len(max_m_indices_list) == 0 and
+                # len(max_m_indices_list) == 0`, :1076 / :1099): without a clean pick it keeps no noise pick either
+                bot = []
+            out.append(([int(pool_idx[j]) for j in top], [int(pool_idx[j]) for j in bot]))
+        return out
+
     def _select(self, eng, rnd, cls, pool_f, pool_idx, proto_dev):
         """-> (clean, noise): dataset indices of the int(clean_threshold * #(sim >= 0)) most similar and the
         int(noise_threshold * #(sim < 0)) least similar pool samples (stable ranks, utils/utils.py:24-35)"""
@@ -428,15 +456,11 @@ class LocalUpdate(object):
         proto_dev = torch.as_tensor(np.asarray(Prototype, dtype=np.float32)).to(eng.device).contiguous()
         # (b)+(c) cosine tagging and stable top-/bottom-k selection per missing class (:1052-1112)
         where = {v: j for j, v in enumerate(ds_idx)}
+        pools = [None if first else [where[v] for v in self.idxss[k]]      # find_indices_in_a :901-902
+                 for k in range(len(negetive_class_list))]
+        picked = self._select_all(eng, rnd, list(negetive_class_list), f, ds_idx, pools, proto_dev)
         for k, cls in enumerate(negetive_class_list):
-            if first:
-                pool_f, pool_idx = f, ds_idx
-            else:
-                rows = [where[v] for v in self.idxss[k]]                   # find_indices_in_a :901-902
-                pool_idx = [ds_idx[r] for r in rows]
-                pool_f = f.index_select(0, torch.as_tensor(rows, device=eng.device, dtype=torch.long)) \
-                    if rows else f[:0]
-            clean, noise = self._select(eng, rnd, cls, pool_f, pool_idx, proto_dev)
+            clean, noise = picked[k]
             if first:
                 self.traindata_idx += [clean, noise]
             else:

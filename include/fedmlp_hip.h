@@ -207,6 +207,14 @@ int fm_cos_tag(fm_engine* e, const float* feat_dev, int64_t N, const float* prot
 int fm_select_topk(fm_engine* e, const float* sim_dev, int64_t N, double clean_thr,
                    double noise_thr, int32_t cap, int32_t* top_host, int32_t* n_top,
                    int32_t* bot_host, int32_t* n_bot);
+/* The same selection for EVERY missing class of a round (the loop of utils/local_training.py:1052-1112) in one launch pair
+ * and one device-to-host read.  sim_dev [n_cls][N] (fm_cos_tag's output); class k's pool = the pool_n_host[k] positions
+ * pool_rows_host[k*stride ..] of its similarity row, in pool order (find_indices_in_a, :901-902; ties go to the earlier pool
+ * position), or all N rows when pool_rows_host is NULL.  Writes pool POSITIONS: top_host / bot_host [n_cls][cap],
+ * n_top / n_bot [n_cls]. */
+int fm_select_topk_rows(fm_engine* e, const float* sim_dev, int64_t N, int32_t n_cls, const int32_t* pool_rows_host,
+                        const int32_t* pool_n_host, int32_t stride, double clean_thr, double noise_thr, int32_t cap,
+                        int32_t* top_host, int32_t* n_top, int32_t* bot_host, int32_t* n_bot);
 
 /* ---- HBM-resident input pipeline --------------------------- */
 /* Train transform of dataset/dataset.py:40-53 on a uint8 cache of already-resized images

@@ -176,10 +176,8 @@ def replay_local_update():
                 return o
             return super()._order(n)
 
-        def _similarity(self, eng, rnd, cls, pool_f, pool_idx, proto_dev):
-            sim = super()._similarity(eng, rnd, cls, pool_f, pool_idx, proto_dev)
-            self.tagging_log.append({"rnd": rnd, "cls": cls, "pool_idx": list(pool_idx), "sim": sim.cpu().numpy()})
-            return sim
+        def _log_similarity(self, rnd, cls, pool_idx, sim_of_pool):
+            self.tagging_log.append({"rnd": rnd, "cls": cls, "pool_idx": list(pool_idx), "sim": sim_of_pool().cpu().numpy()})
 
     return ReplayLocalUpdate
 

@@ -219,3 +219,23 @@ def test_fedavg_fold_of_eight_clients_into_the_engine_state(eng):
     assert torch.equal(z1, z2) and torch.equal(f1, f2)
     with pytest.raises(Exception):
         eng.fedavg_fold(states * 3, lens * 3)             # K > 16
+
+
+def test_select_topk_rows_matches_per_class_selection(eng):
+    """fm_select_topk_rows (every class of a round in one launch pair, one device-to-host read) returns, class by class, exactly
+    what fm_select_topk returns on that class's pool: whole rows and sub-pools in arbitrary pool order, heavy ties, a NaN row
+    (a class nobody annotates: no pick), an empty pool."""
+    rng = np.random.RandomState(5)
+    N, n_cls = 777, 6
+    sims = np.round(rng.randn(n_cls, N).astype(np.float32), 1)          # one decimal: many exact ties
+    sims[3] = np.nan
+    sims_d = torch.from_numpy(sims).to(eng.device)
+    pools = [None, list(rng.permutation(N)[:300]), list(rng.permutation(N)[:41]), None, [], list(range(N - 1, -1, -1))]
+    for ct, nt in ((0.005, 0.01), (0.3, 0.5), (1.0, 1.0)):
+        got = eng.select_topk_rows(sims_d, pools, ct, nt)
+        assert len(got) == n_cls
+        for k in range(n_cls):
+            rows = list(range(N)) if pools[k] is None else [int(r) for r in pools[k]]
+            want = eng.select_topk(torch.from_numpy(sims[k][rows]).to(eng.device).contiguous(), ct, nt) if rows else ([], [])
+            assert got[k] == want, (k, ct, nt)
+    assert eng.select_topk_rows(sims_d[:0], [], 0.5, 0.5) == []

@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 : > gpurun_out/mfma_busy.txt
-for sp in 6 0; do
+for sp in 6; do
   O=gpurun_out/mfma_busy_$sp; rm -rf $O; mkdir -p $O
   FM_MFMA_SPLIT=$sp rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/prof -- python3 tools/probe_conv.py 1024 $CI 0 > $O/log.txt 2>&1
   python3 - $O $sp >> gpurun_out/mfma_busy.txt <<'PY'
@@ -18,7 +18,7 @@ t = glob.glob(O + '/prof/**/*kernel_trace.csv', recursive=True)[0]
 dur = {r['Dispatch_Id']: (int(r['End_Timestamp']) - int(r['Start_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(t))}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
-    if 'igemm' in r['Kernel_Name']:
+    if 'igemm' in r['Kernel_Name'] or 'pconv' in r['Kernel_Name']:
         agg[r['Dispatch_Id']][r['Counter_Name']] += float(r['Counter_Value'])
 for d, c in list(agg.items())[-3:]:
     ns, name = dur[d]
