@@ -90,6 +90,7 @@ SYMBOLS = {
     "fm_debug_exp_bwd": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _P, _P]),
     "fm_debug_get_grads": (C.c_int, [_P, _P]),
     "fm_debug_activation": (C.c_int, [_P, _I32, _I32, _I32, _P, C.POINTER(_I32)]),
+    "fm_debug_stem_masks": (C.c_int, [_P, _I32, _I32, _P, _P]),
 }
 
 _lib = None

@@ -441,6 +441,28 @@ void k_bn_apply(const float* y, const float* scale, const float* shift, const fl
                        pix_per_group, C, relu);
 }
 
+// test hook (fm_debug_stem_masks): the ReLU mask of the dense stem map, with the fused multiply-add stem_pool_kernel uses
+__global__ void stem_relu_bits_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                      uint8_t* __restrict__ bits, int64_t pix_per_group, int C)
+{
+    const int g = blockIdx.y, BQ = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pix_per_group * BQ) return;
+    const int b = (int)(i % BQ);
+    const int64_t pix = (int64_t)g * pix_per_group + i / BQ;
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        m |= (__builtin_fmaf(y[pix * C + 8 * b + j], scale[g * C + 8 * b + j], shift[g * C + 8 * b + j]) > 0.f ? 1u : 0u) << j;
+    bits[pix * BQ + b] = (uint8_t)m;
+}
+void k_stem_relu_bits(const float* y, const float* scale, const float* shift, uint8_t* bits, int groups, int64_t pix_per_group, int C,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(stem_relu_bits_kernel, dim3(cdiv(pix_per_group * (C / 8), 256), groups), dim3(256), 0, s, y, scale, shift, bits,
+                       pix_per_group, C);
+}
+
 // ------------------------------------------------------------ stem pool --------
 __global__ void stem_pool_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                  const float* __restrict__ shift, float* __restrict__ pooled,

@@ -2766,6 +2766,28 @@ int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs,
     return FM_OK;
 }
 
+int fm_debug_stem_masks(fm_engine* e, int32_t imgs, int32_t groups, uint8_t* relu_bits_host, uint8_t* argmax_host)
+{
+    ARGCHK(e && e->model == 0 && !e->precision, "ResNet-18 engine only");
+    ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs / groups");
+    const Conv& c0 = e->convs[0];
+    const int64_t pix = (int64_t)imgs * c0.hout * c0.wout;
+    if (relu_bits_host) {
+        uint8_t* bits = nullptr;
+        HIPCHK(hipMalloc(&bits, (size_t)pix * 8));
+        k_stem_relu_bits(c0.y, e->bns[0].scale, e->bns[0].shift, bits, groups, pix / groups, 64, e->st);
+        hipError_t rc = hipMemcpyAsync(relu_bits_host, bits, (size_t)pix * 8, hipMemcpyDeviceToHost, e->st);
+        if (rc == hipSuccess) rc = hipStreamSynchronize(e->st);
+        (void)hipFree(bits);
+        HIPCHK(rc);
+    }
+    if (argmax_host) {
+        HIPCHK(hipMemcpyAsync(argmax_host, e->idx0, (size_t)imgs * (c0.hout / 2) * (c0.wout / 2) * 64, hipMemcpyDeviceToHost, e->st));
+        HIPCHK(hipStreamSynchronize(e->st));
+    }
+    return FM_OK;
+}
+
 int fm_debug_conv_info(fm_engine* e, int32_t conv, int32_t* info16)
 {
     ARGCHK(e && info16 && conv >= 0 && conv < (int)e->convs.size(), "conv index");

@@ -90,6 +90,9 @@ void k_stem_pool_bwd(const float* dpooled, const float* pooled, const uint8_t* i
 // stem: max-pool backward + BatchNorm backward without the dense 112x112 intermediate.  reduce: the two BN-backward sums over the
 // pooled positions (each window's gradient at its argmax, ReLU mask = pooled > 0) -> part[groups][stem_pool_bn_blocks()][2][C];
 // apply: dy[dense] = ca * (sum of the window gradients that chose this position) + cb * y + cc
+// test hook: bit-packed ReLU mask of the dense stem map, bits[pix][C/8] (bit j of byte b = y*scale+shift > 0 of channel 8b + j)
+void k_stem_relu_bits(const float* y, const float* scale, const float* shift, uint8_t* bits, int groups, int64_t pix_per_group, int C,
+                      hipStream_t s);
 int stem_pool_bn_blocks(int pooled_per_group);
 void k_stem_pool_bn_reduce(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* mean,
                            const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);

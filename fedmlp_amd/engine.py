@@ -375,6 +375,16 @@ class Engine:
         keys = ("cin", "cout", "k", "stride", "pad", "hin", "win", "hout", "wout", "cin_p", "Kw", "kw_p", "cout_p")
         return dict(zip(keys, list(info)))
 
+    def debug_stem_masks(self, imgs, groups):
+        """(relu mask [imgs, H/2, W/2, 64] bool, max-pool argmax code [imgs, H/4, W/4, 64] uint8) of the last train-mode forward's
+        stem (fm_debug_stem_masks)"""
+        H2, W2 = self.in_h // 2, self.in_w // 2
+        bits = np.empty((imgs, H2, W2, 8), np.uint8)
+        code = np.empty((imgs, H2 // 2, W2 // 2, 64), np.uint8)
+        _lib.check(self.lib.fm_debug_stem_masks(self.h, imgs, groups, bits.ctypes.data_as(C.c_void_p),
+                                                code.ctypes.data_as(C.c_void_p)))
+        return np.unpackbits(bits, axis=-1, bitorder="little").astype(bool), code
+
     def debug_get_grads(self):
         flat = np.empty(self.nf, np.float32)
         _lib.check(self.lib.fm_debug_get_grads(self.h, flat.ctypes.data_as(C.c_void_p)))

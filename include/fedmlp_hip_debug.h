@@ -66,6 +66,13 @@ int fm_debug_exp_bwd(fm_engine* e, int32_t conv, const void* da_dev, const void*
 int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs, float* host_nhwc,
                         int32_t* dims4);
 
+/* The discrete decisions of the ResNet-18 stem in the last train-mode forward, for the same purpose: the ReLU mask of
+ * relu(bn1(conv1(x))) over the dense [imgs][H/2][W/2][64] map, bit-packed (byte b of a pixel = channels 8b .. 8b+7, bit j =
+ * channel 8b + j: relu_bits_host [imgs][H/2][W/2][8]), and the 3x3 / stride-2 max-pool's choice per pooled element
+ * (argmax_host [imgs][H/4][W/4][64], code kh * 3 + kw of the chosen window position).  groups = the views of that forward
+ * (BatchNorm statistics are per view). */
+int fm_debug_stem_masks(fm_engine* e, int32_t imgs, int32_t groups, uint8_t* relu_bits_host, uint8_t* argmax_host);
+
 /* Gradients of the last step in state_dict order (running-stat slots are 0). */
 int fm_debug_get_grads(fm_engine* e, float* host_f32);
 

@@ -74,6 +74,24 @@ class _MaskedReLU(torch.autograd.Function):
         return g * mask, None
 
 
+class _RoutedPool(torch.autograd.Function):
+    """max-pool whose forward values are the oracle's own and whose backward sends each gradient to a given input position"""
+
+    @staticmethod
+    def forward(ctx, x, idx, vals):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return vals.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        Bn, Cn, H, W = ctx.shape
+        gin = torch.zeros((Bn, Cn, H * W), dtype=g.dtype)
+        gin.scatter_add_(2, idx.reshape(Bn, Cn, -1), g.reshape(Bn, Cn, -1))
+        return gin.view(ctx.shape), None, None
+
+
 class relu_masks_from_engine:
     """Context manager: the oracle ResNet's backward pass uses the ENGINE's ReLU masks.
 
@@ -87,22 +105,53 @@ class relu_masks_from_engine:
     mask differs from the oracle's own is recorded in `.flips` (it must stay tiny).
 
     Call order inside the oracle (oracle/resnet18_ref.py): per forward pass the stem ReLU, then for each
-    of the 8 basic blocks relu(bn1) and the output ReLU; views are forwarded one after the other."""
+    of the 8 basic blocks relu(bn1) and the output ReLU; views are forwarded one after the other.
 
-    def __init__(self, eng, n_views, B):
+    stem=True also hands over the stem's two discrete decisions (fm_debug_stem_masks): the ReLU mask of relu(bn1(conv1(x))) and
+    the 3x3 max-pool's choice per pooled element -- the oracle's max-pool forward keeps its own values, its backward routes each
+    gradient to the position the ENGINE chose (`.pool_flips` counts the differing choices)."""
+
+    def __init__(self, eng, n_views, B, stem=False):
         self.masks = []
+        self.pool_codes = []
+        stem_m = stem_c = None
+        if stem:
+            stem_m, stem_c = eng.debug_stem_masks(n_views * B, n_views)
         for v in range(n_views):
-            self.masks.append(None)                                    # stem: its own mask (6144+ values per channel)
+            if stem:                                                   # NHWC -> the oracle's NCHW
+                self.masks.append(torch.from_numpy(np.ascontiguousarray(stem_m[v * B:(v + 1) * B].transpose(0, 3, 1, 2))))
+                self.pool_codes.append(torch.from_numpy(np.ascontiguousarray(stem_c[v * B:(v + 1) * B].transpose(0, 3, 1, 2))))
+            else:
+                self.masks.append(None)                                # stem: its own mask (6144+ values per channel)
             for blk in range(8):
                 for kind in (0, 1):
                     a = eng.debug_activation(kind, blk, n_views * B)[v * B:(v + 1) * B]
                     self.masks.append(torch.from_numpy(a > 0))
         self.flips = 0
         self.calls = 0
+        self.pool_flips = 0
+        self.pool_calls = 0
 
     def __enter__(self):
         import torch.nn.functional as F
         self._F, self._orig = F, F.relu
+        self._orig_pool = F.max_pool2d
+
+        def max_pool2d(x, *a, **k):
+            j = self.pool_calls
+            self.pool_calls += 1
+            if j >= len(self.pool_codes) or not x.requires_grad:
+                return self._orig_pool(x, *a, **k)
+            code = self.pool_codes[j].long()                           # kh * 3 + kw of the 3x3 / stride-2 / pad-1 window
+            Bn, Cn, H, W = x.shape
+            Hp, Wp = code.shape[2], code.shape[3]
+            oh = torch.arange(Hp).view(1, 1, Hp, 1)
+            ow = torch.arange(Wp).view(1, 1, 1, Wp)
+            idx = (2 * oh - 1 + code // 3) * W + (2 * ow - 1 + code % 3)
+            own_vals, own_idx = self._orig_pool(x.detach(), 3, 2, 1, return_indices=True)
+            self.pool_flips += int((own_idx != idx).sum())
+            return _RoutedPool.apply(x, idx, own_vals)
+        F.max_pool2d = max_pool2d
 
         def relu(x, *a, **k):
             j = self.calls
@@ -118,6 +167,7 @@ class relu_masks_from_engine:
 
     def __exit__(self, *exc):
         self._F.relu = self._orig
+        self._F.max_pool2d = self._orig_pool
         return False
 
 
