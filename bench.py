@@ -104,7 +104,7 @@ PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (
 EFFNET_FWD_BYTES = {"fp32": 73.8e6, "bf16": 36.9e6}
 RESNET_FWD_FLOP = 3.627e9             # 2 x 1 813 561 344 conv MACs per 224x224 image
 STEP_FLOP = {"stage1": 28.55e9, "train": 10.65e9, "stage2": 10.65e9}    # SURVEY.md 8(d), per sample
-PMC_FILES = [os.path.join("profiles", r, "pmc_traffic.json") for r in ("r04", "r03", "r02")]
+PMC_FILES = [os.path.join("profiles", r, "pmc_traffic.json") for r in ("r05", "r04", "r03", "r02")]
 METRIC = "images/sec/client (ICH 224x224 bs=128) at 1/2/4/8 GPUs; mAP vs ref"
 
 

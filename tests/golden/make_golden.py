@@ -52,7 +52,11 @@ from fedmlp_amd import spec                # noqa: E402
 from oracle.resnet18_ref import ResNet18Ref  # noqa: E402
 from tests.synth import synth_arrays, class_lists, perturbed_bn  # noqa: E402
 
-torch.set_num_threads(8)
+# GOLDEN_THREADS / GOLDEN_MKLDNN=0: the same reference runs under another fp32 summation order (thread count of the reductions,
+# oneDNN vs native convolution kernels) -- tests/golden/oracle_bands.py measures how far the REFERENCE moves from itself
+torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+if os.environ.get("GOLDEN_MKLDNN", "1") == "0":
+    torch.backends.mkldnn.enabled = False
 torch.use_deterministic_algorithms(True)
 
 ORDERS = []       # queue of explicit orders for shuffle=True loaders
@@ -569,6 +573,9 @@ def g_step_full_variants(out):
     rec["train"] = {"data_seed": 62, "loss": float(ret[1]), "grads": _grad_record(work), "norms": tensor_norms(ret[0]),
                     "loss_w": [float(v) for v in loc.loss_w]}
     print("train done", flush=True)
+    if os.environ.get("GOLDEN_ONLY_TRAIN") == "1":       # oracle_bands.py: the `train` record only
+        json.dump(rec, open(os.path.join(out, "step_full_variants.json"), "w"), indent=1)
+        return
     # ---- FixMatch ------------------------------------------------------------------------------
     ds2 = SynthDataset(N, C, hw, 63, True)
     pos, neg = class_lists(ds2.targets, C)
