@@ -60,14 +60,22 @@ template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3
 // steps ahead).  Instantiated: <4, 4, 2> = 128 x 256 (M >= 128) and <2, 4, 2> = 64 x 256 for the 64-channel layers.  Measured and not
 // kept for those: <2, 3, 3> = 64 x 192 with three stages (two steps of DMA lookahead): 315 vs 294 us per 56 x 56 x 64 layer at 256
 // images -- the layer is bound by LDS traffic per MFMA (every B row serves 64 output channels only), not by DMA latency
-template <int FR, int FC, int NS, int SP>
+// TS ("tap rows shared", 3x3 / stride 1): the three taps of a kernel ROW read the same input pixels shifted by one, so the B stage is
+// loaded ONCE per (channel block, kernel row) as the tile's pixels plus one halo pixel on either side ([3 planes][BN + 2 -> 272
+// rows][64 B], two slots), and the tap's column shift is a row offset of the fragment reads (conflict-free at every offset,
+// brute-force checked); a pixel whose shifted neighbour lies in another image row reads a zero (a select on the fragment
+// registers).  B traffic into LDS per K-step: 48 KB -> 17 KB.
+template <int FR, int FC, int NS, int SP, bool TS = false>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__
     constexpr int WN = 4;
     constexpr int BM = 32 * FR, BN = 64 * FC;
-    constexpr int SA = 3 * BM * 64, SB = 3 * BN * 64;          // bytes per stage
-    constexpr int GA = BM / 16, GB = BN / 16;                  // 16-row groups per operand tile
+    constexpr int GA = BM / 16, GB = TS ? (BN + 2 + 15) / 16 : BN / 16;       // 16-row groups per operand stage (TS: + the two halo rows)
+    constexpr int BROWS = 16 * GB;                             // rows of a B stage plane
+    constexpr int SA = 3 * BM * 64, SB = 3 * BROWS * 64;       // bytes per stage
+    constexpr int NSB = TS ? 2 : NS;                           // B slots (TS: one per kernel row, two in flight)
+    static_assert(!TS || (NS == 2 && FC == 4), "tap-row sharing: two stages, 256-pixel tiles");
     constexpr int JA = (3 * GA + 7) / 8;                       // A DMA instructions per wave per stage (waves past 3 GA - 8 (JA - 1): one fewer)
     constexpr int RGB = (GB + 7) / 8;                          // B row groups per wave (wave + 8 i < GB), each x 3 planes
     static_assert(NS == 2 || NS == 3, "two or three LDS stages");
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)smem;              // LDS byte address of the dynamic segment
-    const unsigned As = lds0, Bs = lds0 + NS * SA;             // [NS][3][BM][64], [NS][3][BN][64]
+    const unsigned As = lds0, Bs = lds0 + NS * SA;             // [NS][3][BM][64], [NSB][3][BROWS][64]
 
     const int nsteps = p.nsteps;                               // K-steps of 32: (channel block, tap), tap-minor
     const int ntaps = p.ntaps;
@@ -108,18 +116,25 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const unsigned fro = li * 64 + ((lg ^ ((li >> 1) & 3)) << 4);
     const unsigned Af0 = As + wm * (16 * FR) * 64 + fro;
     const unsigned Bf0 = Bs + wn * (16 * FC) * 64 + fro;
+    // TS: the fragment row of output pixel (c, li) under column shift dw = d - 1 is stage row 1 + dw + 16 c + li (+ 64 wn)
+    unsigned Bfd[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) Bfd[d] = Bs + wn * (16 * FC) * 64 + (li + d) * 64 + ((lg ^ (((li + d) >> 1) & 3)) << 4);
     // DMA instructions this wave issues per K-step (A jobs + 3 planes x its B row groups): the counted vmcnt of NS = 3
     const int ngrpB = (wave + 8 * (RGB - 1) < GB) ? RGB : RGB - 1;
     constexpr int NW_HI = JA + 3 * RGB;                                            // waves that hold the full share
     constexpr int NW_LO = ((3 * GA) % 8 ? JA - 1 : JA) + 3 * (GB % 8 ? RGB - 1 : RGB);   // waves 4 .. 7 when the job counts are odd multiples of 4
-    static_assert(NS == 2 || ((3 * GA) % 8 == 0 || (3 * GA) % 8 == 4) && (GB % 8 == 0 || GB % 8 == 4), "job split by wave < 4");
+    static_assert(NS == 2 || (((3 * GA) % 8 == 0 || (3 * GA) % 8 == 4) && (GB % 8 == 0 || GB % 8 == 4)), "job split by wave < 4");
+    // TS: kernel-row offset and column shifts from the tap table: taps 3 j .. 3 j + 2 share dh; d = dw + 1 of tap t
+    auto tap_d = [&](int t) { return (int)((unsigned)(p.tapcode >> (4 * t + 2)) & 3u); };
 
     // A segment = the K-steps [k0, k1) of one tile that this block's range covers, with the per-lane DMA state of the tile
     struct Seg {
         int tile, k0, k1, grp, tn, m0, n0;
         bool first;                              // the block's first segment (slab slot 0)
         unsigned voffA, voffB[RGB], vmask[RGB];
-        int icc_b, it_b;                         // (channel block, tap) cursor of the next B step to be issued
+        int icc_b, it_b;                         // (channel block, tap) cursor of the next B step to be issued (TS: it_b = kernel row)
+        unsigned cmask;                          // TS: bit 2c = the pixel of column tile c has a left neighbour in its image row, 2c + 1 = a right one
     };
     auto decode = [&](Seg& g) {                  // takes the next segment off the block's range [w, wend)
         g.tile = (int)(w / nsteps);
@@ -137,24 +152,48 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         // B: row group gi = wave + 8 i holds output pixels n0 + 16 gi + drow of the group's virtual grid
 #pragma unroll
         for (int i = 0; i < RGB; ++i) {
-            const int n = g.n0 + 16 * (wave + 8 * i) + drow;
-            const bool rv = n < npix && i < ngrpB;
+            // TS: stage row r holds pixel n0 - 1 + r (one halo pixel on either side of the tile)
+            const int n = g.n0 + 16 * (wave + 8 * i) + drow - (TS ? 1 : 0);
+            const bool rv = n >= 0 && n < npix && i < ngrpB;
             const int nn = rv ? n : 0;
             const int img = nn / HWg, rem = nn - img * HWg;
             const int hg = rem / p.Wg, wg = rem - hg * p.Wg;
             const int ih0 = hg * p.sg, iw0 = wg * p.sg;
             unsigned vm = 0;
+            if constexpr (TS) {
+                // bit j: the pixel's row under kernel row j (dh of tap 3 j) stays inside the image
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const unsigned f = (unsigned)(p.tapcode >> (4 * t)) & 15u;
-                const int ih = ih0 + (int)(f & 3u) - 1, iw = iw0 + (int)(f >> 2) - 1;
-                if (t < ntaps && rv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)Wi) vm |= 1u << t;
+                for (int j = 0; j < 3; ++j) {
+                    const int ih = ih0 + (int)((unsigned)(p.tapcode >> (12 * j)) & 3u) - 1;
+                    if (rv && (unsigned)ih < (unsigned)p.Hi) vm |= 1u << j;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const unsigned f = (unsigned)(p.tapcode >> (4 * t)) & 15u;
+                    const int ih = ih0 + (int)(f & 3u) - 1, iw = iw0 + (int)(f >> 2) - 1;
+                    if (t < ntaps && rv && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)Wi) vm |= 1u << t;
+                }
             }
             g.vmask[i] = vm;
             g.voffB[i] = (unsigned)((((g.grp * p.imgs_per_group + img) * p.Hi + ih0) * Wi + iw0) * 64 + chunk * 16);
         }
-        g.icc_b = g.k0 / ntaps;
-        g.it_b = g.k0 - g.icc_b * ntaps;
+        if constexpr (TS) {
+            g.icc_b = g.k0 / 9;
+            g.it_b = (g.k0 - g.icc_b * 9) / 3;
+            unsigned cm = 0;
+#pragma unroll
+            for (int c = 0; c < FC; ++c) {
+                const int n = g.n0 + wn * (16 * FC) + 16 * c + li;
+                const int wg = n % p.Wg;
+                cm |= (wg > 0 ? 1u : 0u) << (2 * c);
+                cm |= (wg < p.Wg - 1 ? 1u : 0u) << (2 * c + 1);
+            }
+            g.cmask = cm;
+        } else {
+            g.icc_b = g.k0 / ntaps;
+            g.it_b = g.k0 - g.icc_b * ntaps;
+        }
     };
     auto issueA = [&](const Seg& g, int s, int slot) {
 #pragma unroll
@@ -168,6 +207,24 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     };
     // B steps are issued strictly in order k0, k0 + 1, ...: the (channel block, tap) cursor advances with them
     auto issueB = [&](Seg& g, int slot) {
+        if constexpr (TS) {
+            // one kernel row (channel block icc_b, row it_b) of the tile: pixels n0 - 1 .. n0 + BN shifted by dh rows
+            const unsigned dh1 = (unsigned)(p.tapcode >> (12 * g.it_b)) & 3u;          // dh + 1
+            const unsigned tapo = (dh1 * (unsigned)Wi + 1u) * 64u;                      // (dh + 1) * Wi + (0 + 1) pixels
+#pragma unroll
+            for (int i = 0; i < RGB; ++i) {
+                if (GB % 8 != 0 && i >= ngrpB) break;
+                const unsigned vo = ((g.vmask[i] >> g.it_b) & 1u) ? g.voffB[i] : OOB;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned so = (unsigned)((size_t)(g.icc_b * 3 + pl) * p.xp_pix * 64) + tapo;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(size_t)(Bs + slot * SB + (pl * GB + wave + 8 * i) * 1024), 16,
+                                                             vo, so, 0, 0);
+                }
+            }
+            if (++g.it_b == 3) { g.it_b = 0; ++g.icc_b; }
+            return;
+        }
         const unsigned f = (unsigned)(p.tapcode >> (4 * g.it_b)) & 15u;
         const unsigned tapo = ((f & 3u) * (unsigned)Wi + (f >> 2)) * 64u;           // (dh + 1) * Wi + (dw + 1) pixels
 #pragma unroll
@@ -203,7 +260,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         for (int r = 0; r < FR; ++r)
 #pragma unroll
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sp_u32x4 A0[FR][3], A1[FR][3], Bb[2][3];
+        // D2 (FR == 2: a column is only 12 MFMAs): the B fragments are read TWO columns ahead into one buffer per column
+        constexpr bool D2 = FR == 2 && FC == 4;
+        sp_u32x4 A0[FR][3], A1[FR][3], Bb[D2 ? 4 : 2][3];
     // BASE = the fragment base address of the stage slot the read takes (Af0 + slot * SA, Bf0 + slot * SB)
 #define PC_READA(BASE, R, DST)                                                                  \
     {                                                                                           \
@@ -213,9 +272,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     }
 #define PC_READB(BASE, C, DST)                                                                  \
     {                                                                                           \
-        DST[0] = pc_lds_read128<(0 * BN + 16 * (C)) * 64>(BASE);                                \
-        DST[1] = pc_lds_read128<(1 * BN + 16 * (C)) * 64>(BASE);                                \
-        DST[2] = pc_lds_read128<(2 * BN + 16 * (C)) * 64>(BASE);                                \
+        DST[0] = pc_lds_read128<(0 * BROWS + 16 * (C)) * 64>(BASE);                             \
+        DST[1] = pc_lds_read128<(1 * BROWS + 16 * (C)) * 64>(BASE);                             \
+        DST[2] = pc_lds_read128<(2 * BROWS + 16 * (C)) * 64>(BASE);                             \
     }
     // the rolling B buffers: column c of a step of register parity PAR sits in Bb[(c + PAR * FC) & 1] (odd FC: the parity of the
     // first column alternates from step to step, so the next step's column 0 never lands on the column still in use)
@@ -229,7 +288,35 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment's lead DMA: A(k0), B(k0), A(k0 + 1)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (k0 + 1 < k1) issueB(cur, 1);
+        // TS: kernel rows (super-steps of three taps) U = s / 3; this segment covers U0 .. U1; B slot of U = (U - U0) & 1
+        int it_cur = 0, Ucur = 0, ub = 0;
+        bool b_young = false;                  // TS: the youngest DMA group is a B row (issued AFTER the previous step's A stage)
+        // TS: wait for everything but the B row issued last (it is needed two steps later): 3 planes x this wave's row groups
+        auto wait_dma = [&]() {
+            if (TS && b_young) {
+                if (ngrpB == RGB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * RGB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (RGB - 1)) : "memory");
+            } else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const int U1 = (k1 - 1) / 3;
+        auto bsel = [&](int d) { return d == 0 ? Bfd[0] : (d == 1 ? Bfd[1] : Bfd[2]); };
+        // a fragment column whose pixels' shifted neighbours lie in another image row reads zeros (d = dw + 1 of the step's tap)
+        auto maskB = [&](sp_u32x4 (&b)[3], int c, int d) {
+            if (d != 1) {
+                const bool ok = (cur.cmask >> (2 * c + (d == 2 ? 1 : 0))) & 1u;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b[pl][i] = ok ? b[pl][i] : 0u;
+            }
+        };
+        if constexpr (TS) {
+            it_cur = k0 % 9; Ucur = k0 / 3;
+            if (Ucur + 1 <= U1) issueB(cur, 1);
+        } else {
+            if (k0 + 1 < k1) issueB(cur, 1);
+        }
         if constexpr (NS == 3) {
             if (k0 + 2 < k1) issueA(cur, k0 + 2, 2);
             if (k0 + 2 < k1) issueB(cur, 2);
@@ -237,8 +324,18 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         PC_READA(Af0, 0, A0[0]);
         PC_READA(Af0, 1, A0[1]);
         if constexpr (FR == 4) { PC_READA(Af0, 2, A0[2]); PC_READA(Af0, 3, A0[3]); }
-        PC_READB(Bf0, 0, Bb[0]);
+        if constexpr (TS) {
+            const unsigned b0 = bsel(tap_d(it_cur));
+            PC_READB(b0, 0, Bb[0]);
+        } else
+            PC_READB(Bf0, 0, Bb[0]);
+        if constexpr (D2) {
+            if constexpr (TS) { const unsigned b0 = bsel(tap_d(it_cur)); PC_READB(b0, 1, Bb[1]); }
+            else PC_READB(Bf0, 1, Bb[1]);
+        }
         PC_LGKM0();
+        if constexpr (TS) maskB(Bb[0], 0, tap_d(it_cur));
+        if constexpr (TS && D2) maskB(Bb[1], 1, tap_d(it_cur));
         __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + NS)
         asm volatile("" ::: "memory");
         if (k0 + NS < k1) issueA(cur, k0 + NS, 0);
@@ -250,7 +347,63 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             constexpr int PAR = decltype(par_c)::value;
             constexpr bool FULL = decltype(full_c)::value;
             const int ib1 = (ib + 1 == NS) ? 0 : ib + 1;
-            const unsigned b_cur = Bf0 + ib * SB, b_nxt = Bf0 + ib1 * SB, a_nxt = Af0 + ib1 * SA;
+            const unsigned a_nxt = Af0 + ib1 * SA;
+            unsigned b_cur, b_nxt;
+            int d_cur = 1, d_nxt = 1;                // TS: dw + 1 of this step's / the next step's tap
+            bool row_end = false;                    // TS: this step is the last of its kernel row
+            if constexpr (TS) {
+                const int it1 = it_cur == 8 ? 0 : it_cur + 1;
+                d_cur = tap_d(it_cur); d_nxt = tap_d(it1);
+                row_end = it_cur == 2 || it_cur == 5 || it_cur == 8;
+                b_cur = bsel(d_cur) + ub * SB;
+                b_nxt = bsel(d_nxt) + (row_end ? ub ^ 1 : ub) * SB;
+            } else {
+                b_cur = Bf0 + ib * SB; b_nxt = Bf0 + ib1 * SB;
+            }
+            if constexpr (D2) {
+                // B fragments two columns ahead: Bb[c] = column c.  At the start of a step columns 0 and 1 are in registers (read
+                // during the previous step's columns 2, 3); columns 2, 3 and the next step's A fragments are read behind the
+                // MFMAs of columns 0, 1 (24 MFMAs of cover instead of 12).  The barrier sits before column 2: by then all of this
+                // stage's B columns and the next step's A fragments are in registers.
+                const bool more = FULL || s + 1 < k1;
+                if (more) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }
+                PC_READB(b_cur, 2, Bb[2]);
+                PC_READB(b_cur, 3, Bb[3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < FR; ++r) acc[r][0] = pc_mfma<SP>(Ac[r], Bb[0], acc[r][0]);
+#pragma unroll
+                for (int r = 0; r < FR; ++r) acc[r][1] = pc_mfma<SP>(Ac[r], Bb[1], acc[r][1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_dma();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (TS) { maskB(Bb[2], 2, d_cur); maskB(Bb[3], 3, d_cur); }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (more) { PC_READB(b_nxt, 0, Bb[0]); PC_READB(b_nxt, 1, Bb[1]); }
+                if constexpr (TS) {
+                    // A first, then the B row: the next barrier waits for the A stage only and leaves the row in flight
+                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                    b_young = row_end && Ucur + 2 <= U1;
+                    if (b_young) issueB(cur, ub);
+                } else {
+                    if (FULL || s + NS < k1) issueB(cur, ib);
+                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < FR; ++r) acc[r][2] = pc_mfma<SP>(Ac[r], Bb[2], acc[r][2]);
+#pragma unroll
+                for (int r = 0; r < FR; ++r) acc[r][3] = pc_mfma<SP>(Ac[r], Bb[3], acc[r][3]);
+                PC_LGKM0();
+                if constexpr (TS) {
+                    if (more) { maskB(Bb[0], 0, d_nxt); maskB(Bb[1], 1, d_nxt); }
+                    if (row_end) { ub ^= 1; ++Ucur; }
+                    it_cur = it_cur == 8 ? 0 : it_cur + 1;
+                }
+                ib = ib1;
+                return;
+            }
             // columns 0 .. FC - 2: the next column's B fragments and a share of the next step's A fragments go out at the head
             // of the column's MFMAs and are waited for at its end
 #define PC_COLUMN(C)                                                                                             \
@@ -272,6 +425,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[PC_BI(C, PAR)], acc[r][C]); \
                 PC_LGKM0();                                                                                      \
+                if constexpr (TS) maskB(Bb[PC_BI((C) + 1, PAR)], (C) + 1, d_cur);                                \
             }
             PC_COLUMN(0)
             PC_COLUMN(1)
@@ -285,15 +439,28 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_LO) : "memory");
             } else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wait_dma();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (FULL || s + 1 < k1) PC_READB(b_nxt, 0, Bb[PC_BI(0, PAR ^ 1)]);
-            if (FULL || s + NS < k1) issueB(cur, ib);
-            if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+            if constexpr (TS) {
+                // the last tap of a kernel row has consumed its B slot: it takes the row after next.  A first, then the B row: the
+                // next barrier waits for the A stage only and leaves the row in flight
+                if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                b_young = row_end && Ucur + 2 <= U1;
+                if (b_young) issueB(cur, ub);
+            } else {
+                if (FULL || s + NS < k1) issueB(cur, ib);
+                if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+            }
 #pragma unroll
             for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[PC_BI(FC - 1, PAR)], acc[r][FC - 1]);
             PC_LGKM0();
+            if constexpr (TS) {
+                if (FULL || s + 1 < k1) maskB(Bb[PC_BI(0, PAR ^ 1)], 0, d_nxt);
+                if (row_end) { ub ^= 1; ++Ucur; }
+                it_cur = it_cur == 8 ? 0 : it_cur + 1;
+            }
             ib = ib1;
         };
         using I0 = std::integral_constant<int, 0>;
@@ -322,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         }
         const int tile = cur.tile, grp = cur.grp, tn = cur.tn, m0 = cur.m0, n0 = cur.n0;
         // the fix-up / epilogue scratch sits BEHIND the stages (they are being refilled)
-        float* fsmem = reinterpret_cast<float*>(smem + NS * SA + NS * SB);
+        float* fsmem = reinterpret_cast<float*>(smem + NS * SA + NSB * SB);
         bool do_epilogue = true;
 
         // ---- stream-K fix-up: partial tiles meet in the slab ------------------------
@@ -566,7 +733,14 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     // the stages + the fix-up / epilogue scratch behind them (statistics partials [4][BM][2] floats, the last-arriver flag)
     constexpr int LDS_L = 2 * 3 * (128 + 256) * 64 + 4 * 128 * 2 * 4;      // 148 KB: 128 x 256, two stages
     constexpr int LDS_S = 2 * 3 * (64 + 256) * 64 + 4 * 128 * 2 * 4;       // 124 KB: 64 x 256, two stages
+    // tap-row sharing: two A stages + two B row stages of 272 rows + the scratch
+    constexpr int LDS_LT = 2 * 3 * 128 * 64 + 2 * 3 * 272 * 64 + 4 * 128 * 2 * 4;      // 154 KB
+    constexpr int LDS_ST = 2 * 3 * 64 * 64 + 2 * 3 * 272 * 64 + 4 * 128 * 2 * 4;       // 130 KB
     if (!attr_done) {
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 6, true>), LDS_LT, "pconv_kernel<4, 4, 2, 6, true>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 9, true>), LDS_LT, "pconv_kernel<4, 4, 2, 9, true>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 4, 2, 6, true>), LDS_ST, "pconv_kernel<2, 4, 2, 6, true>");
+        set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 4, 2, 9, true>), LDS_ST, "pconv_kernel<2, 4, 2, 9, true>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 6>), LDS_L, "pconv_kernel<4, 4, 2, 6>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 9>), LDS_L, "pconv_kernel<4, 4, 2, 9>");
         set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<2, 4, 2, 6>), LDS_S, "pconv_kernel<2, 4, 2, 6>");
@@ -589,6 +763,26 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, pconv_max_blocks()), p.total_steps);
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
     dim3 grid(nblk);
+    // tap-row sharing: 3x3, stride 1, the taps in three groups of one kernel row each whose column shifts cover -1, 0, +1
+    // (forward convs and their data gradients alike); FM_PCONV_TS=0 (tuning builds) keeps the per-tap stages
+    static const int ts_on = fm_tune("FM_PCONV_TS", 1);
+    bool ts = ts_on && p.ntaps == 9 && p.sg == 1 && p.Hg == p.Hi && p.Wg == p.Wi;
+    for (int j = 0; ts && j < 3; ++j) {
+        ts = p.dh[3 * j] == p.dh[3 * j + 1] && p.dh[3 * j] == p.dh[3 * j + 2];
+        int seen = 0;
+        for (int k = 0; k < 3; ++k) seen |= 1 << (p.dw[3 * j + k] + 1);
+        ts = ts && seen == 7;
+    }
+    if (ts) {
+        if (p.M >= 128) {
+            if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 9, true>), grid, dim3(512), LDS_LT, s, p);
+            else hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 6, true>), grid, dim3(512), LDS_LT, s, p);
+        } else {
+            if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<2, 4, 2, 9, true>), grid, dim3(512), LDS_ST, s, p);
+            else hipLaunchKernelGGL((pconv_kernel<2, 4, 2, 6, true>), grid, dim3(512), LDS_ST, s, p);
+        }
+        return;
+    }
     if (p.M >= 128) {
         if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 9>), grid, dim3(512), LDS_L, s, p);
         else hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 6>), grid, dim3(512), LDS_L, s, p);

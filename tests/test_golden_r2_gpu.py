@@ -155,7 +155,21 @@ def _check_picks(rep, mx, P, rnd, i, k, cls, log, got_clean, got_noise, args, de
         rep["picks_differing"] += len(set(want) - set(got))
 
 
-def _replay_two_stage(name, tol, tol_after_split, delta=(5e-2, 8e-2), model="Resnet18", precision="fp32"):
+def reference_band():
+    """The similarity band of the ResNet-18 two-stage replays, DERIVED from how far the reference moves from itself: the committed
+    record tests/golden/oracle_bands.json (tests/golden/oracle_bands.py re-runs the reference's own traj_fedmlp64 flow under
+    other fp32 summation orders: 3 threads instead of 8, torch's native convolutions instead of oneDNN) holds, per variant, the
+    largest similarity difference to the committed golden as a fraction of the row's range -- 1.5e-2 / 2.4e-2 (first / later
+    stage-2 rounds) for the thread count alone, 2.1e-2 / 3.4e-2 (and 6 of 30 picks changed) for the other convolution kernels.
+    Two implementations that each sit one such band from the exact trajectory differ by up to two: delta = 2 x band + 1e-2."""
+    with open(os.path.join(GOLDEN, "oracle_bands.json")) as f:
+        b = json.load(f)["traj_fedmlp64"]
+    first = max(v["sim_first_round"] for v in b.values())
+    later = max(v["sim_later_rounds"] for v in b.values())
+    return (2 * first + 1e-2, 2 * later + 1e-2)
+
+
+def _replay_two_stage(name, tol, tol_after_split, delta=None, model="Resnet18", precision="fp32"):
     """The FedMLP two-stage flow (stage 1, prototype pass, tagging + selection, stage 2, FedAvg*) FREE-RUNNING against a
     golden trajectory of the reference: the engine's own picks train the following rounds, nothing is replaced.
     tol: fixed bounds {loss, norm, bn_bias_norm, proto, logits, t_count} that hold while every pick so far equals the
@@ -167,7 +181,11 @@ def _replay_two_stage(name, tol, tol_after_split, delta=(5e-2, 8e-2), model="Res
     range, depending on nothing but fp32 rounding: measured on the C = 14 golden under three roundings of the engine's conv
     GEMMs -- fp32 matrix pipe 1.5e-2, bf16 partial products with 256-pixel tiles (and BN partial sums) on the 64-channel layers
     1.2e-2, the same with 192-pixel tiles 3.3e-2 (the tail-of-4 golden: 0.6 / 1.2e-2 / a pick 4.0e-2 behind the boundary) --
-    the chaos amplification of fp32 rounding that profiles/HISTORY.md quantifies; the band is 5e-2."""
+    the chaos amplification of fp32 rounding that profiles/HISTORY.md quantifies.  Round 5: the band is no longer a chosen number but
+    reference_band(): twice what the REFERENCE moves under another summation order, + 1e-2 (5.1e-2, 7.8e-2 from the committed
+    record: the engine's 1.2-3.3e-2 sits inside the reference's own 2.1-3.4e-2)."""
+    if delta is None:
+        delta = reference_band()
     from tests.helpers import replay_local_update
     LocalUpdate = replay_local_update()      # LocalUpdate + recorded batch orders / tagging log (tests/helpers.py)
     from fedmlp_amd.fedavg import FedAvg, FedAvg_tao, FedAvg_proto

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+mkdir -p gpurun_out
+timeout 240 python3 -m pytest tests/test_kernels_gpu.py -x -q 2>&1 | tail -4 > gpurun_out/ts_tests.txt
+if grep -q passed gpurun_out/ts_tests.txt && ! grep -q failed gpurun_out/ts_tests.txt; then
+  FM_DEBUG_REUSE_PLANES=1 timeout 200 python3 tools/probe_conv.py 256 1,3,6,8,11,13,16,18 0,1 > gpurun_out/ts_probe.txt 2>&1
+  timeout 300 python3 -m pytest tests/test_engine_gpu.py -x -q 2>&1 | tail -4 >> gpurun_out/ts_tests.txt
+  timeout 200 python3 bench.py --no-legs --sustain-s 0 --no-cpu-baseline --steps 40 2>&1 | tail -1 | cut -c1-330 >> gpurun_out/ts_tests.txt
+fi
+cat gpurun_out/ts_tests.txt gpurun_out/ts_probe.txt
