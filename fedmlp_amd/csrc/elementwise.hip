@@ -226,7 +226,8 @@ void k_scale(float* x, float w, int64_t n, hipStream_t s)
 // contraction into FMAs is switched off for these two kernels (hipcc's default is -ffp-contract=fast; HIP's __fmul_rn /
 // __fadd_rn are header functions compiled under that default and are contracted all the same, so the operators are written
 // out inside the pragma's scope); fp32 division is correctly rounded by default.
-__global__ void __launch_bounds__(256) fedavg_fold_kernel(FoldArgs a, int K, float tot, float* __restrict__ out, int64_t n4)
+// `out` may be one of the inputs (every element is read before it is written): no __restrict__ on it.
+__global__ void __launch_bounds__(256) fedavg_fold_kernel(FoldArgs a, int K, float tot, float* out, int64_t n4)
 {
 #pragma clang fp contract(off)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256) fedavg_fold_kernel(FoldArgs a, int K, flo
         reinterpret_cast<float4*>(out)[i] = acc;
     }
 }
-__global__ void fedavg_fold_tail_kernel(FoldArgs a, int K, float tot, float* __restrict__ out, int64_t i0, int64_t n)
+__global__ void fedavg_fold_tail_kernel(FoldArgs a, int K, float tot, float* out, int64_t i0, int64_t n)
 {
 #pragma clang fp contract(off)
     const int64_t i = i0 + threadIdx.x;
@@ -257,6 +258,15 @@ __global__ void fedavg_fold_tail_kernel(FoldArgs a, int K, float tot, float* __r
 }
 void k_fedavg_fold(const FoldArgs& a, int K, float tot, float* out, int64_t n, hipStream_t s)
 {
+    // the 16-B path needs 16-B aligned pointers (fm_state_device()'s buffer and torch allocations are; a view at an odd element
+    // offset is not): otherwise every element takes the scalar kernel
+    bool al = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int k = 0; k < K; ++k) al = al && (reinterpret_cast<uintptr_t>(a.s[k]) & 15) == 0;
+    if (!al) {
+        for (int64_t i0 = 0; i0 < n; i0 += 1024)
+            hipLaunchKernelGGL(fedavg_fold_tail_kernel, dim3(1), dim3(1024), 0, s, a, K, tot, out, i0, std::min<int64_t>(n, i0 + 1024));
+        return;
+    }
     const int64_t n4 = n / 4;
     if (n4) hipLaunchKernelGGL(fedavg_fold_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 8192)), dim3(256), 0, s, a, K, tot, out, n4);
     if (n4 * 4 < n) hipLaunchKernelGGL(fedavg_fold_tail_kernel, dim3(1), dim3(64), 0, s, a, K, tot, out, n4 * 4, n);

@@ -6,41 +6,35 @@
 // gradient inside loss.backward() (:674, 965, 1191), which the reference gets
 // from cuDNN through torchvision's resnet18 (model/all_models.py:53-54).
 //
+// In planes mode (ResNet-18 with a split product form: the shipped default) the 3x3 / 1x1 convolutions run through pconv.hip, which
+// takes BOTH operands as bf16 planes; what still runs here: the 7x7 stem (STEM = 2, activations split in the kernel), every conv
+// of a handle on the fp32 matrix pipe (fm_config.reserved[2] = 1) or with FM_PLANES=0, and EfficientNet-B0's wide fp32 1x1 convs.
+//
 // Roofline: SP = 6: v_mfma_f32_16x16x32_bf16, 2 500 TFLOP/s / 6 products = 416.7 TFLOP/s of fp32 products; SP = 0: fp32 matrix pipe
-// (v_mfma_f32_16x16x4_f32, 157 TFLOP/s).  Design (the bullets describe the fp32-pipe generation the split forms grew out of; what the
-// split forms change is said at the template: one 32-k stage per bf16 MFMA step, the weight operand as pre-split planes (WP),
-// 64 x 192 tiles for the 64-row layers, two-stage DMA lookahead from the two-stage ring):
-//  * D = Wp * Xg^T with output CHANNELS on the MFMA row axis, so each lane ends
-//    up with 4 consecutive channels of one pixel -> one 16-B NHWC store.
-//  * 256 threads = 4 waves, each wave owns a 64x64 sub-tile (4x4 MFMA tiles,
-//    64 accumulator VGPRs); block tile 128x128 (M>=128), 64x192 (M==64) or 64x256 (stem); two
-//    blocks per CU.  (The template also builds one-block-per-CU 256x128 /
-//    128x256 / 64x512 tiles with 128x64 wave tiles; measured slower, see the
-//    table above launch_igemm.)
-//  * Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR
-//    staging, no ds_write.  LDS is a ring of 4 stages of 16 k; a step's DMA is
-//    issued three steps ahead of its use (counted s_waitcnt vmcnt + raw
-//    s_barrier), so L2 misses do not stall the MFMA stream.  The LDS image is
-//    lane-linear (DMA destination = base + lane*16 B); the bank swizzle
-//    slot = chunk ^ ((row>>1)&3) is applied on the SOURCE address and on the
-//    read (conflict-free ds_read_b128 on 64-B rows, brute-force checked).
-//  * K order inside a step is permuted (lane group g reads k = 4g..4g+3 with
-//    ONE ds_read_b128 and feeds 4 MFMAs); legal because A and B use the same
-//    permutation.  Tap offsets are scalar kernel arguments; padding and tail
-//    rows read a 16-B zero page.
-//  * STREAM-K scheduling: ResNet's pixel counts are 49*2^k, so a one-tile-per-
-//    block grid leaves the last round of the 256 CUs partly empty.  The launch
-//    is persistent: the (tile, K-step) space is cut into equal contiguous
-//    ranges, one per block.  A block whose range ends inside a tile stores its
-//    partial accumulators to a slab, releases them at agent scope and bumps the
-//    tile's arrival counter; the LAST arriver re-reads every partial of the tile
-//    in segment order (the sum does not depend on arrival order: deterministic)
-//    and runs the epilogue.  Nobody waits on anybody: no residency assumption.
-//  * Epilogue variants (runtime-uniform): raw store + per-channel sum/sumsq
-//    partials (train-mode BN statistics, fixed reduction order), or folded
-//    eval-BN affine + residual + ReLU, or plain residual add (dgrad).
-//  * block -> range map is XCD-aware (blocks b, b+8, .. share an XCD and get
-//    adjacent ranges, i.e. neighbouring tiles share an L2).
+// (v_mfma_f32_16x16x4_f32, 157 TFLOP/s).  The shipped instantiations and their stage schedule:
+//   igemm_kernel<128, 128, 2, 0, NS = 2, KS = 32, SP, WP = 1>   M >= 128: weights as pre-split planes (k_split_weights), pixels fp32
+//   igemm_kernel< 64, 192, 4, 0, 2, 32, SP, 1>                  M = 64
+//   igemm_kernel< 64, 256, 4, 2, 2, 32, SP, 0>                  packed 7x7 stem: both operands fp32, split in the kernel
+//   (SP = 0: the same tiles with fp32 MFMA; KS = 16 / NS = 4 where Ci % 32 != 0)
+//  * D = Wp * Xg^T with output CHANNELS on the MFMA row axis, so each lane ends up with 4 consecutive channels of one pixel
+//    -> one 16-B NHWC store.  256 threads = 4 waves, each wave owns a 64 x 64 (64 x 48) sub-tile; two blocks per CU.
+//  * Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of NS = 2 stages of
+//    KS = 32 k: a whole 128-B line per DMA row.  WP = 1: the weight stage is [3 planes][BM rows][64 B] (24 KB for BM = 128), the
+//    pixel stage fp32 [BN][32] (16 KB).  The LDS image is lane-linear (DMA destination = base + lane * 16 B); the bank swizzle
+//    slot = chunk ^ ((row >> 1) & SM) is applied on the SOURCE address and on the read (conflict-free ds_read_b128).
+//  * One K-step (WP form, "LA2"): wait for the step's DMA (counted vmcnt) -> barrier -> read ALL of the step's fragments into
+//    registers (12 weight-plane + 8 pixel reads) -> barrier -> the slot is free: issue the DMA of step s + 2 (two stages of
+//    lookahead from a two-stage ring) -> 96 MFMAs with the pixel columns' fp32 -> 3 x bf16 split (44 VALU per column) pinned
+//    two instructions into the shadow of every MFMA, one column ahead of its use.
+//  * K order inside a 32-k block is permuted (lane group g supplies k = 4g..4g+3 and 16+4g..16+4g+3); legal because A and B use
+//    the same permutation.  Tap offsets are scalar kernel arguments; padding and tail rows read a 16-B zero page.
+//  * STREAM-K scheduling: ResNet's pixel counts are 49*2^k, so a one-tile-per-block grid leaves the last round of the CUs partly
+//    empty.  The launch is persistent: the (tile, K-step) space is cut into equal contiguous ranges, one per block.  A block
+//    whose range ends inside a tile stores its partial accumulators to a slab, releases them at agent scope and bumps the tile's
+//    arrival counter; the LAST arriver re-reads every partial of the tile in segment order (deterministic) and runs the epilogue.
+//  * Epilogue variants (runtime-uniform): raw store + per-channel sum / sumsq partials (train-mode BN statistics, fixed reduction
+//    order), or folded eval-BN affine + residual + ReLU, or plain residual add (dgrad).
+//  * block -> range map is XCD-aware (blocks b, b+8, .. share an XCD and get adjacent ranges: neighbouring tiles share an L2).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -189,9 +183,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p)
                 // packed 7x7 stem: chunk c of K = floats 4j .. 4j+3 of kernel row kh's 24-float window, which starts at the
                 // framed pixel (2 oh + kh, 2 ow): no bounds to check, chunks past the 42 real ones read the zero page
                 const int koff = s * KS;
+                // rows of W hold Ktot floats (176): a 32-k stage past that (the sixth) would read the next row's head -- harmless
+                // against the zero chunks of X only while those floats are finite, so such chunks come from the zero page
 #pragma unroll
                 for (int q = 0; q < GA; ++q)
-                    __builtin_amdgcn_global_load_lds(av[q] ? asrc[q] + koff : p.zeros,
+                    __builtin_amdgcn_global_load_lds((av[q] && koff + csrc_of(wave * GA + q) < Ktot) ? asrc[q] + koff : p.zeros,
                                                      (lds_void*)(As + slot * STG_A + (wave * GA + q) * 256), 16, 0, 0);
 #pragma unroll
                 for (int q = 0; q < GB; ++q) {

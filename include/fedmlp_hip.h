@@ -98,7 +98,8 @@ int fm_state_scale(fm_engine* e, float w);
 /* FedAvg (utils/FedAvg.py:7-14) of K client states that share ONE GPU (main.py:135-218 trains its clients in turn and
  * aggregates their state_dicts in one process): out[j] = ((s_0[j]*n_0 + s_1[j]*n_1) + ...) / sum(n) in the reference's
  * left-to-right order with its roundings (separate fp32 product and sum, IEEE division), so fp32 entries are bit-identical
- * to utils/FedAvg.py.  states_dev: HOST array of K device pointers to engine-layout states (fm_state_device()'s layout and
+ * to utils/FedAvg.py run on CPU tensors (what the KAT pins; on CUDA tensors torch divides by multiplying with the reciprocal,
+ * which can differ in the last bit).  states_dev: HOST array of K device pointers to engine-layout states (fm_state_device()'s layout and
  * length, e.g. copies of it taken after each client's round); n_host: the K sample counts (dict_len); K <= 16; out_dev may
  * be fm_state_device()'s buffer itself or any of the inputs.  The num_batches_tracked counters stay with the caller
  * (fm_counters). */
