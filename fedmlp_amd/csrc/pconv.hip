@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     constexpr int BROWS = 16 * GB;                             // rows of a B stage plane
     constexpr int SA = 3 * BM * 64, SB = 3 * BROWS * 64;       // bytes per stage
     constexpr int NSB = TS ? 2 : NS;                           // B slots (TS: one per kernel row, two in flight)
-    static_assert(!TS || (NS == 2 && FC == 4), "tap-row sharing: two stages, 256-pixel tiles");
+    static_assert(!TS || FC == 4, "tap-row sharing: 256-pixel tiles");
     constexpr int JA = (3 * GA + 7) / 8;                       // A DMA instructions per wave per stage (waves past 3 GA - 8 (JA - 1): one fewer)
     constexpr int RGB = (GB + 7) / 8;                          // B row groups per wave (wave + 8 i < GB), each x 3 planes
     static_assert(NS == 2 || NS == 3, "two or three LDS stages");
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const int ngrpB = (wave + 8 * (RGB - 1) < GB) ? RGB : RGB - 1;
     constexpr int NW_HI = JA + 3 * RGB;                                            // waves that hold the full share
     constexpr int NW_LO = ((3 * GA) % 8 ? JA - 1 : JA) + 3 * (GB % 8 ? RGB - 1 : RGB);   // waves 4 .. 7 when the job counts are odd multiples of 4
-    static_assert(NS == 2 || (((3 * GA) % 8 == 0 || (3 * GA) % 8 == 4) && (GB % 8 == 0 || GB % 8 == 4)), "job split by wave < 4");
+    static_assert(NS == 2 || TS || (((3 * GA) % 8 == 0 || (3 * GA) % 8 == 4) && (GB % 8 == 0 || GB % 8 == 4)), "job split by wave < 4");
     // TS: kernel-row offset and column shifts from the tap table: taps 3 j .. 3 j + 2 share dh; d = dw + 1 of tap t
     auto tap_d = [&](int t) { return (int)((unsigned)(p.tapcode >> (4 * t + 2)) & 3u); };
 
@@ -290,14 +290,20 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         asm volatile("" ::: "memory");
         // TS: kernel rows (super-steps of three taps) U = s / 3; this segment covers U0 .. U1; B slot of U = (U - U0) & 1
         int it_cur = 0, Ucur = 0, ub = 0;
-        bool b_young = false;                  // TS: the youngest DMA group is a B row (issued AFTER the previous step's A stage)
-        // TS: wait for everything but the B row issued last (it is needed two steps later): 3 planes x this wave's row groups
-        auto wait_dma = [&]() {
-            if (TS && b_young) {
-                if (ngrpB == RGB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * RGB) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (RGB - 1)) : "memory");
-            } else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int b_age = 3;                         // TS: barriers since the last B row was issued (it goes out AFTER that barrier's A stage)
+        // TS: the step's barrier needs A(s + 2) (and, at a row's last step, the next row, issued three steps back).  Vector-memory
+        // operations complete in issue order, so everything YOUNGER than A(s + 2) may stay in flight: the A stages issued since
+        // (NS - 2 of them, when every step issues one: `full`) and a B row issued one or NS - 1 barriers ago
+        const int ja_w = ((3 * GA) % 8 != 0 && wave >= 4) ? JA - 1 : JA;
+        auto wait_dma = [&](bool full) {
+            int n = 0;
+            if (TS && full) n = (NS - 2) * ja_w + ((b_age >= 1 && b_age <= NS - 1) ? 3 * ngrpB : 0);
+            switch (n) {
+#define PC_VM(N_) case N_: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); break;
+                PC_VM(1) PC_VM(2) PC_VM(3) PC_VM(6) PC_VM(7) PC_VM(8) PC_VM(9) PC_VM(10) PC_VM(11) PC_VM(12)
+#undef PC_VM
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         };
         const int U1 = (k1 - 1) / 3;
         auto bsel = [&](int d) { return d == 0 ? Bfd[0] : (d == 1 ? Bfd[1] : Bfd[2]); };
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         }
         if constexpr (NS == 3) {
             if (k0 + 2 < k1) issueA(cur, k0 + 2, 2);
-            if (k0 + 2 < k1) issueB(cur, 2);
+            if constexpr (!TS) { if (k0 + 2 < k1) issueB(cur, 2); }
         }
         PC_READA(Af0, 0, A0[0]);
         PC_READA(Af0, 1, A0[1]);
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #pragma unroll
                 for (int r = 0; r < FR; ++r) acc[r][1] = pc_mfma<SP>(Ac[r], Bb[1], acc[r][1]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wait_dma();
+                wait_dma(FULL);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (TS) { maskB(Bb[2], 2, d_cur); maskB(Bb[3], 3, d_cur); }
                 __builtin_amdgcn_s_barrier();
@@ -384,8 +390,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 if constexpr (TS) {
                     // A first, then the B row: the next barrier waits for the A stage only and leaves the row in flight
                     if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                    b_young = row_end && Ucur + 2 <= U1;
-                    if (b_young) issueB(cur, ub);
+                    if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
                 } else {
                     if (FULL || s + NS < k1) issueB(cur, ib);
                     if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
@@ -400,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                     if (more) { maskB(Bb[0], 0, d_nxt); maskB(Bb[1], 1, d_nxt); }
                     if (row_end) { ub ^= 1; ++Ucur; }
                     it_cur = it_cur == 8 ? 0 : it_cur + 1;
+                    if (b_age < 3) ++b_age;
                 }
                 ib = ib1;
                 return;
@@ -434,12 +440,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             // last column: every wave holds all of this step's fragments and step s+1's A fragments: slot ib of B and slot ib1 of A
             // are free.  B(s + 1) and A(s + 2) must have landed: with three stages the youngest group of DMA (B(s + 2), A(s + 3),
             // issued one step ago) may stay in flight
-            if constexpr (NS == 3 && FULL) {
+            if constexpr (NS == 3 && FULL && !TS) {
                 if constexpr (NW_HI == NW_LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
                 else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_LO) : "memory");
             } else
-                wait_dma();
+                wait_dma(FULL);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (FULL || s + 1 < k1) PC_READB(b_nxt, 0, Bb[PC_BI(0, PAR ^ 1)]);
@@ -447,8 +453,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 // the last tap of a kernel row has consumed its B slot: it takes the row after next.  A first, then the B row: the
                 // next barrier waits for the A stage only and leaves the row in flight
                 if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                b_young = row_end && Ucur + 2 <= U1;
-                if (b_young) issueB(cur, ub);
+                if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
             } else {
                 if (FULL || s + NS < k1) issueB(cur, ib);
                 if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 if (FULL || s + 1 < k1) maskB(Bb[PC_BI(0, PAR ^ 1)], 0, d_nxt);
                 if (row_end) { ub ^= 1; ++Ucur; }
                 it_cur = it_cur == 8 ? 0 : it_cur + 1;
+                if (b_age < 3) ++b_age;
             }
             ib = ib1;
         };
@@ -735,6 +741,8 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     constexpr int LDS_S = 2 * 3 * (64 + 256) * 64 + 4 * 128 * 2 * 4;       // 124 KB: 64 x 256, two stages
     // tap-row sharing: two A stages + two B row stages of 272 rows + the scratch
     constexpr int LDS_LT = 2 * 3 * 128 * 64 + 2 * 3 * 272 * 64 + 4 * 128 * 2 * 4;      // 154 KB
+    // (three A stages for the 64-row tiles -- 142 KB, two steps of A lookahead, counted waits -- were measured: 377-383 vs 368-378 us on
+    // the 56 x 56 x 64 layers, not kept: those tiles are not bound by DMA latency)
     constexpr int LDS_ST = 2 * 3 * 64 * 64 + 2 * 3 * 272 * 64 + 4 * 128 * 2 * 4;       // 130 KB
     if (!attr_done) {
         set_max_dyn_lds(reinterpret_cast<const void*>(&pconv_kernel<4, 4, 2, 6, true>), LDS_LT, "pconv_kernel<4, 4, 2, 6, true>");
