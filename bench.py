@@ -53,7 +53,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NFAM = 6                              # kernel families of fm_profile_read (kernel_names())
+NFAM = 8                              # kernel families of fm_profile_read (kernel_names(); FM_PROFILE_FAMILIES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense
 
@@ -73,12 +73,13 @@ def kernel_names(sp=None, planes=False):
     Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes)."""
     sp = mfma_products() if sp is None else sp
     if planes and sp:      # planes mode (csrc/pconv.hip, pwgrad.hip): both GEMM operands arrive as bf16 planes
-        return {0: f"pconv_kernel<4,4,2,{sp}>", 1: f"pconv_kernel<2,4,2,{sp}>", 2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>",
-                3: f"pwgrad_kernel<4,*,{sp}>", 4: f"pwgrad_kernel<2,*,{sp}>", 5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
+        return {0: f"pconv_kernel<4,4,2,{sp},true>", 1: f"pconv_kernel<2,4,2,{sp},true>", 2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>",
+                3: f"pwgrad_kernel<4,*,{sp}>", 4: f"pwgrad_kernel<2,*,{sp}>", 5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]",
+                6: f"pconv_kernel<4,4,2,{sp},false>", 7: f"pconv_kernel<2,4,2,{sp},false>"}
     wp = 1 if sp else 0
     return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},{wp}>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},{wp}>",
             2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>" if sp else "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
-            5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]"}
+            5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]", 6: "(planes mode only)", 7: "(planes mode only) "}
 
 
 def mfma_peak(sp=None):
@@ -509,10 +510,10 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
                     "measured_in": "the timed region (no free device memory for the one-stream per-kernel pass)"}
         else:
             if args.workload == "conv_fwd":
-                use = [0, 1, 2]
+                use = [0, 1, 2, 6, 7]
                 n = sum(fams[f][0] for f in use); ms = sum(fams[f][1] for f in use)
                 fl = sum(fams[f][2] for f in use)
-                name = "igemm_kernel<*> (all 20 conv forwards of the eval pass)"
+                name = ("pconv_kernel<*> + the stem's igemm_kernel" if planes and sp else "igemm_kernel<*>") + " (all 20 conv forwards of the eval pass)"
             else:
                 dom = max(range(NFAM), key=lambda f: fams[f][1])
                 n, ms, fl = fams[dom]
@@ -536,7 +537,7 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
                 roof["whole_step_frac"] = round(steps_alg / (dt / args.steps) / 1e12 / peak, 4)
                 roof["whole_step_frac_of_fp32_mfma_peak"] = round(steps_alg / (dt / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             if args.workload == "conv_fwd":
-                roof["traffic"] = family_traffic("igemm_kernel<", args)     # mean over the 20 conv launches of a pass
+                roof["traffic"] = family_traffic("pconv_kernel<" if planes and sp else "igemm_kernel<", args)     # mean over the conv launches of a pass
                 roof["algorithmic_flop_per_pass"] = RESNET_FWD_FLOP * B
                 roof["whole_pass_tflops"] = round(RESNET_FWD_FLOP * B / (dt / args.steps) / 1e12, 3)
     effective_mode = eng.stream_mode

@@ -217,6 +217,7 @@ void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 // pconv.hip: the same GEMM with both operands as block-major bf16 planes (p.Wsp, p.Xp); p.nsteps is set by the launcher
 void launch_pconv(IgemmParams p, int groups, hipStream_t s);
 bool pconv_takes(int M, int Ci, long long xp_pix, int Wi);
+bool pconv_uses_ts(const IgemmParams& p);      // will launch_pconv take the tap-row-sharing kernel for these parameters?
 int pconv_tile_m(int M);
 int pconv_tile_n(int M);
 // small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)

@@ -185,8 +185,8 @@ struct fm_engine {
     std::vector<OpEv> opevs;
     std::vector<EvPair> evs;
     std::vector<hipEvent_t> ev_free;
-    double prof_ms[6] = {0, 0, 0, 0, 0, 0}, prof_flops[6] = {0, 0, 0, 0, 0, 0};
-    int64_t prof_n[6] = {0, 0, 0, 0, 0, 0};
+    double prof_ms[FM_PROFILE_FAMILIES] = {}, prof_flops[FM_PROFILE_FAMILIES] = {};
+    int64_t prof_n[FM_PROFILE_FAMILIES] = {};
     std::vector<void*> allocs;
     // dgrad weight packs: rebuilt by ONE launch after every optimizer step (and lazily after any
     // external change of the state), not per convolution call
@@ -1011,7 +1011,8 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         p.tilesM = c.cout_p / pconv_tile_m(c.cout_p);
         p.tilesN = (p.imgs_per_group * c.hout * c.wout + pconv_tile_n(c.cout_p) - 1) / pconv_tile_n(c.cout_p);
         p.relu = relu;
-        ProfScope ps(e, c.cout_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs);
+        // measurement families follow the kernel symbols: 0 / 1 = pconv_kernel<4 | 2, ..., true> (tap rows shared), 6 / 7 = <..., false>
+        ProfScope ps(e, (c.cout_p >= 128 ? 0 : 1) + (pconv_uses_ts(p) ? 0 : 6), 2.0 * c.macs_per_img * imgs);
         launch_pconv(p, groups, e->st);
         return;
     }
@@ -1105,7 +1106,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
             p.tilesM = c.cin_p / pconv_tile_m(c.cin_p);
             p.tilesN = (imgs * p.Hg * p.Wg + pconv_tile_n(c.cin_p) - 1) / pconv_tile_n(c.cin_p);
             p.relu = 0;
-            ProfScope ps(e, c.cin_p >= 128 ? 0 : 1, 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
+            ProfScope ps(e, (c.cin_p >= 128 ? 0 : 1) + (pconv_uses_ts(p) ? 0 : 6), 2.0 * c.macs_per_img * imgs * d.taps.n / (double)(c.k * c.k));
             launch_pconv(p, 1, e->st);
         }
         return;
@@ -2552,7 +2553,7 @@ int fm_profile_enable(fm_engine* e, int32_t on)
 
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops)
 {
-    ARGCHK(e && family >= 0 && family < 6, "family");
+    ARGCHK(e && family >= 0 && family < FM_PROFILE_FAMILIES, "family");
     HIPCHK(hipStreamSynchronize(e->st));
     if (e->prof_fail) { e->prof_fail = false; g_err = "a profiling event could not be created/recorded"; return FM_ERR_HIP; }
     for (auto& p : e->evs) {

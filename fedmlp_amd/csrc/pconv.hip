@@ -732,6 +732,21 @@ bool pconv_takes(int M, int Ci, long long xp_pix, int Wi)
     return ((long long)(Ci >> 5) * 3 * xp_pix + Wi + 1) * 64 < 0x7ff00000LL;
 }
 
+// tap-row sharing applies to: 3x3, stride 1, the taps in three groups of one kernel row each whose column shifts cover -1, 0, +1
+// (forward convs and their data gradients alike); FM_PCONV_TS=0 (tuning builds) keeps the per-tap stages
+bool pconv_uses_ts(const IgemmParams& p)
+{
+    static const int ts_on = fm_tune("FM_PCONV_TS", 1);
+    bool ts = ts_on && p.ntaps == 9 && p.sg == 1 && p.Hg == p.Hi && p.Wg == p.Wi;
+    for (int j = 0; ts && j < 3; ++j) {
+        ts = p.dh[3 * j] == p.dh[3 * j + 1] && p.dh[3 * j] == p.dh[3 * j + 2];
+        int seen = 0;
+        for (int k = 0; k < 3; ++k) seen |= 1 << (p.dw[3 * j + k] + 1);
+        ts = ts && seen == 7;
+    }
+    return ts;
+}
+
 void launch_pconv(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
@@ -773,14 +788,7 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     dim3 grid(nblk);
     // tap-row sharing: 3x3, stride 1, the taps in three groups of one kernel row each whose column shifts cover -1, 0, +1
     // (forward convs and their data gradients alike); FM_PCONV_TS=0 (tuning builds) keeps the per-tap stages
-    static const int ts_on = fm_tune("FM_PCONV_TS", 1);
-    bool ts = ts_on && p.ntaps == 9 && p.sg == 1 && p.Hg == p.Hi && p.Wg == p.Wi;
-    for (int j = 0; ts && j < 3; ++j) {
-        ts = p.dh[3 * j] == p.dh[3 * j + 1] && p.dh[3 * j] == p.dh[3 * j + 2];
-        int seen = 0;
-        for (int k = 0; k < 3; ++k) seen |= 1 << (p.dw[3 * j + k] + 1);
-        ts = ts && seen == 7;
-    }
+    const bool ts = pconv_uses_ts(p);
     if (ts) {
         if (p.M >= 128) {
             if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 9, true>), grid, dim3(512), LDS_LT, s, p);
