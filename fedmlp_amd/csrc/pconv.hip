@@ -50,6 +50,15 @@ template <int IMM> __device__ __forceinline__ sp_u32x4 pc_lds_read128(unsigned a
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
     return v;
 }
+// x = q d + r for x < 2^24 (pixel indices): the float estimate of the quotient is off by at most one; a hardware-less integer
+// division costs ~40 instructions, and a tile decodes / places a dozen pixel indices per lane
+__device__ __forceinline__ void pc_divmod(int x, int d, float rcp, int& q, int& r)
+{
+    q = (int)((float)x * rcp);
+    r = x - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+}
 template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3], const sp_u32x4 (&b)[3], f32x4 v)
 {
     return mfma_split<SP>(a[0], a[1], a[2], b[0], b[1], b[2], v);
@@ -65,10 +74,22 @@ template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3
 // rows][64 B], two slots), and the tap's column shift is a row offset of the fragment reads (conflict-free at every offset,
 // brute-force checked); a pixel whose shifted neighbour lies in another image row reads a zero (a select on the fragment
 // registers).  B traffic into LDS per K-step: 48 KB -> 17 KB.
+// -DPC_PHASES (tools/probe_phases.py, a timing-only build): wave 0 of every block sums the shader-clock cycles it spends in each
+// phase of a segment (lead wait | barrier | prologue reads | main loop | next segment's decode + lead | fix-up | epilogue | gap)
+#ifdef PC_PHASES
+__device__ unsigned long long pc_prof[256 * 8];
+#define PC_T(i) do { const unsigned long long t_ = clock64(); pc_acc[i] += t_ - pc_t; pc_t = t_; } while (0)
+#else
+#define PC_T(i) do { } while (0)
+#endif
 template <int FR, int FC, int NS, int SP, bool TS = false>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__
+#ifdef PC_PHASES
+    unsigned long long pc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc_t = clock64();
+#endif
     constexpr int WN = 4;
     constexpr int BM = 32 * FR, BN = 64 * FC;
     constexpr int GA = BM / 16, GB = TS ? (BN + 2 + 15) / 16 : BN / 16;       // 16-row groups per operand stage (TS: + the two halo rows)
@@ -94,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     const int npix = p.imgs_per_group * HWg;
     const int tiles_pg = p.tilesM * p.tilesN;
     const int Wi = p.Wi;
+    const float rcpHW = 1.0f / (float)HWg, rcpW = 1.0f / (float)p.Wg;
 
     // XCD-aware bijective remap of the block id to a range index
     const int nb = gridDim.x, bid = blockIdx.x;
@@ -137,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         unsigned cmask;                          // TS: bit 2c = the pixel of column tile c has a left neighbour in its image row, 2c + 1 = a right one
     };
     auto decode = [&](Seg& g) {                  // takes the next segment off the block's range [w, wend)
-        g.tile = (int)(w / nsteps);
+        g.tile = (int)((unsigned)w / (unsigned)nsteps);              // (total_steps < 2^31: the launcher checks)
         g.k0 = (int)(w - (long long)g.tile * nsteps);
         g.k1 = min(nsteps, g.k0 + (int)(wend - w));
         g.first = (w == (long long)rbk * S);
@@ -156,8 +178,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             const int n = g.n0 + 16 * (wave + 8 * i) + drow - (TS ? 1 : 0);
             const bool rv = n >= 0 && n < npix && i < ngrpB;
             const int nn = rv ? n : 0;
-            const int img = nn / HWg, rem = nn - img * HWg;
-            const int hg = rem / p.Wg, wg = rem - hg * p.Wg;
+            int img, rem, hg, wg;
+            pc_divmod(nn, HWg, rcpHW, img, rem);
+            pc_divmod(rem, p.Wg, rcpW, hg, wg);
             const int ih0 = hg * p.sg, iw0 = wg * p.sg;
             unsigned vm = 0;
             if constexpr (TS) {
@@ -185,7 +208,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #pragma unroll
             for (int c = 0; c < FC; ++c) {
                 const int n = g.n0 + wn * (16 * FC) + 16 * c + li;
-                const int wg = n % p.Wg;
+                int img, rem, hg, wg;
+                pc_divmod(n, HWg, rcpHW, img, rem);
+                pc_divmod(rem, p.Wg, rcpW, hg, wg);
                 cm |= (wg > 0 ? 1u : 0u) << (2 * c);
                 cm |= (wg < p.Wg - 1 ? 1u : 0u) << (2 * c + 1);
             }
@@ -253,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     Seg cur;
     decode(cur);
     lead(cur);
+    int pend_tile = -1;                          // a stored part of a shared tile that has not been announced yet
     for (;;) {
         const int k0 = cur.k0, k1 = cur.k1;
         f32x4 acc[FR][FC];
@@ -285,9 +311,21 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 
         // ---- prologue.  Stage slot of step s = (s - k0) % NS.  Invariant at the start of step s: B(s), A(s + 1) have landed
         // (A(s) is in registers), B(s + 1 .. s + NS - 1) and A(s + 2 .. s + NS) are issued ----------------------------------------
+        PC_T(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the segment's lead DMA: A(k0), B(k0), A(k0 + 1)
+        PC_T(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (pend_tile >= 0) {
+            // the previous segment's part of a shared tile has reached memory (every wave waited above): announce it
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep: the fence's own wait may be dropped
+                __hip_atomic_fetch_add(p.counters + pend_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            pend_tile = -1;
+        }
+        PC_T(1);
         // TS: kernel rows (super-steps of three taps) U = s / 3; this segment covers U0 .. U1; B slot of U = (U - U0) & 1
         int it_cur = 0, Ucur = 0, ub = 0;
         int b_age = 3;                         // TS: barriers since the last B row was issued (it goes out AFTER that barrier's A stage)
@@ -346,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         asm volatile("" ::: "memory");
         if (k0 + NS < k1) issueA(cur, k0 + NS, 0);
 
+        PC_T(2);
         int ib = 0;                            // stage slot of the current step
         // one K-step (register parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
         // FULL: steps up to s + NS + 1 exist (the main loop: no branch inside, counted vmcnt); otherwise the conditions are tested
@@ -485,6 +524,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #undef PC_LGKM0
 #undef PC_BI
         PC_SYNC_LDS();         // every wave is done reading both stages: they can take the next segment's lead DMA
+        PC_T(3);
 
         // ---- the next segment's pipeline fill starts now, behind this segment's fix-up / epilogue --------------------------------
         const bool more = w < wend;
@@ -493,51 +533,50 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             decode(nx);
             lead(nx);
         }
+        PC_T(4);
         const int tile = cur.tile, grp = cur.grp, tn = cur.tn, m0 = cur.m0, n0 = cur.n0;
         // the fix-up / epilogue scratch sits BEHIND the stages (they are being refilled)
         float* fsmem = reinterpret_cast<float*>(smem + NS * SA + NSB * SB);
         bool do_epilogue = true;
 
         // ---- stream-K fix-up: partial tiles meet in the slab ------------------------
+        // A block's range starts inside a tile at most once (its FIRST segment: the tile's tail, run at the START of the range)
+        // and ends inside one at most once (its LAST segment: the tile's head, run at the END).  The head's owner (b_first) is the
+        // tile's finisher: by the time it gets there -- a whole range later -- the owners of the other parts have long stored theirs,
+        // so it waits on the tile's counter (normally not at all), keeps its own part in registers and sums the parts in segment
+        // order (the result does not depend on timing).  The others store their part and announce it AFTER the next segment's
+        // pipeline fill has been waited for (the drain of the stores hides behind that wait).
         if (k0 != 0 || k1 != nsteps) {
-            // slot 0: the block's first segment, slot 1: its last one (middle ones are whole tiles)
-            float* mine = p.slab + (size_t)(rbk * 2 + (cur.first ? 0 : 1)) * (BM * BN);
+            const unsigned t0 = (unsigned)tile * (unsigned)nsteps;
+            const int b_first = (int)(t0 / (unsigned)S), b_last = (int)((t0 + (unsigned)nsteps - 1u) / (unsigned)S);
+            if (rbk != b_first) {
+                float* mine = p.slab + (size_t)rbk * 2 * (BM * BN);
 #pragma unroll
-            for (int r = 0; r < FR; ++r)
+                for (int r = 0; r < FR; ++r)
 #pragma unroll
-                for (int c = 0; c < FC; ++c)
-                    *reinterpret_cast<f32x4*>(mine + ((r * FC + c) * 512 + tid) * 4) = acc[r][c];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
-            __syncthreads();
-            const long long t0 = (long long)tile * nsteps;
-            const int b_first = (int)(t0 / S), b_last = (int)((t0 + nsteps - 1) / S);
-            int* flag = reinterpret_cast<int*>(fsmem);
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep: the fence's own wait may be dropped
-                const int old = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = old == b_last - b_first;
-                if (last) {
+                    for (int c = 0; c < FC; ++c)
+                        *reinterpret_cast<f32x4*>(mine + ((r * FC + c) * 512 + tid) * 4) = acc[r][c];
+                pend_tile = tile;
+                do_epilogue = false;
+            } else {
+                if (tid == 0) {
+                    const int need = b_last - b_first;
+                    // (bounded: a lost part shows up as a wrong result in the parity tests, not as a hung GPU)
+                    for (int it = 0; it < (1 << 22); ++it) {
+                        if (__hip_atomic_load(p.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == need) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
                     __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                *flag = last;
-            }
-            __syncthreads();
-            const bool last = *flag != 0;
-            __syncthreads();                                          // flag word is reused as LDS below
-            do_epilogue = last;
-            if (last) {
-                // last arriver: sum every segment of this tile in segment order (incl. its own, from the slab) -> the result
-                // is independent of which block arrived last
+                __syncthreads();
 #pragma unroll
                 for (int r = 0; r < FR; ++r)
 #pragma unroll
-                    for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int bb = b_first; bb <= b_last; ++bb) {
-                    const long long sstart = max(t0, (long long)bb * S);
-                    const float* src = p.slab + (size_t)(bb * 2 + (sstart == (long long)bb * S ? 0 : 1)) * (BM * BN);
+                    for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f} + acc[r][c];
+                for (int bb = b_first + 1; bb <= b_last; ++bb) {
+                    const float* src = p.slab + (size_t)bb * 2 * (BM * BN);
 #pragma unroll
                     for (int r = 0; r < FR; ++r)
 #pragma unroll
@@ -547,6 +586,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             }
         }
 
+        PC_T(5);
         if (do_epilogue) {
         // ---- epilogue -------------------------------------------------------------
         // acc[r][c][q] = D[m = m0 + wm*16FR + 16r + 4*lg + q][n = n0 + wn*64 + 16c + li]
@@ -593,10 +633,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         for (int c = 0; c < FC; ++c) {
             const int n = n0 + wn * (16 * FC) + 16 * c + li;
             if (n >= npix) continue;
-            const int img = n / HWg;
-            const int rem = n - img * HWg;
-            const int hg = rem / p.Wg;
-            const int wg = rem - hg * p.Wg;
+            int img, rem, hg, wg;
+            pc_divmod(n, HWg, rcpHW, img, rem);
+            pc_divmod(rem, p.Wg, rcpW, hg, wg);
             const size_t opix = (size_t)((grp * p.imgs_per_group + img) * p.Ho + hg * p.os + p.oh0) * p.Wo + (wg * p.os + p.ow0);
             const size_t o = opix * p.Co;
             f32x4 v[FR];
@@ -656,13 +695,33 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             }
         }
         }
+        PC_T(6);
         if (!more) break;
         PC_SYNC_LDS();         // the scratch (statistics, flag) is reused by the next segment's epilogue
         cur = nx;
     }
+    if (pend_tile >= 0) {                        // (a block whose whole range lies inside one tile)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(p.counters + pend_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #undef PC_SYNC_LDS
+#ifdef PC_PHASES
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) pc_prof[blockIdx.x * 8 + i] = pc_acc[i];
+#endif
 #endif
 }
+#ifdef PC_PHASES
+extern "C" int fm_debug_pconv_prof(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_prof), sizeof(unsigned long long) * 256 * 8);
+}
+#endif
 
 // ---- weight planes, block-major: dst[K block s = (channel block, tap)][3][M][32] from fp32 W[M][ntaps][Ci] ------------------
 // One thread = one 8-value chunk (channels 4g..4g+3, 16+4g..16+4g+3 of a 32-channel block): two 16-B reads 64 B apart, three
@@ -729,7 +788,9 @@ int pconv_max_blocks() { return 256; }     // ONE block per CU (120 - 144 KB of 
 bool pconv_takes(int M, int Ci, long long xp_pix, int Wi)
 {
     if (M % 64 != 0 || (M > 64 && M % 128 != 0) || Ci % 32 != 0) return false;
-    return ((long long)(Ci >> 5) * 3 * xp_pix + Wi + 1) * 64 < 0x7ff00000LL;
+    // (pixel indices below 2^22: the kernel divides them through a float reciprocal; the parity grids of a stride-2 data gradient
+    // hold up to four times the pixels of its input)
+    return ((long long)(Ci >> 5) * 3 * xp_pix + Wi + 1) * 64 < 0x7ff00000LL && xp_pix < (1LL << 22);
 }
 
 // tap-row sharing applies to: 3x3, stride 1, the taps in three groups of one kernel row each whose column shifts cover -1, 0, +1
