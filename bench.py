@@ -53,7 +53,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NFAM = 8                              # kernel families of fm_profile_read (kernel_names(); FM_PROFILE_FAMILIES)
+NFAM = 9                              # kernel families of fm_profile_read (kernel_names(); FM_PROFILE_FAMILIES)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16, dense
 
@@ -75,11 +75,11 @@ def kernel_names(sp=None, planes=False):
     if planes and sp:      # planes mode (csrc/pconv.hip, pwgrad.hip): both GEMM operands arrive as bf16 planes
         return {0: f"pconv_kernel<4,4,2,{sp},true>", 1: f"pconv_kernel<2,4,2,{sp},true>", 2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>",
                 3: f"pwgrad_kernel<4,*,{sp}>", 4: f"pwgrad_kernel<2,*,{sp}>", 5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]",
-                6: f"pconv_kernel<4,4,2,{sp},false>", 7: f"pconv_kernel<2,4,2,{sp},false>"}
+                6: f"pconv_kernel<4,4,2,{sp},false>", 7: f"pconv_kernel<2,4,2,{sp},false>", 8: f"pwgrad_ring_kernel<{sp}>"}
     wp = 1 if sp else 0
     return {0: f"igemm_kernel<128,128,2,0,2,32,{sp},{wp}>", 1: f"igemm_kernel<64,192,4,0,2,32,{sp},{wp}>",
             2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>" if sp else "igemm_kernel<64,256,4,2,4,16,0,0>", 3: f"wgrad_kernel<128,128,2,4,{sp}>", 4: f"wgrad_kernel<64,192,4,3,{sp}>",
-            5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]", 6: "(planes mode only)", 7: "(planes mode only) "}
+            5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]", 6: "(planes mode only)", 7: "(planes mode only) ", 8: "(planes mode only)  "}
 
 
 def mfma_peak(sp=None):

@@ -210,8 +210,15 @@ struct PwgradParams {
     int pix_per_split;           // multiple of 32 (set by the launcher)
     int tilesM, tilesN, nblk_n;  // set by the launcher
     int sp;                      // product form: 6 / 9
+    // pwgrad_ring.hip (set by its launcher): images, padded positions in all, positions per split (multiple of 32), splits,
+    // blocks of a split share an XCD, ceil(2^32 / (Wi + 1)), ceil(2^32 / (Hi + 1))
+    int nimg, Qtot, q_per_split, splits, xcd_remap;
+    unsigned magW, magH;
 };
 int launch_pwgrad(PwgradParams p, size_t slab_floats, hipStream_t s);     // returns the slabs written (0 = nothing launched)
+// pwgrad_ring.hip: 3x3 / stride 1 on the wide maps, X staged once per block through a ring of padded positions
+bool pwgrad_ring_takes(const PwgradParams& p);
+int launch_pwgrad_ring(PwgradParams p, size_t slab_floats, hipStream_t s);
 bool pwgrad_takes(int M, int Ci, int ksz, long long npix, long long xpix, int Wi, int pad);
 void launch_igemm(IgemmParams p, int groups, hipStream_t s);
 // pconv.hip: the same GEMM with both operands as block-major bf16 planes (p.Wsp, p.Xp); p.nsteps is set by the launcher

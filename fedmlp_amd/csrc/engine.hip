@@ -1170,8 +1170,9 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
         q.sp = e->products;
         int sk;
         {
-            ProfScope ps(e, c.cout_p >= 128 ? 3 : 4, 2.0 * c.macs_per_img * imgs);
-            sk = launch_pwgrad(q, e->slab_floats, e->st);
+            const bool ring = pwgrad_ring_takes(q);
+            ProfScope ps(e, ring ? 8 : (c.cout_p >= 128 ? 3 : 4), 2.0 * c.macs_per_img * imgs);
+            sk = ring ? launch_pwgrad_ring(q, e->slab_floats, e->st) : launch_pwgrad(q, e->slab_floats, e->st);
         }
         if (sk > 0) k_reduce_slabs(e->ws_slab, e->grad + c.w_off, sk, (int64_t)c.w_numel, e->st);
         else soft(e, hipErrorInvalidValue);

@@ -59,6 +59,12 @@ __device__ __forceinline__ void pc_divmod(int x, int d, float rcp, int& q, int& 
     if (r < 0) { --q; r += d; }
     else if (r >= d) { ++q; r -= d; }
 }
+// v of the lane a DPP control selects (quad_perm / row_ror: lanes of the same row of 16): a cross-lane move on the VALU, where
+// __shfl_xor is an LDS instruction (ds_bpermute_b32)
+template <int CTRL> __device__ __forceinline__ float pc_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3], const sp_u32x4 (&b)[3], f32x4 v)
 {
     return mfma_split<SP>(a[0], a[1], a[2], b[0], b[1], b[2], v);
@@ -603,12 +609,13 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    // sum over the 16 pixels of the row of lanes; lane li = 0 receives, level by level, the partners the xor
+                    // butterfly 1, 2, 4, 8 would hand it: quad_perm [1,0,3,2], [2,3,0,1], row_ror:12 (lane i <- i + 4), row_ror:8
                     float u = s1[q], v = s2[q];
-#pragma unroll
-                    for (int d = 1; d < 16; d <<= 1) {
-                        u += __shfl_xor(u, d);
-                        v += __shfl_xor(v, d);
-                    }
+                    u += pc_dpp<0xB1>(u); v += pc_dpp<0xB1>(v);
+                    u += pc_dpp<0x4E>(u); v += pc_dpp<0x4E>(v);
+                    u += pc_dpp<0x12C>(u); v += pc_dpp<0x12C>(v);
+                    u += pc_dpp<0x128>(u); v += pc_dpp<0x128>(v);
                     if (li == 0) {
                         const int ml = wm * (16 * FR) + 16 * r + 4 * lg + q;
                         red[(wn * BM + ml) * 2 + 0] = u;
