@@ -148,6 +148,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     unsigned Bfd[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) Bfd[d] = Bs + wn * (16 * FC) * 64 + (li + d) * 64 + ((lg ^ (((li + d) >> 1) & 3)) << 4);
+    // TS: a lane whose pixel has no neighbour under the tap's column shift (the neighbour lies in another image row) reads its
+    // fragment from the stage's zero rows -- ONE select on the address per column where masking the fragment took twelve on
+    // the registers.  Zc[c] + the read's own offset (plane, 16 c rows) = row BN + 2 + (li & 7), chunk lg of the plane
+    unsigned Zc[FC];
+#pragma unroll
+    for (int c = 0; c < FC; ++c) Zc[c] = Bs + (unsigned)((BN + 2 + (li & 7) - 16 * c) * 64 + lg * 16);
     // DMA instructions this wave issues per K-step (A jobs + 3 planes x its B row groups): the counted vmcnt of NS = 3
     const int ngrpB = (wave + 8 * (RGB - 1) < GB) ? RGB : RGB - 1;
     constexpr int NW_HI = JA + 3 * RGB;                                            // waves that hold the full share
@@ -162,7 +168,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         bool first;                              // the block's first segment (slab slot 0)
         unsigned voffA, voffB[RGB], vmask[RGB];
         int icc_b, it_b;                         // (channel block, tap) cursor of the next B step to be issued (TS: it_b = kernel row)
-        unsigned cmask;                          // TS: bit 2c = the pixel of column tile c has a left neighbour in its image row, 2c + 1 = a right one
+        // TS: lane masks (wave-uniform; the four 16-lane rows of a wave hold the same pixels): bit li = the pixel of lane row li in
+        // column tile c has a left neighbour in its image row, bit 16 + li = a right one
+        unsigned mLR[FC];
     };
     auto decode = [&](Seg& g) {                  // takes the next segment off the block's range [w, wend)
         g.tile = (int)((unsigned)w / (unsigned)nsteps);              // (total_steps < 2^31: the launcher checks)
@@ -182,7 +190,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         for (int i = 0; i < RGB; ++i) {
             // TS: stage row r holds pixel n0 - 1 + r (one halo pixel on either side of the tile)
             const int n = g.n0 + 16 * (wave + 8 * i) + drow - (TS ? 1 : 0);
-            const bool rv = n >= 0 && n < npix && i < ngrpB;
+            // (TS: the rows past the halo, BN + 2 .. 16 GB - 1, are the stage's ZERO rows)
+            const bool rv = n >= 0 && n < npix && i < ngrpB && (!TS || 16 * (wave + 8 * i) + drow < BN + 2);
             const int nn = rv ? n : 0;
             int img, rem, hg, wg;
             pc_divmod(nn, HWg, rcpHW, img, rem);
@@ -210,17 +219,16 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         if constexpr (TS) {
             g.icc_b = g.k0 / 9;
             g.it_b = (g.k0 - g.icc_b * 9) / 3;
-            unsigned cm = 0;
 #pragma unroll
             for (int c = 0; c < FC; ++c) {
                 const int n = g.n0 + wn * (16 * FC) + 16 * c + li;
                 int img, rem, hg, wg;
                 pc_divmod(n, HWg, rcpHW, img, rem);
                 pc_divmod(rem, p.Wg, rcpW, hg, wg);
-                cm |= (wg > 0 ? 1u : 0u) << (2 * c);
-                cm |= (wg < p.Wg - 1 ? 1u : 0u) << (2 * c + 1);
+                const unsigned bl = (unsigned)__builtin_amdgcn_ballot_w64(wg > 0) & 0xffffu;
+                const unsigned br = (unsigned)__builtin_amdgcn_ballot_w64(wg < p.Wg - 1) & 0xffffu;
+                g.mLR[c] = (unsigned)__builtin_amdgcn_readfirstlane((int)(bl | (br << 16)));
             }
-            g.cmask = cm;
         } else {
             g.icc_b = g.k0 / ntaps;
             g.it_b = g.k0 - g.icc_b * ntaps;
@@ -304,9 +312,10 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     }
 #define PC_READB(BASE, C, DST)                                                                  \
     {                                                                                           \
-        DST[0] = pc_lds_read128<(0 * BROWS + 16 * (C)) * 64>(BASE);                             \
-        DST[1] = pc_lds_read128<(1 * BROWS + 16 * (C)) * 64>(BASE);                             \
-        DST[2] = pc_lds_read128<(2 * BROWS + 16 * (C)) * 64>(BASE);                             \
+        const unsigned base_ = (BASE);                                                          \
+        DST[0] = pc_lds_read128<(0 * BROWS + 16 * (C)) * 64>(base_);                            \
+        DST[1] = pc_lds_read128<(1 * BROWS + 16 * (C)) * 64>(base_);                            \
+        DST[2] = pc_lds_read128<(2 * BROWS + 16 * (C)) * 64>(base_);                            \
     }
     // the rolling B buffers: column c of a step of register parity PAR sits in Bb[(c + PAR * FC) & 1] (odd FC: the parity of the
     // first column alternates from step to step, so the next step's column 0 never lands on the column still in use)
@@ -351,15 +360,14 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         };
         const int U1 = (k1 - 1) / 3;
         auto bsel = [&](int d) { return d == 0 ? Bfd[0] : (d == 1 ? Bfd[1] : Bfd[2]); };
-        // a fragment column whose pixels' shifted neighbours lie in another image row reads zeros (d = dw + 1 of the step's tap)
-        auto maskB = [&](sp_u32x4 (&b)[3], int c, int d) {
-            if (d != 1) {
-                const bool ok = (cur.cmask >> (2 * c + (d == 2 ? 1 : 0))) & 1u;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) b[pl][i] = ok ? b[pl][i] : 0u;
-            }
+        // fragment base of column tile c under column shift d - 1 in the B slot at byte offset so: the shifted rows, or the zero rows
+        auto colbase = [&](int c, int d, unsigned so) -> unsigned {
+            const unsigned h = d == 0 ? (cur.mLR[c] & 0xffffu) : (cur.mLR[c] >> 16);
+            const unsigned w32 = d == 1 ? ~0u : (h | (h << 16));
+            const unsigned long long m = (unsigned long long)w32 | ((unsigned long long)w32 << 32);
+            unsigned r;
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(Zc[c] + so), "v"(bsel(d) + so), "s"(m));
+            return r;
         };
         if constexpr (TS) {
             it_cur = k0 % 9; Ucur = k0 / 3;
@@ -375,17 +383,14 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         PC_READA(Af0, 1, A0[1]);
         if constexpr (FR == 4) { PC_READA(Af0, 2, A0[2]); PC_READA(Af0, 3, A0[3]); }
         if constexpr (TS) {
-            const unsigned b0 = bsel(tap_d(it_cur));
-            PC_READB(b0, 0, Bb[0]);
+            PC_READB(colbase(0, tap_d(it_cur), 0u), 0, Bb[0]);
         } else
             PC_READB(Bf0, 0, Bb[0]);
         if constexpr (D2) {
-            if constexpr (TS) { const unsigned b0 = bsel(tap_d(it_cur)); PC_READB(b0, 1, Bb[1]); }
+            if constexpr (TS) { PC_READB(colbase(1, tap_d(it_cur), 0u), 1, Bb[1]); }
             else PC_READB(Bf0, 1, Bb[1]);
         }
         PC_LGKM0();
-        if constexpr (TS) maskB(Bb[0], 0, tap_d(it_cur));
-        if constexpr (TS && D2) maskB(Bb[1], 1, tap_d(it_cur));
         __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + NS)
         asm volatile("" ::: "memory");
         if (k0 + NS < k1) issueA(cur, k0 + NS, 0);
@@ -399,18 +404,20 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             constexpr bool FULL = decltype(full_c)::value;
             const int ib1 = (ib + 1 == NS) ? 0 : ib + 1;
             const unsigned a_nxt = Af0 + ib1 * SA;
-            unsigned b_cur, b_nxt;
+            unsigned b_cur = 0, b_nxt = 0, so_cur = 0, so_nxt = 0;       // (TS: slot byte offsets; the bases come from colbase)
             int d_cur = 1, d_nxt = 1;                // TS: dw + 1 of this step's / the next step's tap
             bool row_end = false;                    // TS: this step is the last of its kernel row
             if constexpr (TS) {
                 const int it1 = it_cur == 8 ? 0 : it_cur + 1;
                 d_cur = tap_d(it_cur); d_nxt = tap_d(it1);
                 row_end = it_cur == 2 || it_cur == 5 || it_cur == 8;
-                b_cur = bsel(d_cur) + ub * SB;
-                b_nxt = bsel(d_nxt) + (row_end ? ub ^ 1 : ub) * SB;
+                so_cur = (unsigned)(ub * SB);
+                so_nxt = (unsigned)((row_end ? ub ^ 1 : ub) * SB);
             } else {
                 b_cur = Bf0 + ib * SB; b_nxt = Bf0 + ib1 * SB;
             }
+            auto bc = [&](int c) { if constexpr (TS) return colbase(c, d_cur, so_cur); else return b_cur; };
+            auto bn = [&](int c) { if constexpr (TS) return colbase(c, d_nxt, so_nxt); else return b_nxt; };
             if constexpr (D2) {
                 // B fragments two columns ahead: Bb[c] = column c.  At the start of a step columns 0 and 1 are in registers (read
                 // during the previous step's columns 2, 3); columns 2, 3 and the next step's A fragments are read behind the
@@ -418,8 +425,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 // stage's B columns and the next step's A fragments are in registers.
                 const bool more = FULL || s + 1 < k1;
                 if (more) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }
-                PC_READB(b_cur, 2, Bb[2]);
-                PC_READB(b_cur, 3, Bb[3]);
+                PC_READB(bc(2), 2, Bb[2]);
+                PC_READB(bc(3), 3, Bb[3]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < FR; ++r) acc[r][0] = pc_mfma<SP>(Ac[r], Bb[0], acc[r][0]);
@@ -428,10 +435,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wait_dma(FULL);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (TS) { maskB(Bb[2], 2, d_cur); maskB(Bb[3], 3, d_cur); }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (more) { PC_READB(b_nxt, 0, Bb[0]); PC_READB(b_nxt, 1, Bb[1]); }
+                if (more) { PC_READB(bn(0), 0, Bb[0]); PC_READB(bn(1), 1, Bb[1]); }
                 if constexpr (TS) {
                     // A first, then the B row: the next barrier waits for the A stage only and leaves the row in flight
                     if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
@@ -447,7 +453,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 for (int r = 0; r < FR; ++r) acc[r][3] = pc_mfma<SP>(Ac[r], Bb[3], acc[r][3]);
                 PC_LGKM0();
                 if constexpr (TS) {
-                    if (more) { maskB(Bb[0], 0, d_nxt); maskB(Bb[1], 1, d_nxt); }
                     if (row_end) { ub ^= 1; ++Ucur; }
                     it_cur = it_cur == 8 ? 0 : it_cur + 1;
                     if (b_age < 3) ++b_age;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             // of the column's MFMAs and are waited for at its end
 #define PC_COLUMN(C)                                                                                             \
             {                                                                                                    \
-                PC_READB(b_cur, (C) + 1, Bb[PC_BI((C) + 1, PAR)]);                                               \
+                PC_READB(bc((C) + 1), (C) + 1, Bb[PC_BI((C) + 1, PAR)]);                                         \
                 if (FULL || s + 1 < k1) {                                                                        \
                     if constexpr (FR == 4 && FC == 4) {                                                          \
                         if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }        \
@@ -476,7 +481,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[PC_BI(C, PAR)], acc[r][C]); \
                 PC_LGKM0();                                                                                      \
-                if constexpr (TS) maskB(Bb[PC_BI((C) + 1, PAR)], (C) + 1, d_cur);                                \
             }
             PC_COLUMN(0)
             PC_COLUMN(1)
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 wait_dma(FULL);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (FULL || s + 1 < k1) PC_READB(b_nxt, 0, Bb[PC_BI(0, PAR ^ 1)]);
+            if (FULL || s + 1 < k1) PC_READB(bn(0), 0, Bb[PC_BI(0, PAR ^ 1)]);
             if constexpr (TS) {
                 // the last tap of a kernel row has consumed its B slot: it takes the row after next.  A first, then the B row: the
                 // next barrier waits for the A stage only and leaves the row in flight
@@ -507,7 +511,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[PC_BI(FC - 1, PAR)], acc[r][FC - 1]);
             PC_LGKM0();
             if constexpr (TS) {
-                if (FULL || s + 1 < k1) maskB(Bb[PC_BI(0, PAR ^ 1)], 0, d_nxt);
                 if (row_end) { ub ^= 1; ++Ucur; }
                 it_cur = it_cur == 8 ? 0 : it_cur + 1;
                 if (b_age < 3) ++b_age;
