@@ -359,14 +359,24 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             }
         };
         const int U1 = (k1 - 1) / 3;
-        auto bsel = [&](int d) { return d == 0 ? Bfd[0] : (d == 1 ? Bfd[1] : Bfd[2]); };
-        // fragment base of column tile c under column shift d - 1 in the B slot at byte offset so: the shifted rows, or the zero rows
-        auto colbase = [&](int c, int d, unsigned so) -> unsigned {
-            const unsigned h = d == 0 ? (cur.mLR[c] & 0xffffu) : (cur.mLR[c] >> 16);
-            const unsigned w32 = d == 1 ? ~0u : (h | (h << 16));
+        // c ? b : a for a wave-uniform c, as ONE v_cndmask (the compiler's own form of a uniform select between vector
+        // registers is a branch: three per fragment column in this loop)
+        auto usel = [&](unsigned a, unsigned b, bool c) -> unsigned {
+            const unsigned w32 = (unsigned)__builtin_amdgcn_readfirstlane(c ? -1 : 0);
             const unsigned long long m = (unsigned long long)w32 | ((unsigned long long)w32 << 32);
             unsigned r;
-            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(Zc[c] + so), "v"(bsel(d) + so), "s"(m));
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+            return r;
+        };
+        // the shifted fragment rows under column shift d - 1, slot byte offset so
+        auto bsel = [&](int d, unsigned so) { return usel(usel(Bfd[2], Bfd[1], d == 1), Bfd[0], d == 0) + so; };
+        // fragment base of column tile c: the shifted rows (real), or the zero rows where the lane's pixel has no neighbour
+        auto colbase = [&](int c, int d, unsigned so, unsigned real) -> unsigned {
+            const unsigned h = d == 0 ? (cur.mLR[c] & 0xffffu) : (cur.mLR[c] >> 16);
+            const unsigned w32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(d == 1 ? ~0u : (h | (h << 16))));
+            const unsigned long long m = (unsigned long long)w32 | ((unsigned long long)w32 << 32);
+            unsigned r;
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(Zc[c] + so), "v"(real), "s"(m));
             return r;
         };
         if constexpr (TS) {
@@ -383,11 +393,11 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         PC_READA(Af0, 1, A0[1]);
         if constexpr (FR == 4) { PC_READA(Af0, 2, A0[2]); PC_READA(Af0, 3, A0[3]); }
         if constexpr (TS) {
-            PC_READB(colbase(0, tap_d(it_cur), 0u), 0, Bb[0]);
+            PC_READB(colbase(0, tap_d(it_cur), 0u, bsel(tap_d(it_cur), 0u)), 0, Bb[0]);
         } else
             PC_READB(Bf0, 0, Bb[0]);
         if constexpr (D2) {
-            if constexpr (TS) { PC_READB(colbase(1, tap_d(it_cur), 0u), 1, Bb[1]); }
+            if constexpr (TS) { PC_READB(colbase(1, tap_d(it_cur), 0u, bsel(tap_d(it_cur), 0u)), 1, Bb[1]); }
             else PC_READB(Bf0, 1, Bb[1]);
         }
         PC_LGKM0();
@@ -416,8 +426,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             } else {
                 b_cur = Bf0 + ib * SB; b_nxt = Bf0 + ib1 * SB;
             }
-            auto bc = [&](int c) { if constexpr (TS) return colbase(c, d_cur, so_cur); else return b_cur; };
-            auto bn = [&](int c) { if constexpr (TS) return colbase(c, d_nxt, so_nxt); else return b_nxt; };
+            if constexpr (TS) { b_cur = bsel(d_cur, so_cur); b_nxt = bsel(d_nxt, so_nxt); }
+            auto bc = [&](int c) { if constexpr (TS) return colbase(c, d_cur, so_cur, b_cur); else return b_cur; };
+            auto bn = [&](int c) { if constexpr (TS) return colbase(c, d_nxt, so_nxt, b_nxt); else return b_nxt; };
             if constexpr (D2) {
                 // B fragments two columns ahead: Bb[c] = column c.  At the start of a step columns 0 and 1 are in registers (read
                 // during the previous step's columns 2, 3); columns 2, 3 and the next step's A fragments are read behind the
