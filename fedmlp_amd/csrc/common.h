@@ -26,7 +26,8 @@ __device__ __forceinline__ float fm_swish_f32(float v)
 // Tuning knobs of the kernels (tile orders, split counts, variant choices that were measured and settled): the shipped
 // library uses the defaults; a `make TUNING=1` build (-DFM_TUNING) reads them from the environment for measurements.
 // The few RUNTIME switches the shipped library does read are listed in DESIGN.md section 9, each with the test that
-// exercises it (FM_IGEMM_BLOCKS, FM_STEM_PACKED, FM_BN_MASK_FROM_Y, FM_EW_ROWS / FM_EW_ROWS_F32, FM_DW_GENERIC, FM_FUSE_GATE).
+// exercises it (FM_MFMA_SPLIT, FM_PLANES, FM_IGEMM_BLOCKS, FM_STEM_PACKED, FM_BN_MASK_FROM_Y, FM_EW_ROWS / FM_EW_ROWS_F32,
+// FM_DW_GENERIC, FM_FUSE_GATE; FM_DEBUG_REUSE_PLANES belongs to the timing probes of the test hooks).
 inline int fm_tune(const char* name, int dflt)
 {
 #ifdef FM_TUNING

@@ -273,12 +273,12 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
 }
 
 // the ring form takes: 3x3, stride 1, pad 1; whole 64-channel tiles on both sides; rows short enough for the ring (a tap shift of
-// W + 2 positions within the 64 the ring keeps behind the current step); maps from FM_PWGRAD_RING_MINW (28) pixels wide up -- below
-// that the padding positions cost more MFMA work than the form saves.  FM_PWGRAD_RING=0 keeps pwgrad.hip everywhere.
+// W + 2 positions within the 64 the ring keeps behind the current step); maps from 28 pixels wide up -- below that the padding
+// positions cost more MFMA work than the form saves (measured with the tuning build's FM_PWGRAD_RING_MINW=7: 14 x 14 maps 369 vs
+// 346 us, 7 x 7 maps 366 vs 342 us per launch at 256 images; FM_PWGRAD_RING=0 there keeps pwgrad.hip everywhere).
 bool pwgrad_ring_takes(const PwgradParams& p)
 {
-    static const int on = getenv("FM_PWGRAD_RING") ? atoi(getenv("FM_PWGRAD_RING")) : 1;
-    static const int minw = getenv("FM_PWGRAD_RING_MINW") ? atoi(getenv("FM_PWGRAD_RING_MINW")) : 28;
+    static const int on = fm_tune("FM_PWGRAD_RING", 1), minw = fm_tune("FM_PWGRAD_RING_MINW", 28);
     if (!on || p.ksz != 3 || p.pad != 1 || p.stride != 1 || p.Ho != p.Hi || p.Wo != p.Wi) return false;
     if (p.M % 64 != 0 || p.Ci % 64 != 0 || p.Wi + 2 > 64 || p.Wi < minw) return false;
     const long long nimg = p.npix / ((long long)p.Ho * p.Wo);

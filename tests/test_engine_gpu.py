@@ -416,3 +416,24 @@ def test_step_in_the_three_product_forms(monkeypatch):
     monkeypatch.delenv("FM_MFMA_SPLIT")
     for mode in (6, 9):
         assert abs(outs[mode][0] - outs[0][0]) <= 1e-6 * abs(outs[0][0]), (mode, outs[mode][0], outs[0][0])
+    # FM_PLANES=0 (read at fm_create): the same product form through the fp32-operand kernels (igemm.hip / wgrad.hip split the
+    # operands themselves) instead of the producer-written bf16 planes (pconv.hip / pwgrad*.hip): same arithmetic, another order
+    # of the partial sums -- the step passes the same oracle check and the loss agrees to 1e-6
+    monkeypatch.setenv("FM_PLANES", "0")
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    try:
+        assert e.products == 6 and not e.planes
+        _stage1_step_check(e, "stage1, FM_PLANES=0")
+        _load(e)
+        e.teacher_snapshot()
+        lo = torch.zeros(1, device="cuda")
+        e.step_stage1(x1.cuda(), x2.cuda(), y.cuda(), mask, 1, 8, lo)
+        assert abs(lo.item() - outs[6][0]) <= 1e-6 * abs(outs[6][0]), (lo.item(), outs[6][0])
+    finally:
+        e.close()
+    monkeypatch.delenv("FM_PLANES")
+    e = Engine("Resnet18", C_, HW, HW, 16)
+    try:
+        assert e.planes
+    finally:
+        e.close()
