@@ -362,8 +362,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         // c ? b : a for a wave-uniform c, as ONE v_cndmask (the compiler's own form of a uniform select between vector
         // registers is a branch: three per fragment column in this loop)
         auto usel = [&](unsigned a, unsigned b, bool c) -> unsigned {
-            const unsigned w32 = (unsigned)__builtin_amdgcn_readfirstlane(c ? -1 : 0);
-            const unsigned long long m = (unsigned long long)w32 | ((unsigned long long)w32 << 32);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(c);      // (every lane is active: all ones or zero, a scalar pair)
             unsigned r;
             asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
             return r;
