@@ -247,8 +247,8 @@ def family_traffic(prefix, args):
     """launch-weighted mean HBM bytes per launch over every profiled kernel whose name contains `prefix`"""
     try:
         doc = pmc_doc(args)[0]
-        ks = [v for k, v in doc["kernels"].items()
-              if prefix in k.replace(" ", "").replace("false", "0").replace("true", "1")]   # (older profiles: bool STEM)
+        norm = lambda t: t.replace(" ", "").replace("false", "0").replace("true", "1")   # (older profiles: bool STEM)
+        ks = [v for k, v in doc["kernels"].items() if norm(prefix) in norm(k)]
         n = sum(v["launches"] for v in ks)
         return int(sum(v["launches"] * v["hbm_bytes_per_launch_corrected"] for v in ks) / n) if n else None
     except Exception:
@@ -312,9 +312,10 @@ def measured_traffic(kernel_name, args):
     doc, _ = pmc_doc(args)
     if doc is None:
         return None
-    key = kernel_name.replace(" ", "")
+    norm = lambda t: t.replace(" ", "").replace("false", "0").replace("true", "1")   # (older profiles: bool STEM)
+    key = norm(kernel_name)
     for k, v in doc["kernels"].items():
-        if key in k.replace(" ", "").replace("false", "0").replace("true", "1"):     # (older profiles: bool STEM)
+        if key in norm(k):
             return v["hbm_bytes_per_launch_corrected"]
     return None
 

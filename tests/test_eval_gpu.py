@@ -147,7 +147,8 @@ def test_map_after_converged_training_matches_oracle():
     on that plateau and by 0.3-0.5 % between two hosts (order 3: 0.8342 in the build container, 0.8325 and 0.8364 on two GPU
     boxes' hosts), and the HIP side of that pair measured 0.8302, 0.8284 and 0.8216 under three roundings of the engine's
     GEMMs (fp32 MFMA of rounds 3 and 4, the bf16-partial-product form).  So one pair is bounded by 2 % absolute and the
-    statement is the MEAN over the three orders, below 0.75 % (measured: mAP -0.48 / -0.79 / +0.69 %, mean -0.19 %; AUROC -0.07 %).  The 32-seed paired study
+    statement is the MEAN over the three orders, below 0.75 % (measured under round 5's kernels, profiles/r05/parity_map_converged.json: mAP -0.49 / +0.50 / +0.52 %, mean
+    +0.18 %; AUROC +0.03 %; round 4's kernels: -0.14 / -0.13 / +0.34 %).  The 32-seed paired study
     below is the statistical form; the north star's +-0.2 % needs a real dataset to be decidable."""
     import json
     g = load_golden("map_converged_oracle.json")
