@@ -578,22 +578,28 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 pend_tile = tile;
                 do_epilogue = false;
             } else {
+                int* arrived = reinterpret_cast<int*>(fsmem);
                 if (tid == 0) {
                     const int need = b_last - b_first;
-                    // (bounded: a lost part shows up as a wrong result in the parity tests, not as a hung GPU)
-                    for (int it = 0; it < (1 << 22); ++it) {
-                        if (__hip_atomic_load(p.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == need) break;
-                        __builtin_amdgcn_s_sleep(4);
+                    // bounded (a few seconds: the parts were stored a whole range ago; only a block that was never scheduled can be
+                    // missing): a lost part must not hang the GPU -- it POISONS the tile instead (NaN: the step's loss says so)
+                    int got = 0;
+                    for (int it = 0; it < (1 << 22) && !got; ++it) {
+                        got = __hip_atomic_load(p.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == need;
+                        if (!got) __builtin_amdgcn_s_sleep(4);
                     }
                     __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    *arrived = got;
                 }
                 __syncthreads();
+                const float first = *arrived ? 0.f : __builtin_nanf("");
+                PC_SYNC_LDS();                  // (the word is scratch of the epilogue below)
 #pragma unroll
                 for (int r = 0; r < FR; ++r)
 #pragma unroll
-                    for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f} + acc[r][c];
+                    for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{first, first, first, first} + acc[r][c];
                 for (int bb = b_first + 1; bb <= b_last; ++bb) {
                     const float* src = p.slab + (size_t)bb * 2 * (BM * BN);
 #pragma unroll
