@@ -1,6 +1,6 @@
 """bench.py's stdout contract: the LAST line is the one the driver parses; it holds the contract's fields only and
 stays under 1 800 characters (the driver keeps a stdout tail of a few KB: round 4's 25 KB line arrived without its head
-and was not parsed).  Every leg is its own short line printed before it.  Canned record: profiles/r04's full run."""
+and was not parsed).  Every leg is its own short line printed before it.  Canned records: the full runs of rounds 4 and 5."""
 import io
 import json
 import os
@@ -11,18 +11,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-CANNED = os.path.join(ROOT, "profiles", "r04", "bench_gpus1_with_legs.json")
+import pytest  # noqa: E402
+
+RECORDS = [os.path.join(ROOT, "profiles", "r04", "bench_gpus1_with_legs.json"), os.path.join(ROOT, "profiles", "r05", "bench_legs.json")]
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
-def _canned():
-    with open(CANNED) as f:
+@pytest.fixture(params=RECORDS, ids=["r04", "r05"])
+def canned(request):
+    with open(request.param) as f:
         return json.load(f)
 
 
-def test_headline_line_is_short_and_round_trips():
-    out = _canned()
+def test_headline_line_is_short_and_round_trips(canned):
+    out = canned
     s = bench.compact_line(out, 6)
     assert len(s) < 1800 and "\n" not in s
     d = json.loads(s)
@@ -35,8 +38,8 @@ def test_headline_line_is_short_and_round_trips():
     assert d["roofline"]["frac"] == out["roofline"]["frac"]
 
 
-def test_eight_rank_line_is_short():
-    out = _canned()
+def test_eight_rank_line_is_short(canned):
+    out = canned
     out["n_gpus"] = 8
     out["config"]["per_rank"] = [{"rank": r, "ms_per_step_incl_allreduce": 27.1234, "allreduce_ms_total": 1.234,
                                   "allreduces": 3} for r in range(8)]
@@ -46,8 +49,8 @@ def test_eight_rank_line_is_short():
     assert len(json.loads(s)["config"]["per_rank_ms_per_step"]) == 8
 
 
-def test_emit_prints_legs_first_and_headline_last(tmp_path):
-    out = _canned()
+def test_emit_prints_legs_first_and_headline_last(tmp_path, canned):
+    out = canned
     out["_products"] = 6
     buf = io.StringIO()
     with redirect_stdout(buf):
