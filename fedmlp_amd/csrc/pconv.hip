@@ -30,7 +30,8 @@
 //  * LDS reads are inline asm with explicit waits (issued at the head of a column's 6 FR MFMAs, waited for at its end): the
 //    compiler's own placement put them right in front of their first use.
 //  * Stream-K (as igemm.hip): the (tile, K-step) space is cut into equal contiguous ranges, one per block; partial tiles meet
-//    in a slab, the last arriver sums them in segment order (deterministic) and runs the epilogue.  ResNet's pixel counts are
+//    in a slab: the owner of a tile's head (the designated finisher) sums them in segment order (deterministic) and runs the
+//    epilogue; the others store their part (one slab slot per block: a range starts inside a tile at most once).  ResNet's pixel counts are
 //    49 * 2^k: one-tile-per-block grids leave 23 % of the CUs idle on three of the four layers.
 //  * Epilogues: raw fp32 + BatchNorm partial sums (train forward), folded eval BatchNorm + residual + ReLU with fp32 and /
 //    or plane output (eval forward), raw + residual with strided placement (data gradient, parity classes of stride 2).
@@ -78,8 +79,11 @@ template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3
 // TS ("tap rows shared", 3x3 / stride 1): the three taps of a kernel ROW read the same input pixels shifted by one, so the B stage is
 // loaded ONCE per (channel block, kernel row) as the tile's pixels plus one halo pixel on either side ([3 planes][BN + 2 -> 272
 // rows][64 B], two slots), and the tap's column shift is a row offset of the fragment reads (conflict-free at every offset,
-// brute-force checked); a pixel whose shifted neighbour lies in another image row reads a zero (a select on the fragment
-// registers).  B traffic into LDS per K-step: 48 KB -> 17 KB.
+// brute-force checked); a pixel whose shifted neighbour lies in another image row reads the stage's ZERO rows (rows BN + 2 .. 271,
+// filled by out-of-range DMA offsets): one select on the fragment ADDRESS per column.  B traffic into LDS per K-step: 48 KB -> 17 KB.
+// (the 64-row tiles are bound by a roughly constant per-step issue + synchronisation overhead over only 48 MFMAs per wave and by
+// their per-tile fixed cost at 18 K-steps per tile, tools/probe_phases.py -- not by LDS traffic or DMA latency, which the 64 x 192
+// arm above was built against)
 // -DPC_PHASES (tools/probe_phases.py, a timing-only build): wave 0 of every block sums the shader-clock cycles it spends in each
 // phase of a segment (lead wait | barrier | prologue reads | main loop | next segment's decode + lead | fix-up | epilogue | gap)
 #ifdef PC_PHASES
@@ -165,7 +169,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     // A segment = the K-steps [k0, k1) of one tile that this block's range covers, with the per-lane DMA state of the tile
     struct Seg {
         int tile, k0, k1, grp, tn, m0, n0;
-        bool first;                              // the block's first segment (slab slot 0)
         unsigned voffA, voffB[RGB], vmask[RGB];
         int icc_b, it_b;                         // (channel block, tap) cursor of the next B step to be issued (TS: it_b = kernel row)
         // TS: lane masks (wave-uniform; the four 16-lane rows of a wave hold the same pixels): bit li = the pixel of lane row li in
@@ -176,7 +179,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         g.tile = (int)((unsigned)w / (unsigned)nsteps);              // (total_steps < 2^31: the launcher checks)
         g.k0 = (int)(w - (long long)g.tile * nsteps);
         g.k1 = min(nsteps, g.k0 + (int)(wend - w));
-        g.first = (w == (long long)rbk * S);
         w += g.k1 - g.k0;
         g.grp = g.tile / tiles_pg;
         const int tl = g.tile - g.grp * tiles_pg;
