@@ -75,7 +75,6 @@ struct Conv {
     long long sp_off = -1;    // bf16 planes of the forward weights inside fm_engine::wsp_f / twsp_f (2-byte units), -1 = none
     long long bm_off = -1;    // block-major planes of the forward weights inside fm_engine::wbm_f / twbm_f (pconv.hip), -1 = none
     long long wb_off = -1, wbt_off = -1;   // bf16 shadow of a 1x1 conv's weights [cout_p][cin_p] / transposed (bf16 mode)
-    bool last_pro = false;    // the last conv_fwd of this conv carried an operand prologue (decides the bf16 statistics layout)
     double macs_per_img;      // algorithmic MACs (real k, real cin)
     float* y = nullptr;       // raw conv output (train) [max_images][hout][wout][cout]
 };
@@ -160,6 +159,9 @@ struct fm_engine {
     uint8_t* idx0 = nullptr;
     float *GA = nullptr, *GB = nullptr, *GC = nullptr, *GD = nullptr, *GE = nullptr;
     float *ws_stats = nullptr, *ws_part = nullptr, *ws_slab = nullptr;
+    // what ws_stats holds: the BN partial sums of conv `stats_conv`, `stats_tiles_n` tiles per group -- written by the conv_fwd
+    // that launched the GEMM (the count depends on the kernel and on that call's operand prologue), read by the finalize
+    int stats_conv = -1, stats_tiles_n = 0;
     size_t slab_floats = 0;
     float *ca = nullptr, *cb = nullptr, *cc = nullptr;
     float *feat = nullptr, *logits = nullptr, *tfeat = nullptr, *tlogits = nullptr, *dlogits = nullptr;
@@ -986,12 +988,26 @@ bool conv_uses_pconv(const fm_engine* e, const Conv& c, int imgs)
 
 // xp: the input's block-major planes (planes mode; null = made here from x); yp: also / only write the output's planes
 // (eval epilogue; y may then be null)
+// partial-sum tiles per group the forward GEMM of conv c leaves in `stats` (pro_gate: this call carries an operand prologue)
+static int stats_tiles_for(fm_engine* e, const Conv& c, int imgs_per_group, int groups, bool pro_gate)
+{
+    if (e->precision && (c.k == 1 || c.cin == 3))
+        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, pro_gate, c.hout * c.wout);
+    if (conv_uses_pconv(e, c, imgs_per_group * groups)) return (imgs_per_group * c.hout * c.wout + pconv_tile_n(c.cout_p) - 1) / pconv_tile_n(c.cout_p);
+    const int bn = igemm_tile_n(c.cout_p, c.cin == 3);
+    return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
+}
+
 void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, int imgs, int groups,
               const float* scale, const float* shift, const float* res, int relu, float* stats,
               const Prologue* pro = nullptr, const unsigned short* xp = nullptr, unsigned short* yp = nullptr,
               const unsigned short* resp = nullptr)
 {
     Conv& c = e->convs[ci];
+    if (stats) {
+        e->stats_conv = ci;
+        e->stats_tiles_n = stats_tiles_for(e, c, imgs / groups, groups, pro && pro->gate);
+    }
     if (conv_uses_pconv(e, c, imgs)) {
         IgemmParams p{};
         p.xp_pix = (long long)imgs * c.hin * c.win;
@@ -1020,7 +1036,6 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     if (e->precision && (c.k == 1 || stem16)) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
         PwParams q{};
         q.zeros = e->zeros;
-        c.last_pro = pro && pro->gate;
         q.W = shadow_of(e, S) + c.wb_off;
         q.X = reinterpret_cast<const bf16*>(stem16 ? e->stem_col : x); q.Y = reinterpret_cast<bf16*>(y);
         q.M = c.cout_p; q.K = stem16 ? c.Kw : c.cin_p;
@@ -1067,14 +1082,13 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     launch_igemm(p, groups, e->st);
 }
 
+// tiles per group of the partial sums conv ci's forward left in ws_stats (set by that conv_fwd call; asking for another conv's
+// is a graph error: the buffer holds one conv's partials at a time)
 int stats_tiles(fm_engine* e, int ci, int imgs_per_group, int groups)
 {
-    const Conv& c = e->convs[ci];
-    if (e->precision && (c.k == 1 || c.cin == 3))
-        return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, c.last_pro, c.hout * c.wout);
-    if (conv_uses_pconv(e, c, imgs_per_group * groups)) return (imgs_per_group * c.hout * c.wout + pconv_tile_n(c.cout_p) - 1) / pconv_tile_n(c.cout_p);
-    const int bn = igemm_tile_n(c.cout_p, c.cin == 3);
-    return (imgs_per_group * c.hout * c.wout + bn - 1) / bn;
+    (void)imgs_per_group; (void)groups;
+    if (e->stats_conv != ci) soft(e, hipErrorInvalidValue);
+    return e->stats_tiles_n;
 }
 
 // dx[imgs][hin][win][cin] = dgrad(dy[imgs][hout][wout][cout]); res: optional residual added
