@@ -2,6 +2,7 @@
 """CPU stand-in for `python bench.py --gpus N`: same launch logic (fedmlp_amd.launch), gloo instead
 of RCCL, so the self-launch path (parent spawns N ranks, rank 0 prints ONE JSON line, the parent
 exits with the children's code) is covered without a GPU."""
+import datetime
 import argparse
 import json
 import os
@@ -24,7 +25,7 @@ def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus
     if world > 1:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
     if rank == args.fail_rank:
         sys.exit(3)
     t = torch.tensor([float(rank + 1)])

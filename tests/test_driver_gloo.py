@@ -3,6 +3,7 @@
 code and against the reference-surface FedAvg / FedAvg_tao / FedAvg_proto (pinned on the reference's KATs in
 test_oracle_golden.py) -- state, num_batches_tracked, tao and prototypes incl. the NaN rows of a class nobody annotates,
 the 1.0 tao of a class nobody misses and a NaN prototype row of an ACTIVE class (0/0 of the unguarded first pass)."""
+import datetime
 import os
 import socket
 
@@ -49,7 +50,7 @@ def _run_rank(rank, world, with_tp=True):
 
 def _worker(rank, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=180))
     state, cnt, tao, proto = _run_rank(rank, 2)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), state=state, cnt=cnt, tao=tao, proto=proto)
     dist.barrier()

@@ -1,6 +1,7 @@
 """The N>1 path on CPU: world_size-2 `gloo` process groups run the same all-reduce
 forms the 8-GPU job runs over RCCL (fedmlp_amd/fedavg.py) and are checked against
 the single-process reference-surface FedAvg / FedAvg_tao / FedAvg_proto."""
+import datetime
 import os
 import socket
 
@@ -56,7 +57,7 @@ CLASS_NEG = [[1], [0], [0, 1], [0, 1]]
 
 def _worker(rank, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=180))
     state, cnt, t, proto = _inputs(rank)
     w = N_LOCAL[rank] / float(sum(N_LOCAL))
     eng = FakeEngine(state.clone(), cnt.copy())
@@ -124,7 +125,7 @@ class FakeCommEngine:
 def _comm_worker(rank, port, out_dir, case):
     from fedmlp_amd.fedavg import comm_init
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=180))
     eng = FakeCommEngine(fail_init=(case == "init_fails_on_rank1" and rank == 1), fail_id=(case == "id_fails" and rank == 0),
                          fail_preflight=(case == "preflight_fails_on_rank1" and rank == 1))
     try:
