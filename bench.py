@@ -73,7 +73,7 @@ def kernel_names(sp=None, planes=False):
     Ci % 32 == 0: the 32-k-stage instantiations; the last two template arguments = partial products, weight planes)."""
     sp = mfma_products() if sp is None else sp
     if planes and sp:      # planes mode (csrc/pconv.hip, pwgrad.hip): both GEMM operands arrive as bf16 planes
-        return {0: f"pconv_kernel<4,4,2,{sp},true>", 1: f"pconv_kernel<2,4,2,{sp},true>", 2: f"igemm_kernel<64,256,4,2,2,32,{sp},0>",
+        return {0: f"pconv_kernel<4,4,2,{sp},true>", 1: f"pconv_kernel<2,4,2,{sp},true>", 2: f"stem_rows_kernel<{sp}>",
                 3: f"pwgrad_kernel<4,*,{sp}>", 4: f"pwgrad_kernel<2,*,{sp}>", 5: f"wgrad_kernel<64,192,4,3,{sp}> [7x7 stem launch]",
                 6: f"pconv_kernel<4,4,2,{sp},false>", 7: f"pconv_kernel<2,4,2,{sp},false>", 8: f"pwgrad_ring_kernel<{sp}>"}
     wp = 1 if sp else 0

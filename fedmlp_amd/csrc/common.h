@@ -216,6 +216,21 @@ struct PwgradParams {
     int nimg, Qtot, q_per_split, splits, xcd_remap;
     unsigned magW, magH;
 };
+// stem_rows.hip: ResNet-18's 7x7 stem forward from planes of the framed input (four channels per pixel) and resident weight planes
+struct StemRowsParams {
+    const unsigned short* Xp;     // [3 planes][imgs][Hp][Wp][4] bf16
+    const unsigned short* Wst;    // [7 kh][3 planes][64][32] bf16, k = 4 kw + c
+    float* Y;                     // [imgs][Ho][Wo][64]
+    const float* scale;           // eval: folded BatchNorm per channel (with relu), else null
+    const float* shift;
+    float* stats;                 // train: BatchNorm partial sums [group][imgs_per_group * Ho / 4][2][64], else null
+    int imgs, imgs_per_group, Hp, Wp, Ho, Wo, relu, sp;
+    long long plane_bytes;        // imgs * Hp * Wp * 8
+};
+bool stem_rows_takes(int k, int stride, int cout, int hout, int wout, long long plane_bytes);
+int stem_rows_stats_tiles(int imgs_per_group, int hout);
+void launch_stem_rows(StemRowsParams p, hipStream_t s);
+void k_stem_weight_planes(const float* w, unsigned short* dst, int Kw, hipStream_t s);
 int launch_pwgrad(PwgradParams p, size_t slab_floats, hipStream_t s);     // returns the slabs written (0 = nothing launched)
 // pwgrad_ring.hip: 3x3 / stride 1 on the wide maps, X staged once per block through a ring of padded positions
 bool pwgrad_ring_takes(const PwgradParams& p);

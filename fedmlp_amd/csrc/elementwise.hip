@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
+#include "split3.h"
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
@@ -110,8 +111,10 @@ void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, in
 
 // input of the packed 7x7 stem: y [imgs][H + 2*fr_t...] -- a zero-framed NHWC3 image (frame written once at allocation,
 // only the interior here).  src_nhwc3 = 0: x is the caller's NCHW fp32 batch; 1: x is [imgs][H][W][3] (test hook).
+// yp (planes mode, stem_rows.hip): the same framed image as three bf16 planes x = h + m + l of FOUR channels per pixel (the fourth
+// zero), [3][imgs][Hp][Wp][4]: 8 B per pixel and plane
 __global__ void frame_nhwc3_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int H, int W, int Hp, int Wp,
-                                   int top, int left, int src_nhwc3)
+                                   int top, int left, int src_nhwc3, unsigned short* __restrict__ yp, long long yp_plane_elems)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (img, h, w)
     if (i >= n) return;
@@ -125,6 +128,16 @@ __global__ void frame_nhwc3_kernel(const float* __restrict__ x, float* __restric
         v[c] = src_nhwc3 ? x[i * 3 + c] : x[((img * 3 + c) * H + h) * (int64_t)W + w];
     float* o = y + ((img * Hp + h + top) * (int64_t)Wp + w + left) * 3;
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+#if __HIP_DEVICE_COMPILE__
+    if (yp) {
+        sp_u32x4 Hh, Mm, Ll;
+        split3(f32x4{v[0], v[1], v[2], 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, Hh, Mm, Ll);
+        unsigned short* q = yp + ((img * Hp + h + top) * (int64_t)Wp + w + left) * 4;
+        *reinterpret_cast<uint2*>(q) = make_uint2(Hh[0], Hh[1]);
+        *reinterpret_cast<uint2*>(q + yp_plane_elems) = make_uint2(Mm[0], Mm[1]);
+        *reinterpret_cast<uint2*>(q + 2 * yp_plane_elems) = make_uint2(Ll[0], Ll[1]);
+    }
+#endif
 }
 // packed stem: the 8th tap slot of every kernel row multiplies real pixels (the window over-reads one pixel) with a zero
 // weight; its weight GRADIENT is not zero by itself and must not reach Adam
@@ -140,10 +153,11 @@ void k_stem3_mask_grad(float* g, int O, hipStream_t s)
     hipLaunchKernelGGL(stem3_mask_grad_kernel, dim3(cdiv(O * 21, 256)), dim3(256), 0, s, g, O);
 }
 void k_frame_nhwc3(const float* x, float* y, int imgs, int H, int W, int Hp, int Wp, int top, int left, int src_nhwc3,
-                   hipStream_t s)
+                   hipStream_t s, unsigned short* yp, long long yp_plane_elems)
 {
     const int64_t n = (int64_t)imgs * H * W;
-    hipLaunchKernelGGL(frame_nhwc3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, n, H, W, Hp, Wp, top, left, src_nhwc3);
+    hipLaunchKernelGGL(frame_nhwc3_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, x, y, n, H, W, Hp, Wp, top, left, src_nhwc3, yp,
+                       yp_plane_elems);
 }
 
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int T, int Ci, TapList taps)

@@ -156,6 +156,11 @@ struct fm_engine {
     // workspaces
     float *x4 = nullptr, *p0 = nullptr, *dyh0 = nullptr;
     float* x3 = nullptr;      // packed stem: zero-framed NHWC3 input [max_images][H + 6][W + 8][3]
+    // planes mode at 112-pixel stem rows (stem_rows.hip): the framed input as bf16 planes of four channels per pixel
+    // [3][max_images][H + 6][W + 8][4], and the stem's weight planes [7][3][64][32] of the student and of the teacher
+    bool stem_rows = false;
+    unsigned short *x3p = nullptr, *wst = nullptr, *twst = nullptr;
+    long long x3p_plane_elems = 0;
     uint8_t* idx0 = nullptr;
     float *GA = nullptr, *GB = nullptr, *GC = nullptr, *GD = nullptr, *GE = nullptr;
     float *ws_stats = nullptr, *ws_part = nullptr, *ws_slab = nullptr;
@@ -707,6 +712,14 @@ int alloc_workspaces(fm_engine* e)
         const size_t n3 = B * e->convs[0].Hp * e->convs[0].Wp * 3 + 64;      // + slack for the last window's over-read
         DALLOC(e->x3, n3);
         HIPCHK(hipMemset(e->x3, 0, n3 * 4));                                   // the frame stays zero for the engine's life
+        const Conv& c0 = e->convs[0];
+        e->x3p_plane_elems = (long long)B * c0.Hp * c0.Wp * 4;
+        e->stem_rows = e->planes && stem_rows_takes(c0.k, c0.stride, c0.cout_p, c0.hout, c0.wout, e->x3p_plane_elems * 2);
+        if (e->stem_rows) {
+            DALLOC(e->x3p, (size_t)3 * e->x3p_plane_elems + 64);
+            HIPCHK(hipMemset(e->x3p, 0, ((size_t)3 * e->x3p_plane_elems + 64) * 2));
+            DALLOC(e->wst, 7 * 3 * 64 * 32); DALLOC(e->twst, 7 * 3 * 64 * 32);
+        }
     }
     size_t max_stats = 0, max_slab = 0;
     for (auto& c : e->convs) {
@@ -991,6 +1004,7 @@ bool conv_uses_pconv(const fm_engine* e, const Conv& c, int imgs)
 // partial-sum tiles per group the forward GEMM of conv c leaves in `stats` (pro_gate: this call carries an operand prologue)
 static int stats_tiles_for(fm_engine* e, const Conv& c, int imgs_per_group, int groups, bool pro_gate)
 {
+    if (e->stem_rows && c.stem3) return stem_rows_stats_tiles(imgs_per_group, c.hout);
     if (e->precision && (c.k == 1 || c.cin == 3))
         return pw_blocks(imgs_per_group * c.hout * c.wout, groups, c.cout_p, c.cin == 3 ? c.Kw : c.cin_p, pro_gate, c.hout * c.wout);
     if (conv_uses_pconv(e, c, imgs_per_group * groups)) return (imgs_per_group * c.hout * c.wout + pconv_tile_n(c.cout_p) - 1) / pconv_tile_n(c.cout_p);
@@ -1007,6 +1021,16 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
     if (stats) {
         e->stats_conv = ci;
         e->stats_tiles_n = stats_tiles_for(e, c, imgs / groups, groups, pro && pro->gate);
+    }
+    if (e->stem_rows && c.stem3) {           // `x` is ignored: the operand is the framed image's planes (to_nhwc4)
+        StemRowsParams q{};
+        q.Xp = e->x3p; q.Wst = S == e->tstate ? e->twst : e->wst; q.Y = y;
+        q.scale = scale; q.shift = shift; q.stats = stats; q.relu = relu;
+        q.imgs = imgs; q.imgs_per_group = imgs / groups; q.Hp = c.Hp; q.Wp = c.Wp; q.Ho = c.hout; q.Wo = c.wout;
+        q.sp = e->products; q.plane_bytes = e->x3p_plane_elems * 2;
+        ProfScope ps(e, 2, 2.0 * c.macs_per_img * imgs);
+        launch_stem_rows(q, e->st);
+        return;
     }
     if (conv_uses_pconv(e, c, imgs)) {
         IgemmParams p{};
@@ -1294,7 +1318,8 @@ void to_nhwc4(fm_engine* e, const float* const* xs, int groups, int B)
     if (e->convs[0].stem3) {
         const Conv& c = e->convs[0];
         for (int g = 0; g < groups; ++g)
-            k_frame_nhwc3(xs[g], e->x3 + (size_t)g * B * c.Hp * c.Wp * 3, B, e->H, e->W, c.Hp, c.Wp, 3, 3, 0, e->st);
+            k_frame_nhwc3(xs[g], e->x3 + (size_t)g * B * c.Hp * c.Wp * 3, B, e->H, e->W, c.Hp, c.Wp, 3, 3, 0, e->st,
+                          e->stem_rows ? e->x3p + (size_t)g * B * c.Hp * c.Wp * 4 : nullptr, e->x3p_plane_elems);
         return;
     }
     for (int g = 0; g < groups; ++g)
@@ -1416,6 +1441,7 @@ void ensure_packed(fm_engine* e)
     if (e->planes) {
         k_split_weights_bm(e->state, e->wbm_f, e->bm_f, e->n_bm_f, e->n_bm_f_blocks, e->st);
         k_split_weights_bm(nullptr, e->wbm_d, e->bm_d, e->n_bm_d, e->n_bm_d_blocks, e->st);      // planes of the packs just made
+        if (e->stem_rows) k_stem_weight_planes(e->state + e->convs[0].w_off, e->wst, e->convs[0].Kw, e->st);
     } else {
         k_split_weights(e->state, e->wsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
         k_split_weights(nullptr, e->wsp_d, e->split_d, e->n_split_d, e->n_split_d_blocks, e->st);     // planes of the packs just made
@@ -1426,7 +1452,10 @@ void ensure_teacher_shadow(fm_engine* e)
 {
     if (!e->twb_dirty) return;
     if (e->precision) launch_cast_weights(e->tstate, e->twb, e->cast_jobs, e->n_cast_jobs, e->n_cast_blocks, e->st);
-    else if (e->planes) k_split_weights_bm(e->tstate, e->twbm_f, e->bm_f, e->n_bm_f, e->n_bm_f_blocks, e->st);
+    else if (e->planes) {
+        k_split_weights_bm(e->tstate, e->twbm_f, e->bm_f, e->n_bm_f, e->n_bm_f_blocks, e->st);
+        if (e->stem_rows) k_stem_weight_planes(e->tstate + e->convs[0].w_off, e->twst, e->convs[0].Kw, e->st);
+    }
     else k_split_weights(e->tstate, e->twsp_f, e->split_f, e->n_split_f, e->n_split_f_blocks, e->st);
     e->twb_dirty = false;
 }
@@ -2822,7 +2851,7 @@ int fm_debug_conv(fm_engine* e, int32_t op, int32_t conv, const float* x_dev, co
     ARGCHK(imgs >= 1 && imgs <= e->maxB && groups >= 1 && imgs % groups == 0, "imgs/groups");
     Conv& c = e->convs[conv];
     if (c.stem3 && x_dev)       // the packed stem reads the framed copy of its [imgs][H][W][3] input
-        k_frame_nhwc3(x_dev, e->x3, imgs, c.hin, c.win, c.Hp, c.Wp, 3, 3, 1, e->st);
+        k_frame_nhwc3(x_dev, e->x3, imgs, c.hin, c.win, c.Hp, c.Wp, 3, 3, 1, e->st, e->stem_rows ? e->x3p : nullptr, e->x3p_plane_elems);
     ensure_packed(e);           // the forward reads the weight planes, the data gradient the transposed packs
     if (op == 0) {
         ARGCHK(x_dev, "x");

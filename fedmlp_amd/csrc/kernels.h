@@ -22,7 +22,7 @@ void k_ohwi_to_oihw(const float* src, float* dst, int O, int I, int H, int W, in
 // zero-framed NHWC3 input of the packed 7x7 stem (interior only; the frame is zeroed once at allocation)
 void k_stem3_mask_grad(float* g, int O, hipStream_t s);     // zero the gradient of the packed stem's zero tap slots
 void k_frame_nhwc3(const float* x, float* y, int imgs, int H, int W, int Hp, int Wp, int top, int left, int src_nhwc3,
-                   hipStream_t s);
+                   hipStream_t s, unsigned short* yp = nullptr, long long yp_plane_elems = 0);
 // dgrad pack: out[ci][j][co] = w[co][taps.t[j]][ci]   (w is [Co][T][Ci])
 void k_pack_dgrad(const float* w, float* out, int Co, int T, int Ci, TapList taps, hipStream_t s);
 // all data-gradient weight packs of a step in one launch: job j fills jobs[j].out from state + jobs[j].w_off

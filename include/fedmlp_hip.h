@@ -287,7 +287,8 @@ int fm_planes_mode(fm_engine* e);
  * gradient), the launch count, total milliseconds and algorithmic FLOPs since the last read.  Planes mode (fm_planes_mode):
  * 0 / 1 = pconv_kernel<4 | 2, 4, 2, SP, true> (3x3 stride-1 convs and their data gradients, M >= 128 | M = 64), 6 / 7 =
  * pconv_kernel<4 | 2, 4, 2, SP, false> (stride-2 / 1x1 convs, parity classes), 3 / 4 = pwgrad_kernel<4 | 2, ...>,
- * 8 = pwgrad_ring_kernel<SP> (weight gradients of the 3x3 stride-1 convs on the 56 x 56 and 28 x 28 maps). */
+ * 8 = pwgrad_ring_kernel<SP> (weight gradients of the 3x3 stride-1 convs on the 56 x 56 and 28 x 28 maps), 2 = stem_rows_kernel<SP>
+ * (the 7x7 stem forward at 112-pixel output rows; other input sizes: igemm_kernel<64,256,4,2,...>). */
 #define FM_PROFILE_FAMILIES 9
 int fm_profile_enable(fm_engine* e, int32_t on);
 int fm_profile_read(fm_engine* e, int32_t family, int64_t* launches, double* ms, double* flops);
