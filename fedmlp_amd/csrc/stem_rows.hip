@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void stem_rows_kernel(const StemRowsParams 
         for (int r = 0; r < FR; ++r)
 #pragma unroll
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sp_u32x4 A0[FR][3], A1[FR][3], Bb[2][3];
+        sp_u32x4 A0[FR][3], A1[FR][3], Bb[3][3];
 #define SR_READA(KH, DST)                                                                        \
     {                                                                                            \
         const unsigned a_ = Af + (unsigned)((KH) * 3 * 4096);      /* (LDS offsets are 16-bit immediates) */ \
@@ -189,25 +190,32 @@ __global__ __launch_bounds__(512, 2) void stem_rows_kernel(const StemRowsParams 
 #define SR_MFMA(C, AC, BI)                                                                                           \
     _Pragma("unroll") for (int r = 0; r < FR; ++r)                                                                    \
         acc[r][C] = mfma_split<SP>(AC[r][0], AC[r][1], AC[r][2], Bb[BI][0], Bb[BI][1], Bb[BI][2], acc[r][C])
-        // column (KH, C): its fragment sits in Bb[(7 KH + C) & 1]; the next column's (or the next kernel row's first, with that row's
-        // weights) goes out at the head of its 12 MFMAs and is waited for at their end
-#define SR_COLUMN(KH, C, ACUR, ANXT)                                                             \
-    {                                                                                            \
-        if ((C) < FC - 1) { SR_READB(Bf + (KH) * krow, (C) + 1, Bb[(7 * (KH) + (C) + 1) & 1]); }  \
-        else if ((KH) < 6) { SR_READA((KH) + 1, ANXT); SR_READB(Bf + ((KH) + 1) * krow, 0, Bb[(7 * ((KH) + 1)) & 1]); } \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        SR_MFMA(C, ACUR, (7 * (KH) + (C)) & 1);                                                  \
-        SR_LGKM0();                                                                              \
-    }
-#define SR_ROW(KH, ACUR, ANXT)                                                                   \
-    SR_COLUMN(KH, 0, ACUR, ANXT) SR_COLUMN(KH, 1, ACUR, ANXT) SR_COLUMN(KH, 2, ACUR, ANXT) SR_COLUMN(KH, 3, ACUR, ANXT) \
-    SR_COLUMN(KH, 4, ACUR, ANXT) SR_COLUMN(KH, 5, ACUR, ANXT) SR_COLUMN(KH, 6, ACUR, ANXT)
+        // column G = 7 kh + c of the tile's 49: its fragment sits in Bb[G % 3], read TWO columns ahead (a column is only 12 MFMAs);
+        // a kernel row's weight fragments travel with its first column.  The wait at a column's end leaves the newest reads in flight
+        auto column = [&](auto g_c) {
+            constexpr int G = decltype(g_c)::value, KH = G / 7, C = G % 7, G2 = G + 2, KH2 = G2 / 7, C2 = G2 % 7;
+            if constexpr (G2 <= 48) {
+                if constexpr (C2 == 0) {
+                    if constexpr ((KH2 & 1) == 0) { SR_READA(KH2, A0); } else { SR_READA(KH2, A1); }
+                }
+                SR_READB(Bf + KH2 * krow, C2, Bb[G2 % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((KH & 1) == 0) { SR_MFMA(C, A0, G % 3); } else { SR_MFMA(C, A1, G % 3); }
+            if constexpr (G2 > 48) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if constexpr (C2 == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
         SR_READA(0, A0);
         SR_READB(Bf, 0, Bb[0]);
+        SR_READB(Bf, 1, Bb[1]);
         SR_LGKM0();
-        SR_ROW(0, A0, A1) SR_ROW(1, A1, A0) SR_ROW(2, A0, A1) SR_ROW(3, A1, A0) SR_ROW(4, A0, A1) SR_ROW(5, A1, A0) SR_ROW(6, A0, A1)
-#undef SR_ROW
-#undef SR_COLUMN
+#define SR_G(N) column(std::integral_constant<int, N>{});
+#define SR_G7(N) SR_G(N) SR_G(N + 1) SR_G(N + 2) SR_G(N + 3) SR_G(N + 4) SR_G(N + 5) SR_G(N + 6)
+        SR_G7(0) SR_G7(7) SR_G7(14) SR_G7(21) SR_G7(28) SR_G7(35) SR_G7(42)
+#undef SR_G7
+#undef SR_G
 #undef SR_MFMA
 #undef SR_READB
 #undef SR_READA
