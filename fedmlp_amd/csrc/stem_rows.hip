@@ -93,7 +93,9 @@ __global__ __launch_bounds__(512, 2) void stem_rows_kernel(const StemRowsParams 
         }
     };
     // (measured and not kept: the epilogue deferred to the start of the next iteration, from a copy of the accumulators, so that its
-    // stores drain beside the next tile's MFMAs: 487 vs 473 us -- the wait at the loop's top is not what a tile's time goes to)
+    // stores drain beside the next tile's MFMAs: 487 vs 473 us -- the wait at the loop's top is not what a tile's time goes to; four
+    // waves per block, each holding all 64 channels of an output row (half the B-fragment reads per MFMA, one wave per SIMD): the
+    // same time as the eight-wave form)
     auto epilogue = [&](const f32x4 (&a)[FR][FC], int tile) {
         const int img = tile / tiles_per_img, t4 = tile - img * tiles_per_img;
         // ---- epilogue: a[r][c][q] = D[channel 32 wm + 16 r + 4 lg + q][pixel (4 t4 + wn, 16 c + li)] ----------------------------
