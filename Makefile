@@ -21,4 +21,8 @@ $(LIB): $(OBJ)
 clean:
 	rm -rf build $(LIB)
 
-.PHONY: all clean
+# measurement-only artefacts (tuning / probe builds, assembly dumps): nothing of the product depends on them
+clean-scratch:
+	rm -rf scratch tune build/*.s __pycache__ .pytest_cache
+
+.PHONY: all clean clean-scratch

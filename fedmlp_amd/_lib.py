@@ -91,6 +91,7 @@ SYMBOLS = {
     "fm_debug_get_grads": (C.c_int, [_P, _P]),
     "fm_debug_activation": (C.c_int, [_P, _I32, _I32, _I32, _P, C.POINTER(_I32)]),
     "fm_debug_stem_masks": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "fm_debug_lose_part": (C.c_int, [_I32]),
 }
 
 _lib = None
@@ -110,7 +111,13 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)        # AttributeError if the .so lacks a declared symbol
+        try:
+            fn = getattr(lib, name)    # AttributeError if the .so lacks a declared symbol
+        except AttributeError:
+            # an OLDER build selected for a same-box A/B (tools/) may lack a newer test hook; the shipped library may not
+            if os.environ.get("FEDMLP_HIP_LIB") and name.startswith("fm_debug_"):
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -181,7 +181,17 @@ struct IgemmParams {
     // floats per row of W when that is not nsteps * KS (the packed stem in 32-k stages: rows of 176 floats walked as 6 x 32 --
     // the 16 floats past a row's end meet the zero-page chunks of X); 0 = nsteps * KS
     int wrow = 0;
+    // pconv.hip scheduling switches (set by launch_pconv): bit 0 = waves 4-7 issue a step's DMA behind its last column's MFMAs
+    // instead of in front of them (their SIMD partners 0-3 issue in front: one of a pair computes while the other issues),
+    // bit 1 = s_setprio 1 for waves 4-7, bit 2 = s_setprio 1 for waves 0-3
+    int pc_flags = 0;
+    // pconv.hip: where a stream-K finisher reports a part that never arrived (its wait is bounded): a device word the optimizer
+    // kernel reads (a step with a lost part does not update the weights) and its host-mapped twin the next API call checks
+    int* err = nullptr;
+    int* err_host = nullptr;
 };
+// test hook (fedmlp_hip_debug.h fm_debug_lose_part): the non-finishers of shared stream-K tiles do not announce their parts
+void pconv_debug_lose_part(int on);
 
 // Weight-gradient GEMM: dW[m][n] = sum_p dY[p][m] * Xg[p][n], split over p.
 struct WgradParams {
@@ -243,6 +253,7 @@ bool pconv_takes(int M, int Ci, long long xp_pix, int Wi);
 bool pconv_uses_ts(const IgemmParams& p);      // will launch_pconv take the tap-row-sharing kernel for these parameters?
 int pconv_tile_m(int M);
 int pconv_tile_n(int M);
+size_t pconv_slab_floats();   // stream-K slab of launch_pconv (p.slab): pconv_max_blocks() x 2 x the largest tile
 // small-K (Ci <= 256) 1x1 stride-1 convolutions; false = shape not handled (run igemm)
 bool launch_conv1x1_stream(const IgemmParams& p, int groups, hipStream_t s);
 bool conv1x1_stream_takes(int Ci, int M, int Co);     // would a stride-1 1x1 conv of this shape stream through conv1x1.hip?

@@ -331,9 +331,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ run_mean, float* __restrict__ run_var,
                                    float* __restrict__ mean, float* __restrict__ istd,
-                                   float* __restrict__ scale, float* __restrict__ shift, float eps, float momentum)
+                                   float* __restrict__ scale, float* __restrict__ shift, float eps, float momentum,
+                                   const int* __restrict__ skip)
 {
     __shared__ double red[2][4][64];
+    // (a kernel of this step reported a lost part, adam_kernel: the running statistics stay as they are too)
+    const bool keep_running = skip && *skip;
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const bool chv = blockIdx.x * 64 + cl < C;             // C need not be a multiple of 64
     const int ch = chv ? blockIdx.x * 64 + cl : C - 1;
@@ -363,8 +366,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int groups, 
             scale[g * C + ch] = sc;
             shift[g * C + ch] = be - (float)mu * sc;
             const double unb = count > 1 ? var * n / (n - 1.0) : var;
-            run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * (float)mu;
-            run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)unb;
+            if (!keep_running) {
+                run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * (float)mu;
+                run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (float)unb;
+            }
         }
         __syncthreads();
     }
@@ -393,7 +398,7 @@ __global__ void bn_fold_tiles_kernel(const float* __restrict__ stats, float* __r
 
 void k_bn_finalize(const float* stats, int groups, int tiles, int C, int count, const float* gamma,
                    const float* beta, float* run_mean, float* run_var, float* mean, float* istd, float* scale,
-                   float* shift, float eps, float momentum, hipStream_t s)
+                   float* shift, float eps, float momentum, hipStream_t s, const int* skip)
 {
     const float* src = stats;
     if (tiles > 64) {
@@ -404,7 +409,7 @@ void k_bn_finalize(const float* stats, int groups, int tiles, int C, int count, 
         tiles = 32;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, src, groups, tiles, C, count, gamma,
-                       beta, run_mean, run_var, mean, istd, scale, shift, eps, momentum);
+                       beta, run_mean, run_var, mean, istd, scale, shift, eps, momentum, skip);
 }
 
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -892,8 +897,11 @@ void k_bn_bwd_apply(const float* dz, const float* z, const float* y, const float
 // denom = sqrt(v)/sqrt(bc2) + eps, p -= lr/bc1 * m/denom), L2 decay folded into g.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n4, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt)
+                            float bc1, float bc2_sqrt, const int* __restrict__ skip)
 {
+    // a kernel of this step reported a lost part (pconv.hip's bounded stream-K wait): the gradients are poisoned, the weights
+    // and moments stay as they are; the host learns of it through the word's mapped twin at its next call
+    if (skip && *skip) return;
     const float step = lr / bc1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -914,11 +922,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 void k_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-            float wd, float bc1, float bc2_sqrt, hipStream_t s)
+            float wd, float bc1, float bc2_sqrt, hipStream_t s, const int* skip)
 {
     const int64_t n4 = n / 4;     // engine pads the parameter arena to a multiple of 4
     hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, s, p, g, m, v, n4, lr, b1, b2,
-                       eps, wd, bc1, bc2_sqrt);
+                       eps, wd, bc1, bc2_sqrt, skip);
 }
 
 // out[i] = sum_s slab[s][i]; block = 64 float4 columns x 16 split lanes, lanes combined through

@@ -183,6 +183,11 @@ struct fm_engine {
     // profiling
     bool prof = false, prof_fail = false;
     hipError_t soft_err = hipSuccess;      // first failed event record / stream wait of the current step (soft())
+    // a kernel's own failure report (pconv.hip: a stream-K part that never arrived): dev_err is read by the optimizer kernel
+    // (the step does not touch the weights), host_err is its host-mapped twin that STEP_DONE checks at every call
+    int* dev_err = nullptr;
+    int* host_err = nullptr;
+    int* host_err_dev = nullptr;
     // per-op timing (FM profile leg of tools/op_profile.py): label = "<op>@<block>"
     bool oprof = false;
     int ctx = -1;
@@ -263,6 +268,12 @@ static inline void soft(fm_engine* e, hipError_t rc)
         (e)->soft_err = hipSuccess;                                  \
         HIPCHK(se_);                                                 \
         HIPCHK(hipGetLastError());                                   \
+        if ((e)->host_err && *(volatile int*)(e)->host_err) {        \
+            *(volatile int*)(e)->host_err = 0;                       \
+            (void)hipMemsetAsync((e)->dev_err, 0, sizeof(int), (e)->st); \
+            g_err = "a stream-K part never arrived (pconv): the step's optimizer update was skipped"; \
+            return FM_ERR_HIP;                                       \
+        }                                                            \
     } while (0)
 
 
@@ -850,7 +861,13 @@ int alloc_workspaces(fm_engine* e)
         DALLOC(t3, (e->xp_scratch_elems + 1) / 2);
         e->xp_scratch2 = reinterpret_cast<unsigned short*>(t3);
     }
-    DALLOC(e->sk_slab, (size_t)igemm_max_blocks() * 2 * 16384);   // [blocks][2][BM*BN]
+    const size_t sk_floats = std::max((size_t)igemm_max_blocks() * 2 * 16384, pconv_slab_floats());
+    DALLOC(e->sk_slab, sk_floats);   // [blocks][2][BM*BN]
+    DALLOC(e->dev_err, 16);
+    HIPCHK(hipMemset(e->dev_err, 0, 16 * sizeof(int)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->host_err), 64, hipHostMallocMapped));
+    *e->host_err = 0;
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->host_err_dev), e->host_err, 0));
     DALLOC(e->sk_counters, (size_t)1 << 20);
     HIPCHK(hipMemset(e->sk_counters, 0, ((size_t)1 << 20) * 4));
     {
@@ -866,12 +883,12 @@ int alloc_workspaces(fm_engine* e)
                 const Conv& c = e->convs[blk.c1];
                 need += (size_t)(blk.ds >= 0 ? 3 : 2) * B * c.hout * c.wout * c.cout * 4;
             }
-            need += (size_t)igemm_max_blocks() * 2 * 16384 * 4 + ((size_t)4 << 20);
+            need += sk_floats * 4 + ((size_t)4 << 20);
             if (e->planes) need += need * 3 / 2;       // the planes of the teacher's activations and of the second gradient set
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)4 << 30)) side = 0;
         }
         if (side) {
-            DALLOC(e->sk_slab2, (size_t)igemm_max_blocks() * 2 * 16384);
+            DALLOC(e->sk_slab2, sk_floats);
             DALLOC(e->sk_counters2, (size_t)1 << 20);
             HIPCHK(hipMemset(e->sk_counters2, 0, ((size_t)1 << 20) * 4));
             // ResNet-18 (MFMA-bound, persistent 512-block kernels): 39.0 -> 37.7 ms per stage-1 step with the teacher and the
@@ -1038,7 +1055,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         p.Xp = xp ? xp : scratch_planes(e, x, p.xp_pix, c.cin_p);
         p.Wsp = (S == e->tstate ? e->twbm_f : e->wbm_f) + c.bm_off;
         p.Y = y; p.Yp = yp; p.yp_pix = (long long)imgs * c.hout * c.wout;
-        p.slab = e->sk_slab; p.counters = e->sk_counters; p.sp = e->products;
+        p.slab = e->sk_slab; p.counters = e->sk_counters; p.err = e->dev_err; p.err_host = e->host_err_dev; p.sp = e->products;
         p.ntaps = c.k * c.k;
         for (int t = 0; t < c.k * c.k; ++t) { p.dh[t] = t / c.k - c.pad; p.dw[t] = t % c.k - c.pad; }
         p.res = res; p.resp = resp; p.scale = scale; p.shift = shift; p.stats = stats;
@@ -1072,7 +1089,7 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         return;
     }
     IgemmParams p{};
-    p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+    p.W = S + c.w_off; p.X = x; p.Y = y; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters; p.err = e->dev_err; p.err_host = e->host_err_dev;
     p.sp = e->products;
     if (c.sp_off >= 0 && e->wsp_f) p.Wsp = (S == e->tstate ? e->twsp_f : e->wsp_f) + c.sp_off;
     if (c.cin == 3) {
@@ -1129,7 +1146,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
             DgradClass& d = c.cls[k];
             IgemmParams p{};
             p.Xp = dyp; p.xp_pix = xp_pix; p.Wsp = e->wbm_d + d.bm_off;
-            p.Y = dx; p.slab = e->sk_slab; p.counters = e->sk_counters; p.sp = e->products;
+            p.Y = dx; p.slab = e->sk_slab; p.counters = e->sk_counters; p.err = e->dev_err; p.err_host = e->host_err_dev; p.sp = e->products;
             p.ntaps = d.taps.n;
             for (int t = 0; t < d.taps.n; ++t) { p.dh[t] = d.dh[t]; p.dw[t] = d.dw[t]; }
             p.res = res ? res : ((acc_cls0 && d.ph == 0 && d.pw == 0) ? dx : nullptr);
@@ -1164,7 +1181,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
     for (int k = 0; k < c.ncls; ++k) {
         DgradClass& d = c.cls[k];
         IgemmParams p{};
-        p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters;
+        p.W = d.wpack; p.X = dy; p.Y = dx; p.zeros = e->zeros; p.slab = e->sk_slab; p.counters = e->sk_counters; p.err = e->dev_err; p.err_host = e->host_err_dev;
         p.sp = e->products;
         if (d.sp_off >= 0 && e->wsp_d) p.Wsp = e->wsp_d + d.sp_off;
         p.ntaps = d.taps.n;
@@ -1279,7 +1296,7 @@ void bn_fwd_finalize(fm_engine* e, int ci, int groups, int imgs_per_group)
     k_bn_finalize(e->ws_stats, groups, stats_tiles(e, ci, imgs_per_group, groups), b.C, imgs_per_group * c.hout * c.wout,
                   e->state + e->off_gamma + b.ch_off, e->state + e->off_beta + b.ch_off,
                   e->state + e->off_rm + b.ch_off, e->state + e->off_rv + b.ch_off, b.mean, b.istd, b.scale,
-                  b.shift, e->bn_eps, e->bn_mom, e->st);
+                  b.shift, e->bn_eps, e->bn_mom, e->st, e->dev_err);
     e->counters[bi] += groups;
 }
 
@@ -1467,7 +1484,7 @@ void adam_step(fm_engine* e)
     const double bc1 = 1.0 - pow((double)e->hp.beta1, (double)e->adam_t);
     const double bc2 = 1.0 - pow((double)e->hp.beta2, (double)e->adam_t);
     k_adam(e->state, e->grad, e->adam_m, e->adam_v, (int64_t)e->NP, e->hp.lr, e->hp.beta1, e->hp.beta2, e->hp.eps,
-           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st);
+           e->hp.weight_decay, (float)bc1, (float)sqrt(bc2), e->st, e->dev_err);
     e->ev_dirty = true;
     e->wpack_dirty = true;
     ensure_packed(e);        // the next step's data gradients read the packed (transposed) weights
@@ -2043,6 +2060,7 @@ int fm_destroy(fm_engine* e)
         }
     if (e->ev_wdone) (void)hipEventDestroy(e->ev_wdone);
     if (e->comm) { (void)fmcomm_destroy(e->comm); e->comm = nullptr; }
+    if (e->host_err) (void)hipHostFree(e->host_err);
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& p : e->evs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto v : e->ev_free) (void)hipEventDestroy(v);
@@ -2808,6 +2826,12 @@ int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs,
                               hipMemcpyDeviceToHost, e->st));
         HIPCHK(hipStreamSynchronize(e->st));
     }
+    return FM_OK;
+}
+
+int fm_debug_lose_part(int32_t on)
+{
+    pconv_debug_lose_part(on);
     return FM_OK;
 }
 

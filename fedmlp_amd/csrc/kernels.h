@@ -74,7 +74,7 @@ void k_augment(const uint8_t* cache, const int* idx, const int* params, float* o
 void k_bn_finalize(const float* stats, int groups, int tiles, int C, int count,
                    const float* gamma, const float* beta, float* run_mean, float* run_var,
                    float* mean, float* istd, float* scale, float* shift, float eps, float momentum,
-                   hipStream_t s);
+                   hipStream_t s, const int* skip = nullptr);    // *skip != 0: the running statistics are not updated
 // eval-mode folded affine for all BN channels at once
 void k_bn_eval_affine(const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                       float* scale, float* shift, int n, float eps, hipStream_t s);
@@ -190,7 +190,7 @@ void k_loss_fixmatch(const float* z, const float* y, ClassVec pos_w, ClassVec po
 
 // ---- optimiser -------------------------------------------------------------------
 void k_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-            float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s);
+            float eps, float wd, float bc1, float bc2_sqrt, hipStream_t s, const int* skip = nullptr);   // *skip != 0: no update
 void k_reduce_slabs(const float* slab, float* out, int splits, int64_t n, hipStream_t s);
 
 // ---- prototypes / tagging ----------------------------------------------------------

@@ -291,6 +291,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     };
 
     if (w >= wend) return;                       // (a block whose range is empty: the grid was rounded up)
+    if ((p.pc_flags & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if ((p.pc_flags & 4) && wave < 4) __builtin_amdgcn_s_setprio(1);
     Seg cur;
     decode(cur);
     lead(cur);
@@ -323,6 +325,17 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
     // first column alternates from step to step, so the next step's column 0 never lands on the column still in use)
 #define PC_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
 #define PC_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // the wait at the END of column C's MFMAs.  The accumulators are operands of the statement: without that dependence the machine
+    // scheduler is free to move the bare wait anywhere between the two scheduling barriers, and it put it behind the column's FIRST
+    // MFMA (rounds 4-5 shipped that: every column waited for its reads before 23 of its 24 MFMAs)
+#define PC_LGKM0_COL(C)                                                                                                           \
+    do {                                                                                                                          \
+        if constexpr (FR == 4)                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C]), "+v"(acc[2][C]), "+v"(acc[3][C])::"memory"); \
+        else                                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    } while (0)
     // workgroup barrier that orders LDS accesses only: a __syncthreads() would also wait for the LDS-DMA in flight
 #define PC_SYNC_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // keep: the fence's own wait may be dropped
-                __hip_atomic_fetch_add(p.counters + pend_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(p.pc_flags & 8)) __hip_atomic_fetch_add(p.counters + pend_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             pend_tile = -1;
         }
@@ -351,6 +364,16 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         // (NS - 2 of them, when every step issues one: `full`) and a B row issued one or NS - 1 barriers ago
         const int ja_w = ((3 * GA) % 8 != 0 && wave >= 4) ? JA - 1 : JA;
         auto wait_dma = [&](bool full) {
+            if constexpr (TS && NS == 2) {
+                // two stages: the only DMA that may stay in flight is a B row issued one barrier ago.  Every wave waits with the
+                // count of the waves that hold the SMALLER share of a row (the others wait for three of their pieces more): ONE
+                // branch -- the count as a run-time switch over vmcnt immediates compiled into a chain of ~25 scalar branches
+                // between a step's third and fourth column
+                constexpr int NROW = 3 * (GB % 8 ? RGB - 1 : RGB);
+                if (full && b_age == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NROW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                return;
+            }
             int n = 0;
             if (TS && full) n = (NS - 2) * ja_w + ((b_age >= 1 && b_age <= NS - 1) ? 3 * ngrpB : 0);
             switch (n) {
@@ -408,6 +431,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 
         PC_T(2);
         int ib = 0;                            // stage slot of the current step
+        // the two waves of a SIMD (w, w + 4) run this loop in lockstep between barriers: when both issue a step's DMA at the same
+        // point the matrix pipe idles behind them.  `late`: waves 4-7 issue theirs BEHIND the last column's MFMAs
+        const bool late = (p.pc_flags & 1) && wave >= 4;
         // one K-step (register parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
         // FULL: steps up to s + NS + 1 exist (the main loop: no branch inside, counted vmcnt); otherwise the conditions are tested
         auto step = [&](auto par_c, auto full_c, int s, sp_u32x4 (&Ac)[FR][3], sp_u32x4 (&An)[FR][3]) {
@@ -444,25 +470,31 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 for (int r = 0; r < FR; ++r) acc[r][0] = pc_mfma<SP>(Ac[r], Bb[0], acc[r][0]);
 #pragma unroll
                 for (int r = 0; r < FR; ++r) acc[r][1] = pc_mfma<SP>(Ac[r], Bb[1], acc[r][1]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1])::"memory");
                 wait_dma(FULL);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (more) { PC_READB(bn(0), 0, Bb[0]); PC_READB(bn(1), 1, Bb[1]); }
-                if constexpr (TS) {
-                    // A first, then the B row: the next barrier waits for the A stage only and leaves the row in flight
-                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                    if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
-                } else {
-                    if (FULL || s + NS < k1) issueB(cur, ib);
-                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                }
+                auto issue_dma = [&]() {
+                    if constexpr (TS) {
+                        // A first, then the B row: the next barrier waits for the A stage only and leaves the row in flight
+                        if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                        if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
+                    } else {
+                        if (FULL || s + NS < k1) issueB(cur, ib);
+                        if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                    }
+                };
+                if (!late) issue_dma();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < FR; ++r) acc[r][2] = pc_mfma<SP>(Ac[r], Bb[2], acc[r][2]);
 #pragma unroll
                 for (int r = 0; r < FR; ++r) acc[r][3] = pc_mfma<SP>(Ac[r], Bb[3], acc[r][3]);
+                asm volatile("" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[0][3]), "+v"(acc[1][3]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (late) issue_dma();
                 PC_LGKM0();
                 if constexpr (TS) {
                     if (row_end) { ub ^= 1; ++Ucur; }
@@ -492,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[PC_BI(C, PAR)], acc[r][C]); \
-                PC_LGKM0();                                                                                      \
+                PC_LGKM0_COL(C);                                                                                 \
             }
             PC_COLUMN(0)
             PC_COLUMN(1)
@@ -510,18 +542,23 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (FULL || s + 1 < k1) PC_READB(bn(0), 0, Bb[PC_BI(0, PAR ^ 1)]);
-            if constexpr (TS) {
-                // the last tap of a kernel row has consumed its B slot: it takes the row after next.  A first, then the B row: the
-                // next barrier waits for the A stage only and leaves the row in flight
-                if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
-            } else {
-                if (FULL || s + NS < k1) issueB(cur, ib);
-                if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-            }
+            auto issue_dma = [&]() {
+                if constexpr (TS) {
+                    // the last tap of a kernel row has consumed its B slot: it takes the row after next.  A first, then the B row:
+                    // the next barrier waits for the A stage only and leaves the row in flight
+                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                    if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
+                } else {
+                    if (FULL || s + NS < k1) issueB(cur, ib);
+                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
+                }
+            };
+            if (!late) issue_dma();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[PC_BI(FC - 1, PAR)], acc[r][FC - 1]);
-            PC_LGKM0();
+            PC_LGKM0_COL(FC - 1);
+            if (late) issue_dma();
             if constexpr (TS) {
                 if (row_end) { ub ^= 1; ++Ucur; }
                 it_cur = it_cur == 8 ? 0 : it_cur + 1;
@@ -543,6 +580,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
 #undef PC_READA
 #undef PC_READB
 #undef PC_LGKM0
+#undef PC_LGKM0_COL
 #undef PC_BI
         PC_SYNC_LDS();         // every wave is done reading both stages: they can take the next segment's lead DMA
         PC_T(3);
@@ -586,9 +624,15 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
                     // bounded (a few seconds: the parts were stored a whole range ago; only a block that was never scheduled can be
                     // missing): a lost part must not hang the GPU -- it POISONS the tile instead (NaN: the step's loss says so)
                     int got = 0;
-                    for (int it = 0; it < (1 << 22) && !got; ++it) {
+                    const int spins = (p.pc_flags & 8) ? (1 << 8) : (1 << 22);        // (bit 3: the test hook's short wait)
+                    for (int it = 0; it < spins && !got; ++it) {
                         got = __hip_atomic_load(p.counters + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == need;
                         if (!got) __builtin_amdgcn_s_sleep(4);
+                    }
+                    if (!got) {
+                        // the step must not reach the weights: the optimizer kernel reads p.err, the host reads its mapped twin
+                        if (p.err) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.err_host) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                     __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -734,7 +778,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(p.counters + pend_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(p.pc_flags & 8)) __hip_atomic_fetch_add(p.counters + pend_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 #undef PC_SYNC_LDS
@@ -809,9 +853,13 @@ void k_split_planes(const float* x, unsigned short* dst, long long npix, int C, 
     if (n > 0) hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, dst, npix, C);
 }
 
+int pconv_max_blocks() { return 256; }     // ONE block per CU (120 - 144 KB of LDS)
+static int g_lose_part = 0;
+void pconv_debug_lose_part(int on) { g_lose_part = on; }
+// floats of the stream-K slab: one slot of two tiles' worth per block (a range starts inside a tile at most once)
+size_t pconv_slab_floats() { return (size_t)pconv_max_blocks() * 2 * 128 * 256; }
 int pconv_tile_m(int M) { return M >= 128 ? 128 : 64; }
 int pconv_tile_n(int M) { (void)M; return 256; }
-int pconv_max_blocks() { return 256; }     // ONE block per CU (120 - 144 KB of LDS)
 // does the planes kernel take this GEMM?  whole M tiles, whole 32-channel blocks, taps within [-1, 1], planes below 2 GB
 bool pconv_takes(int M, int Ci, long long xp_pix, int Wi)
 {
@@ -878,6 +926,8 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     // tap-row sharing: 3x3, stride 1, the taps in three groups of one kernel row each whose column shifts cover -1, 0, +1
     // (forward convs and their data gradients alike); FM_PCONV_TS=0 (tuning builds) keeps the per-tap stages
     const bool ts = pconv_uses_ts(p);
+    static const int pc_flags = fm_tune("FM_PCONV_FLAGS", 1);      // (measured: 1 = -0.6 % of a step, 2 / 4 = +0.3 %)
+    p.pc_flags = (pc_flags & 7) | (g_lose_part ? 8 : 0);
     if (ts) {
         if (p.M >= 128) {
             if (p.sp == 9) hipLaunchKernelGGL((pconv_kernel<4, 4, 2, 9, true>), grid, dim3(512), LDS_LT, s, p);

@@ -182,6 +182,16 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
         else PW_READ(DST, Bf, b_w, (SLOT) * SB, (C) + 1)                                           \
     }
 #define PW_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // the wait at the END of column C's MFMAs: the accumulators are operands, so that the machine scheduler cannot move the bare
+    // wait up behind the column's first MFMA (which is where it put it: pconv.hip PC_LGKM0_COL)
+#define PW_LGKM0_COL(C)                                                                                                           \
+    do {                                                                                                                          \
+        if constexpr (FR == 4)                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C]), "+v"(acc[2][C]), "+v"(acc[3][C])::"memory"); \
+        else                                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    } while (0)
     // the rolling X buffers: column c of a step of parity PAR sits in Bb[(c + PAR * FC) & 1] (FC = 3: the parity of the first column
     // alternates from step to step, so that the next step's column 0 never lands on the column still in use)
 #define PW_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
                 }                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 _Pragma("unroll") for (int r = 0; r < FR; ++r) PW_MFMA(r, C, Ac, PW_BI(C, PAR));                 \
-                PW_LGKM0();                                                                                      \
+                PW_LGKM0_COL(C);                                                                                 \
             }
             PW_COLUMN(0)
             PW_COLUMN(1)
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
             if (FULL || s + 3 < nsteps) issueA(PAR ^ 1);
 #pragma unroll
             for (int r = 0; r < FR; ++r) PW_MFMA(r, FC - 1, Ac, PW_BI(FC - 1, PAR));
-            PW_LGKM0();
+            PW_LGKM0_COL(FC - 1);
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
 #undef PW_READA
 #undef PW_READB
 #undef PW_LGKM0
+#undef PW_LGKM0_COL
 #undef PW_MFMA
 #undef PW_BI
 

@@ -184,6 +184,13 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
         DST[2] = sp_u32x4{l0.x, l0.y, l1.x, l1.y};                                                 \
     }
 #define PR_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // the wait at the END of column C's MFMAs: the accumulators are operands, so that the machine scheduler cannot move the bare
+    // wait up behind the column's first MFMA (which is where it put it: pconv.hip PC_LGKM0_COL)
+#define PR_LGKM0_COL(C)                                                                            \
+    do {                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #define PR_MFMA(C, AC, BI_)                                                                                                  \
     _Pragma("unroll") for (int r = 0; r < FR; ++r)                                                                            \
         acc[r][C] = mfma_split<SP>(Bb[BI_][0], Bb[BI_][1], Bb[BI_][2], AC[r][0], AC[r][1], AC[r][2], acc[r][C])
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
                 EXTRA;                                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                                 \
                 PR_MFMA(C, Ac, ((C) + PAR) & 1);                                                   \
-                PR_LGKM0();                                                                        \
+                PR_LGKM0_COL(C);                                                                   \
             }
             PR_COLUMN(0, (void)0)
             PR_COLUMN(1, (void)0)
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
             PR_READB(0, Bb[(0 + (PAR ^ 1)) & 1]);          // the next step's column 0
             __builtin_amdgcn_sched_barrier(0);
             PR_MFMA(8, Ac, (8 + PAR) & 1);
-            PR_LGKM0();
+            PR_LGKM0_COL(8);
             slot0 = slot1;
             slot1 = slot1 == PR_NSA - 1 ? 0 : slot1 + 1;
         };
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
 #undef PR_READA
 #undef PR_READB
 #undef PR_LGKM0
+#undef PR_LGKM0_COL
 #undef PR_MFMA
 
     // ---- epilogue: acc[r][c][q] = dW[m of (tile 2 wm + r, position li)][n of (tap c, block cb0 + cbw, positions 16 hhw + 4 lg + q)]

@@ -204,9 +204,10 @@ __global__ __launch_bounds__(512, 2) void stem_rows_kernel(const StemRowsParams 
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((KH & 1) == 0) { SR_MFMA(C, A0, G % 3); } else { SR_MFMA(C, A1, G % 3); }
-            if constexpr (G2 > 48) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if constexpr (C2 == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            // (the column's accumulators are operands of the wait: the machine scheduler moved a bare one behind the column's FIRST MFMA)
+            if constexpr (G2 > 48) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");
+            else if constexpr (C2 == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");
             __builtin_amdgcn_sched_barrier(0);
         };
         SR_READA(0, A0);

@@ -73,6 +73,12 @@ int fm_debug_activation(fm_engine* e, int32_t kind, int32_t block, int32_t imgs,
  * (BatchNorm statistics are per view). */
 int fm_debug_stem_masks(fm_engine* e, int32_t imgs, int32_t groups, uint8_t* relu_bits_host, uint8_t* argmax_host);
 
+/* Fault injection for the stream-K fix-up of the planes conv GEMMs (pconv.hip): on = 1 makes the owners of partial tiles keep
+ * their arrival announcements to themselves (and shortens the finisher's bounded wait), so that every shared tile times out.
+ * Expected behaviour, which tests/test_engine_gpu.py checks: the step's optimizer update is skipped on the device (weights,
+ * moments unchanged) and the NEXT call that ends a step or synchronises returns FM_ERR_HIP once.  Process-wide; on = 0 restores. */
+int fm_debug_lose_part(int32_t on);
+
 /* Gradients of the last step in state_dict order (running-stat slots are 0). */
 int fm_debug_get_grads(fm_engine* e, float* host_f32);
 

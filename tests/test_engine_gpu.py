@@ -437,3 +437,44 @@ def test_step_in_the_three_product_forms(monkeypatch):
         assert e.planes
     finally:
         e.close()
+
+
+def test_lost_streamk_part_skips_the_update_and_is_reported():
+    """ADVICE r5 (pconv.hip's bounded stream-K wait): a part of a shared tile that never arrives must not end in the weights.
+    With the fault injected (fm_debug_lose_part) on a grid forced to odd splits, the step's Adam update is skipped on the
+    device (state bit-identical), the next synchronising call returns an error ONCE, and the step after that trains again.
+    Child process: the grid override is read once per process."""
+    import os, subprocess, sys
+    code = r'''
+import sys; sys.path.insert(0, '.')
+import numpy as np, torch
+from fedmlp_amd.engine import Engine
+from fedmlp_amd import spec, _lib
+e = Engine('Resnet18', 5, 64, 64, 8)
+flat, cnt = spec.init_state('Resnet18', 5, 1037)
+e.set_state(flat, cnt); e.adam_reset(1e-3)
+g = torch.Generator().manual_seed(3)
+x = torch.randn((8, 3, 64, 64), generator=g).cuda(); y = (torch.rand((8, 5), generator=g) > 0.5).float().cuda()
+lo = torch.zeros(1, device='cuda')
+e.step_bce(x, y, [1.0] * 5, 8, lo); e.sync()
+s0, _ = e.get_state()
+assert np.isfinite(s0).all() and not np.array_equal(s0, flat), 'a healthy step must train'
+e.lib.fm_debug_lose_part(1)
+err = None
+try:
+    e.step_bce(x, y, [1.0] * 5, 8, lo); e.sync()
+except Exception as ex:
+    err = str(ex)
+e.lib.fm_debug_lose_part(0)
+assert err is not None and 'stream-K' in err, err
+s1, _ = e.get_state()
+assert np.array_equal(s0, s1), 'the poisoned step reached the weights'
+e.sync()                                   # reported once
+e.step_bce(x, y, [1.0] * 5, 8, lo); e.sync()
+s2, _ = e.get_state()
+assert np.isfinite(s2).all() and not np.array_equal(s2, s1), 'training must resume'
+e.close(); print('ok')
+'''
+    env = dict(os.environ, FM_IGEMM_BLOCKS="61")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, f"{r.stdout[-2000:]} {r.stderr[-3000:]}"
