@@ -269,6 +269,9 @@ static inline void soft(fm_engine* e, hipError_t rc)
         HIPCHK(se_);                                                 \
         HIPCHK(hipGetLastError());                                   \
         if ((e)->host_err && *(volatile int*)(e)->host_err) {        \
+            /* drain the failed step (its later kernels may report too), then clear both words: it is reported ONCE */ \
+            (void)hipStreamSynchronize((e)->st);                     \
+            if ((e)->st2) (void)hipStreamSynchronize((e)->st2);      \
             *(volatile int*)(e)->host_err = 0;                       \
             (void)hipMemsetAsync((e)->dev_err, 0, sizeof(int), (e)->st); \
             g_err = "a stream-K part never arrived (pconv): the step's optimizer update was skipped"; \

@@ -442,7 +442,8 @@ def test_step_in_the_three_product_forms(monkeypatch):
 def test_lost_streamk_part_skips_the_update_and_is_reported():
     """ADVICE r5 (pconv.hip's bounded stream-K wait): a part of a shared tile that never arrives must not end in the weights.
     With the fault injected (fm_debug_lose_part) on a grid forced to odd splits, the step's Adam update is skipped on the
-    device (state bit-identical), the next synchronising call returns an error ONCE, and the step after that trains again.
+    device (every trainable tensor bit-identical, nothing non-finite anywhere), the next synchronising call returns an error
+    ONCE, and the step after that trains again.
     Child process: the grid override is read once per process."""
     import os, subprocess, sys
     code = r'''
@@ -468,7 +469,12 @@ except Exception as ex:
 e.lib.fm_debug_lose_part(0)
 assert err is not None and 'stream-K' in err, err
 s1, _ = e.get_state()
-assert np.array_equal(s0, s1), 'the poisoned step reached the weights'
+assert np.isfinite(s1).all(), 'poison in the state'
+d0 = spec.flat_to_state_dict('Resnet18', 5, s0, cnt); d1 = spec.flat_to_state_dict('Resnet18', 5, s1, cnt)
+for k in d0:
+    # (running statistics of layers in FRONT of the failed kernel have taken this batch's -- valid -- statistics)
+    if 'running_' in k or 'num_batches' in k: continue
+    assert np.array_equal(np.asarray(d0[k]), np.asarray(d1[k])), 'the poisoned step reached ' + k
 e.sync()                                   # reported once
 e.step_bce(x, y, [1.0] * 5, 8, lo); e.sync()
 s2, _ = e.get_state()

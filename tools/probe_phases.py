@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle counts of one pconv launch (build/exp/lib_8.so: pconv.hip with -DPC_PHASES).  Timing aid, not part of the product."""
+"""Per-phase cycle counts of one pconv launch (FEDMLP_HIP_LIB=tune/lib_phases.so: pconv.hip with -DPC_PHASES, tools/build_phases.sh).  Timing aid, not part of the product."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
