@@ -437,6 +437,14 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
         per_rank = [{"rank": r, "ms_per_step_incl_allreduce": round(v[0].item(), 4),
                      "allreduce_ms_total": round(v[1].item(), 3), "allreduces": int(v[2].item())}
                     for r, v in enumerate(allr)]
+        if args.workload != "conv_fwd":
+            # outside the timed region: the ranks have just averaged their states -- they must now hold the same bits
+            # (the first N > 1 run on hardware is also a correctness run of fm_fedavg_allreduce)
+            from fedmlp_amd.fedavg import state_agreement
+            agree, worst = state_agreement(eng)
+            if not agree:
+                raise SystemExit(f"[bench] rank {rank}: the ranks' states differ after the FedAvg all-reduce "
+                                 f"(checksum spread {worst:.3e} of the magnitude sum)")
     fams_region = None
     if in_region:
         fams_region = read_families(eng)
@@ -564,7 +572,8 @@ def run_workload(args, rank, world, dev, dist, cpu_cand=None, cpu_budget_s=6.0):
                       "views_per_sec": round(views * total / dt, 3), "parallelism": f"clients{world}",
                       "stream_mode": STREAM_MODE_NAMES.get(effective_mode, str(effective_mode)) +
                                      (" (--one-stream)" if args.one_stream else ""),
-                      "rccl_ranks": rccl_ranks, "timed_region_s": round(dt, 3),
+                      "rccl_ranks": rccl_ranks, "ranks_agree_after_allreduce": (True if world > 1 and args.workload != "conv_fwd" else None),
+                      "timed_region_s": round(dt, 3),
                       "arithmetic": ("bf16 storage, fp32 accumulation" if (args.model == "Efficient_b0" and args.precision == "bf16")
                                      else ARITHMETIC[sp])},
            "roofline": roof,
@@ -830,7 +839,7 @@ def compact_line(out, products=None):
     """The ONE line the driver parses (the contract of the module docstring): contract fields only."""
     cfg = out.get("config") or {}
     c = {"workload": _short(cfg.get("workload", ""), 170)}
-    for k in ("parallelism", "rccl_ranks"):
+    for k in ("parallelism", "rccl_ranks", "ranks_agree_after_allreduce"):
         if k in cfg:
             c[k] = cfg[k]
     if "stream_mode" in cfg:
@@ -849,13 +858,35 @@ def compact_line(out, products=None):
     for k in ("sustained_ms_per_step", "value_on_fp32_mfma_pipe"):
         if k in out:
             line[k] = out[k]
+    return _fit(line, LINE_LIMIT, (("cpu_baseline", "sample"), ("config", "stream_mode"), ("config", "arithmetic"),
+                                   ("config", "per_rank_allreduce_ms"), ("roofline", "kernel"), ("config", "per_rank_ms_per_step"),
+                                   ("value_on_fp32_mfma_pipe",), ("sustained_ms_per_step",), ("cpu_baseline",)))
+
+
+def _fit(line, limit, optional):
+    """json.dumps(line) within `limit` characters: never let prose cost the parse (an assert here threw away minutes of
+    measurement).  Optional keys go first, in the order given; then every string is halved until the line fits."""
     s = json.dumps(line)
-    if len(s) > LINE_LIMIT:                       # never let prose cost the parse: drop the optional strings first
-        for k in ("sample",):
-            (line["cpu_baseline"] or {}).pop(k, None)
-        c.pop("stream_mode", None)
+    for path in optional:
+        if len(s) <= limit:
+            return s
+        d = line
+        for k in path[:-1]:
+            d = d.get(k) or {}
+        d.pop(path[-1], None)
         s = json.dumps(line)
-    assert len(s) <= LINE_LIMIT, len(s)
+
+    def shorten(o, n):
+        if isinstance(o, dict):
+            return {k: shorten(v, n) for k, v in o.items()}
+        if isinstance(o, list):
+            return [shorten(v, n) for v in o]
+        return _short(o, n) if isinstance(o, str) else o
+    n = 160
+    while len(s) > limit and n >= 8:
+        line = shorten(line, n)
+        s = json.dumps(line)
+        n //= 2
     return s
 
 
@@ -871,20 +902,21 @@ def compact_leg(name, leg):
     line["config"] = {"workload": _short((leg.get("config") or {}).get("workload", ""), 200)}
     line["roofline"] = _compact_roof(leg.get("roofline"))
     line["cpu_baseline"] = _compact_cpu(leg.get("cpu_baseline"), 90)
-    s = json.dumps(line)
-    assert len(s) <= LEG_LIMIT, (name, len(s))
-    return s
+    return _fit(line, LEG_LIMIT, (("cpu_baseline", "sample"), ("roofline", "kernel"), ("cpu_baseline",)))
 
 
 def emit(out, path="bench_legs.json"):
     """legs (short lines) first, the full record to `path`, the parsed line LAST."""
-    for name, leg in (out.get("legs") or {}).items():
-        print(compact_leg(name, leg), flush=True)
-    try:
+    try:                                            # the full record first: nothing below may cost it
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
     except OSError as ex:
         print(f"[bench] could not write {path}: {ex}", file=sys.stderr)
+    for name, leg in (out.get("legs") or {}).items():
+        try:
+            print(compact_leg(name, leg), flush=True)
+        except Exception as ex:                     # a leg's line is a convenience, the headline line is the contract
+            print(json.dumps({"leg": name, "error": _short(repr(ex), 200)}), flush=True)
     print(compact_line(out, out.get("_products")), flush=True)
 
 

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -368,7 +369,9 @@ int build_tables(fm_engine* e)
         for (auto& c : e->convs) {
             if (c.cin == 3) continue;
             if (!pconv_takes(c.cout_p, c.cin_p, (long long)e->maxB * c.hin * c.win, c.win) ||
-                !pconv_takes(c.cin_p, c.cout_p, (long long)e->maxB * c.hout * c.wout, c.wout))
+                !pconv_takes(c.cin_p, c.cout_p, (long long)e->maxB * c.hout * c.wout, c.wout) ||
+                !pwgrad_takes(c.cout_p, c.cin_p, c.k, (long long)e->maxB * c.hout * c.wout, (long long)e->maxB * c.hin * c.win, c.win,
+                              c.pad))
                 e->planes = false;
         }
     }
@@ -457,7 +460,7 @@ int build_tables(fm_engine* e)
         long long off_f = 0, off_d = 0;
         int bf = 0, bd = 0;
         for (auto& c : e->convs) {
-            if (c.cin == 3) continue;
+            if (c.cin == 3 || e->planes) continue;      // (planes mode: the fp32-operand kernels never run on these convs)
             if (c.cout_p % 64 == 0 && c.cin_p % 32 == 0) {
                 c.sp_off = off_f;
                 jf.push_back({(long long)c.w_off, nullptr, off_f, c.cout_p, c.Kw / 32, bf});
@@ -1076,6 +1079,9 @@ void conv_fwd(fm_engine* e, int ci, const float* S, const float* x, float* y, in
         launch_pconv(p, groups, e->st);
         return;
     }
+    // planes mode keeps no fp32 operands for these convs (activations exist only as planes, no row-major weight planes): a shape
+    // the planes kernel does not take is a graph error, not a reason to run the fp32-operand kernel on unwritten buffers
+    if (e->planes && c.cin != 3) { soft(e, hipErrorInvalidValue); return; }
     const bool stem16 = e->precision && c.cin == 3;     // `x` is ignored: the operand is the im2col matrix
     if (e->precision && (c.k == 1 || stem16)) {          // bf16 storage + bf16 MFMA (pwconv_bf16.hip)
         PwParams q{};
@@ -1169,6 +1175,7 @@ void conv_dgrad(fm_engine* e, int ci, const float* S, const float* dy, float* dx
         }
         return;
     }
+    if (e->planes && c.cin != 3) { soft(e, hipErrorInvalidValue); return; }      // (see conv_fwd: no fp32-operand fallback in planes mode)
     if (e->precision && c.k == 1) {          // dX = dY W: the same streaming kernel with the transposed bf16 shadow
         PwParams q{};
         q.zeros = e->zeros;
@@ -1236,6 +1243,7 @@ void conv_wgrad(fm_engine* e, int ci, const float* x, const float* dy, int imgs,
         else soft(e, hipErrorInvalidValue);
         return;
     }
+    if (e->planes && c.cin != 3) { soft(e, hipErrorInvalidValue); return; }      // (see conv_fwd: no fp32-operand fallback in planes mode)
     const bool stem16 = e->precision && c.cin == 3;
     if (e->precision && (c.k == 1 || stem16)) {
         PwWgradParams q{};
@@ -2024,15 +2032,15 @@ int fm_create(const fm_config* cfg, fm_engine** out)
     ARGCHK(cfg->reserved[0] == 0 || (cfg->reserved[0] == 1 && cfg->model == 1),
            "precision (reserved[0]) must be 0 (fp32) or, for EfficientNet-B0, 1 (bf16 activations)");
     ARGCHK(cfg->reserved[1] >= 0 && cfg->reserved[1] <= 2, "reserved[1] (stream mode) must be 0, 1 or 2");
-    ARGCHK(cfg->reserved[2] >= 0 && cfg->reserved[2] <= 2,
+    ARGCHK(cfg->reserved[2] >= 0 && cfg->reserved[2] <= 3,
            "reserved[2] (product form of the fp32 conv GEMMs) must be 0 (library default: six bf16 partial products), 1 (fp32 "
-           "matrix pipe) or 2 (nine bf16 partial products)");
+           "matrix pipe), 2 (nine bf16 partial products) or 3 (exactly six, whatever the default)");
     fm_engine* e = new fm_engine();
     e->precision = cfg->reserved[0];
     e->stream_mode = cfg->reserved[1];
     // the product form belongs to the handle: fixed here, carried to every launch in the kernels' parameter blocks.  0 resolves
     // to the library default, which the test-only FM_MFMA_SPLIT overrides (read once, here)
-    e->products = cfg->reserved[2] == 1 ? 0 : (cfg->reserved[2] == 2 ? 9 : fm_mfma_split());
+    e->products = cfg->reserved[2] == 1 ? 0 : (cfg->reserved[2] == 2 ? 9 : (cfg->reserved[2] == 3 ? 6 : fm_mfma_split()));
     // planes mode: ResNet-18 in a split product form (FM_PLANES=0 keeps the fp32-operand kernels of igemm.hip: the A/B arm)
     e->planes = cfg->model == 0 && cfg->reserved[0] == 0 && e->products != 0 && !(getenv("FM_PLANES") && atoi(getenv("FM_PLANES")) == 0);
     e->dt = e->precision ? DT_BF16 : DT_F32;
@@ -2506,12 +2514,26 @@ int fm_select_topk_rows(fm_engine* e, const float* sim_dev, int64_t N, int32_t n
     for (int k = 0; k < n_cls; ++k) {
         ARGCHK(pool_n_host[k] >= 0 && pool_n_host[k] <= (pool_rows_host ? stride : N), "pool size");
         maxn = std::max(maxn, pool_n_host[k]);
+        // a row outside [0, N) would be an out-of-bounds read of sim in the counting / ranking kernels
+        if (pool_rows_host)
+            for (int i = 0; i < pool_n_host[k]; ++i) {
+                const int32_t r = pool_rows_host[(size_t)k * stride + i];
+                ARGCHK(r >= 0 && (int64_t)r < N, "pool row outside [0, N)");
+            }
     }
     const size_t rows_ints = pool_rows_host ? (size_t)n_cls * stride : 0;
     const size_t need = (size_t)n_cls * (3 + 2 * (size_t)cap) + rows_ints;
     if (e->tag_buf_ints < need) {
-        e->tag_buf_ints = need + need / 2;
-        DALLOC(e->tag_buf, e->tag_buf_ints);
+        if (e->tag_buf) {               // the outgrown buffer goes back now, not at fm_destroy (the stream may still read it)
+            HIPCHK(hipStreamSynchronize(e->st));
+            auto it = std::find(e->allocs.begin(), e->allocs.end(), (void*)e->tag_buf);
+            if (it != e->allocs.end()) e->allocs.erase(it);
+            (void)hipFree(e->tag_buf);
+            e->tag_buf = nullptr; e->tag_buf_ints = 0;
+        }
+        const size_t want = need + need / 2;
+        DALLOC(e->tag_buf, want);
+        e->tag_buf_ints = want;
     }
     int* d_pn = e->tag_buf;
     int* d_counts = d_pn + n_cls;

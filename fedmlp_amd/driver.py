@@ -109,10 +109,13 @@ class RoundAccumulator:
 
     def reduce(self, eng, dev, with_tao_proto):
         """-> (global num_batches_tracked counters, tao or None, Prototype or None); the averaged state is in the engine"""
-        from fedmlp_amd.fedavg import fedavg_allreduce, tao_allreduce, proto_allreduce
+        from fedmlp_amd.fedavg import fedavg_allreduce, tao_allreduce, proto_allreduce, state_agreement
         eng.state_tensor().copy_(self.acc)
         eng.counters(np.zeros(len(self.acc_cnt), np.int64))      # the counters are reduced as float64 below
         fedavg_allreduce(eng, 1.0)                               # fm_fedavg_allreduce: ncclAllReduce of the state arena
+        agree, worst = state_agreement(eng)                      # every rank starts the next round from the same w_glob
+        if not agree:
+            raise RuntimeError(f"the ranks' states differ after the FedAvg all-reduce (checksum spread {worst:.3e})")
         cnt = np.trunc(rank_sum(self.acc_cnt, dev) + 1e-9).astype(np.int64)   # utils/FedAvg.py:13 + load_state_dict
         eng.counters(cnt)
         if not with_tao_proto:

@@ -12,8 +12,9 @@ from . import _lib, spec
 
 MODEL_IDS = {"Resnet18": 0, "Efficient_b0": 1}
 PRECISION_IDS = {"fp32": 0, "bf16": 1}
-# fm_config.reserved[2]: None = the library default (six products), 0 = fp32 matrix pipe, 9 = all nine partial products
-PRODUCT_FORMS = {None: 0, 6: 0, 0: 1, 9: 2}
+# fm_config.reserved[2]: None = the library default (six products unless FM_MFMA_SPLIT says otherwise), 0 = fp32 matrix pipe,
+# 9 = all nine partial products, 6 = exactly six (an explicit request is not subject to the environment override)
+PRODUCT_FORMS = {None: 0, 6: 3, 0: 1, 9: 2}
 
 
 def _ptr(t):

@@ -11,6 +11,7 @@ Two forms of the same arithmetic:
     on CPU test rigs the same code runs over gloo tensors.
 """
 import copy
+import logging
 from collections import OrderedDict
 
 import numpy as np
@@ -76,6 +77,10 @@ def FedAvg_proto(Prototypes, weight, class_active_client_list):
 
 
 # ---- one client per GPU: RCCL --------------------------------------------------------
+_log = logging.getLogger("fedmlp_amd.fedavg")
+_warned_fallback = False
+
+
 def _dist():
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized()) else None
@@ -146,12 +151,41 @@ def fedavg_allreduce(engine, w):
     engine.state_scale(float(w))
     st = engine.state_tensor()
     if d is not None and d.get_world_size() > 1:
+        global _warned_fallback
+        if not _warned_fallback:
+            # a caller that skipped comm_init (or whose comm_init failed) gets a DIFFERENT path from the one bench.py / driver.py
+            # insist on: say so once
+            _warned_fallback = True
+            _log.warning("fedavg_allreduce: no library RCCL communicator (fm_comm_init was not called or failed): the all-reduce "
+                         "of the state goes through torch.distributed (%s) instead of fm_fedavg_allreduce", d.get_backend())
         d.all_reduce(st, op=d.ReduceOp.SUM)
         engine.state_tensor()                 # marks the engine's derived buffers (BN folds, weight packs) stale
         cnt = torch.from_numpy(engine.counters().astype(np.float64) * float(w)).to(st.device)
         d.all_reduce(cnt, op=d.ReduceOp.SUM)
         engine.counters(np.trunc(cnt.cpu().numpy() + 1e-9).astype(np.int64))
     return st
+
+
+def state_agreement(engine):
+    """After a FedAvg every rank must hold the SAME state (utils/FedAvg.py:7-14 hands one w_glob to every client, main.py:216-222).
+    Three checksums of the device arena -- the sum of its bit patterns as integers (any flipped bit moves it), the float64 sum and
+    the float64 sum of magnitudes -- are compared across ranks with ONE extra all-reduce: returns (agree, worst) where worst is the
+    largest difference between the ranks' checksums, relative to the magnitude sum.  A world of one agrees by definition.
+    The first multi-GPU run of bench.py / driver.py is therefore also a correctness run of the RCCL path."""
+    d = _dist()
+    if d is None or d.get_world_size() <= 1:
+        return True, 0.0
+    st = engine.state_tensor()
+    bits = st.view(torch.int32).to(torch.int64).sum().to(torch.float64)
+    s1 = st.to(torch.float64).sum()
+    s2 = st.to(torch.float64).abs().sum()
+    v = torch.stack([bits, s1, s2, -bits, -s1, -s2])
+    d.all_reduce(v, op=d.ReduceOp.MAX)                 # max(x) and max(-x) = -min(x) in one collective
+    v = v.cpu().numpy()
+    spread = v[:3] + v[3:]                             # max - min of each checksum over the ranks
+    scale = max(abs(float(v[2])), 1e-30)
+    worst = float(max(spread[1], spread[2]) / scale)
+    return bool(spread[0] == 0.0 and spread[1] == 0.0 and spread[2] == 0.0), worst
 
 
 def tao_allreduce(t, n_i, is_negative_client_mask, device="cpu", engine=None):

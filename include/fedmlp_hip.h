@@ -61,7 +61,8 @@ typedef struct fm_config {
                              reserved[2] = product form of the fp32 convolution GEMMs, fixed for the handle's life:
                              0 (default) the library default = every fp32 product as six exact bf16 partial products
                              on the bf16 matrix pipe, fp32 accumulation (csrc/split3.h); 1 = products on the fp32
-                             matrix pipe; 2 = all nine partial products.  fm_products() reports it. */
+                             matrix pipe; 2 = all nine partial products; 3 = exactly six (what 0 resolves to in the
+                             shipped library, but not overridden by the test-only FM_MFMA_SPLIT).  fm_products() reports it. */
     void*   stream;       /* hipStream_t; NULL = null stream                         */
 } fm_config;
 

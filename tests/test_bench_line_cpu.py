@@ -71,3 +71,21 @@ def test_emit_prints_legs_first_and_headline_last(tmp_path, canned):
 def test_failed_leg_is_reported_short():
     s = bench.compact_leg("x", {"error": "RuntimeError: " + "y" * 5000, "leg_wall_s": 0.1})
     assert len(s) < 1500 and json.loads(s)["leg"] == "x"
+
+
+def test_oversized_fields_are_truncated_not_fatal(canned):
+    """a long workload string / error / many ranks must shorten the line, never abort the run before it is printed."""
+    out = canned
+    out["config"]["workload"] = "w" * 5000
+    out["config"]["stream_mode"] = "s" * 3000
+    out["config"]["per_rank"] = [{"rank": r, "ms_per_step_incl_allreduce": 27.123456789, "allreduce_ms_total": 1.23456789,
+                                  "allreduces": 3} for r in range(64)]
+    out["roofline"]["kernel"] = "k" * 4000
+    s = bench.compact_line(out, 6)
+    assert len(s) <= 1800
+    d = json.loads(s)
+    assert d["value"] == out["value"] and d["ms_per_step"] == out["ms_per_step"] and d["roofline"]["frac"] == out["roofline"]["frac"]
+    leg = {"value": 1.0, "unit": "u", "config": {"workload": "w" * 9000}, "roofline": {"kernel": "k" * 9000, "frac": 0.5},
+           "cpu_baseline": {"value": 1, "unit": "u", "cores": 1, "kind": "port", "sample": "s" * 9000}}
+    s = bench.compact_leg("big", leg)
+    assert len(s) <= 1500 and json.loads(s)["value"] == 1.0

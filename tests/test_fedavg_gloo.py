@@ -72,6 +72,43 @@ def _worker(rank, port, out_dir):
     dist.destroy_process_group()
 
 
+def _agree_worker(rank, port, out_dir):
+    import logging
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD, timeout=datetime.timedelta(seconds=180))
+    from fedmlp_amd.fedavg import state_agreement
+    msgs = []
+
+    class H(logging.Handler):
+        def emit(self, rec):
+            msgs.append(rec.getMessage())
+    logging.getLogger("fedmlp_amd.fedavg").addHandler(H())
+    state, cnt, _, _ = _inputs(rank)
+    eng = FakeEngine(state.clone(), cnt.copy())
+    before = state_agreement(eng)                       # different inputs per rank: must be seen
+    fedavg_allreduce(eng, 0.5)
+    fedavg_allreduce(eng, 0.5)
+    after = state_agreement(eng)
+    eng.state[rank * 7 + 3] += 1e-6 * (rank + 1)        # ONE element nudged differently on each rank
+    nudged = state_agreement(eng)
+    np.savez(os.path.join(out_dir, f"a{rank}.npz"), before=before[0], after=after[0], nudged=nudged[0], worst=nudged[1],
+             warnings=len([m for m in msgs if "torch.distributed" in m]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_state_agreement_and_fallback_warning(tmp_path):
+    """after an all-reduce the ranks' states are compared through one extra collective of checksums
+    (bench.py --gpus N and driver.py fail on disagreement), and the torch.distributed fallback of fedavg_allreduce says so ONCE."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_agree_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    for r in range(WORLD):
+        got = np.load(os.path.join(str(tmp_path), f"a{r}.npz"))
+        assert not bool(got["before"]) and bool(got["after"]) and not bool(got["nudged"])
+        assert float(got["worst"]) > 0
+        assert int(got["warnings"]) == 1                # two all-reduces, one warning
+
+
 def test_allreduce_forms_match_reference_surface(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
