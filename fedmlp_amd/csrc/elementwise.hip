@@ -383,16 +383,17 @@ __global__ void bn_fold_tiles_kernel(const float* __restrict__ stats, float* __r
     const int t0 = blockIdx.x * per, t1 = min(tiles, t0 + per);
     const float* st = stats + (size_t)g * tiles * C2;
     for (int c = threadIdx.x; c < C2; c += blockDim.x) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // (double sums, round 6: ~100 fp32 terms per chunk were the one fp32 accumulation in the statistics path)
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int t = t0;
         for (; t + 3 < t1; t += 4) {
-            a0 += st[(size_t)t * C2 + c];
-            a1 += st[(size_t)(t + 1) * C2 + c];
-            a2 += st[(size_t)(t + 2) * C2 + c];
-            a3 += st[(size_t)(t + 3) * C2 + c];
+            a0 += (double)st[(size_t)t * C2 + c];
+            a1 += (double)st[(size_t)(t + 1) * C2 + c];
+            a2 += (double)st[(size_t)(t + 2) * C2 + c];
+            a3 += (double)st[(size_t)(t + 3) * C2 + c];
         }
-        for (; t < t1; ++t) a0 += st[(size_t)t * C2 + c];
-        out[((size_t)g * nch + blockIdx.x) * C2 + c] = (a0 + a1) + (a2 + a3);
+        for (; t < t1; ++t) a0 += (double)st[(size_t)t * C2 + c];
+        out[((size_t)g * nch + blockIdx.x) * C2 + c] = (float)((a0 + a1) + (a2 + a3));
     }
 }
 
@@ -609,7 +610,8 @@ int bn_bwd_blocks(int pix_per_group)
 __global__ void stem_pool_bn_reduce_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
                                            const uint8_t* __restrict__ idx, const float* __restrict__ y,
                                            const float* __restrict__ mean, const float* __restrict__ istd,
-                                           float* __restrict__ part, int imgs_per_group, int H, int W, int C)
+                                           float* __restrict__ part, int imgs_per_group, int H, int W, int C,
+                                           const float* __restrict__ gamma, const float* __restrict__ beta)
 {
     __shared__ f32x4 red[2][256];
     const int g = blockIdx.y, nblk = gridDim.x;
@@ -619,6 +621,18 @@ __global__ void stem_pool_bn_reduce_kernel(const float* __restrict__ dp, const f
     const int TP = 8 * P;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + cq * 4);
     const f32x4 is = *reinterpret_cast<const f32x4*>(istd + g * C + cq * 4);
+    // round 6: the normalised value at the argmax comes from the POOLED value itself -- a pooled value > 0 is
+    // fma(y0, gamma istd, beta - mean gamma istd) of its argmax, so xhat = (pooled - beta) / gamma -- instead of a 4-byte gather of
+    // y0 out of the dense map per element (the gathers touched every line of the 112 x 112 map: the pass read 0.4 GB more than
+    // its inputs).  A channel whose |gamma| is small keeps the gather (the division would magnify pooled's rounding).
+    f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = ga;
+    bool fast[4] = {false, false, false, false};
+    if (gamma) {
+        ga = *reinterpret_cast<const f32x4*>(gamma + cq * 4);
+        be = *reinterpret_cast<const f32x4*>(beta + cq * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fast[k] = fabsf(ga[k]) >= 0.0625f;
+    }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (int t0 = blockIdx.x * TP; t0 < npool; t0 += nblk * TP)
         for (int pp = t0 + pl; pp < min(npool, t0 + TP); pp += P) {
@@ -634,10 +648,14 @@ __global__ void stem_pool_bn_reduce_kernel(const float* __restrict__ dp, const f
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(pv[k] > 0.f)) continue;
-                const int ih = 2 * oh - 1 + code[k] / 3, iw = 2 * ow - 1 + code[k] % 3;
-                const float yy = y[((size_t)(img * H + ih) * W + iw) * C + cq * 4 + k];
+                float xh;
+                if (fast[k]) xh = (pv[k] - be[k]) / ga[k];
+                else {
+                    const int ih = 2 * oh - 1 + code[k] / 3, iw = 2 * ow - 1 + code[k] % 3;
+                    xh = (y[((size_t)(img * H + ih) * W + iw) * C + cq * 4 + k] - mu[k]) * is[k];
+                }
                 s1[k] += d[k];
-                s2[k] += d[k] * ((yy - mu[k]) * is[k]);
+                s2[k] += d[k] * xh;
             }
         }
     red[0][threadIdx.x] = s1;
@@ -652,6 +670,65 @@ __global__ void stem_pool_bn_reduce_kernel(const float* __restrict__ dp, const f
         *reinterpret_cast<f32x4*>(o) = s1;
         *reinterpret_cast<f32x4*>(o + C) = s2;
     }
+}
+// round 6, even H and W: one thread = the 2 x 2 dense positions (2 oh + a, 2 ow + b) of one pooled index and channel quad.  They
+// are covered by the four windows (oh + i, ow + j) only -- window (i, j) reaches position (a, b) when i <= a and j <= b, with the
+// window-local code (a - 2 i + 1) * 3 + (b - 2 j + 1) -- so a thread reads four windows' (argmax code, pooled value, gradient) for
+// four outputs where the per-position kernel below read 2.25 windows per output, and does its index arithmetic once for four.
+__global__ __launch_bounds__(256) void stem_pool_bn_apply2_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
+                                                                  const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                                                  const float* __restrict__ ca, const float* __restrict__ cb,
+                                                                  const float* __restrict__ cc, float* __restrict__ dy,
+                                                                  int imgs_per_group, int H, int W, int C)
+{
+    const int g = blockIdx.y;
+    const int Hp = H / 2, Wp = W / 2, Q = C >> 2;
+    const int64_t n = (int64_t)imgs_per_group * Hp * Wp * Q;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int cq = (int)(i % Q);
+    int64_t t = i / Q;
+    const int ow = (int)(t % Wp); t /= Wp;
+    const int oh = (int)(t % Hp);
+    const int img = g * imgs_per_group + (int)(t / Hp);
+    // gw[i][j][k] = the gradient window (i, j) sends, cw = the window-local code of its argmax (15: nothing to send)
+    f32x4 gw[2][2];
+    int cw[2][2][4];
+#pragma unroll
+    for (int wi = 0; wi < 2; ++wi)
+#pragma unroll
+        for (int wj = 0; wj < 2; ++wj) {
+            const bool ok = oh + wi < Hp && ow + wj < Wp;
+            const size_t o = ((size_t)(img * Hp + (ok ? oh + wi : oh)) * Wp + (ok ? ow + wj : ow)) * C + cq * 4;
+            const uchar4 c4 = *reinterpret_cast<const uchar4*>(idx + o);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pooled + o);
+            gw[wi][wj] = *reinterpret_cast<const f32x4*>(dp + o);
+            const int code[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cw[wi][wj][k] = (ok && pv[k] > 0.f) ? code[k] : 15;
+        }
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ca + g * C + cq * 4);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(cb + g * C + cq * 4);
+    const f32x4 c4v = *reinterpret_cast<const f32x4*>(cc + g * C + cq * 4);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // the same order of additions as the per-position kernel: windows by rising (oh, ow)
+#pragma unroll
+            for (int wi = 0; wi <= a; ++wi)
+#pragma unroll
+                for (int wj = 0; wj <= b; ++wj) {
+                    const int code = (a - 2 * wi + 1) * 3 + (b - 2 * wj + 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cw[wi][wj][k] == code) acc[k] += gw[wi][wj][k];
+                }
+            const size_t od = ((size_t)(img * H + 2 * oh + a) * W + 2 * ow + b) * C + cq * 4;
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + od);
+            *reinterpret_cast<f32x4*>(dy + od) = a4 * acc + b4 * yy + c4v;
+        }
 }
 __global__ void stem_pool_bn_apply_kernel(const float* __restrict__ dp, const float* __restrict__ pooled,
                                           const uint8_t* __restrict__ idx, const float* __restrict__ y,
@@ -698,16 +775,24 @@ __global__ void stem_pool_bn_apply_kernel(const float* __restrict__ dp, const fl
 }
 int stem_pool_bn_blocks(int pooled_per_group) { return bn_bwd_blocks(pooled_per_group); }
 void k_stem_pool_bn_reduce(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* mean,
-                           const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s)
+                           const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s,
+                           const float* gamma, const float* beta)
 {
     dim3 grid(stem_pool_bn_blocks(imgs_per_group * (H / 2) * (W / 2)), groups);
     hipLaunchKernelGGL(stem_pool_bn_reduce_kernel, grid, dim3(256), 0, s, dpooled, pooled, idx, y, mean, istd, part,
-                       imgs_per_group, H, W, C);
+                       imgs_per_group, H, W, C, gamma, beta);
 }
 void k_stem_pool_bn_apply(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* ca,
                           const float* cb, const float* cc, float* dy, int groups, int imgs_per_group, int H, int W, int C,
                           hipStream_t s)
 {
+    static const int blocks2 = fm_tune("FM_STEM_APPLY_2X2", 1);
+    if (blocks2 && H % 2 == 0 && W % 2 == 0) {
+        const int64_t n2 = (int64_t)imgs_per_group * (H / 2) * (W / 2) * (C / 4);
+        hipLaunchKernelGGL(stem_pool_bn_apply2_kernel, dim3(cdiv(n2, 256), groups), dim3(256), 0, s, dpooled, pooled, idx, y, ca, cb,
+                           cc, dy, imgs_per_group, H, W, C);
+        return;
+    }
     const int64_t n = (int64_t)imgs_per_group * H * W * (C / 4);
     hipLaunchKernelGGL(stem_pool_bn_apply_kernel, dim3(cdiv(n, 256), groups), dim3(256), 0, s, dpooled, pooled, idx, y, ca, cb,
                        cc, dy, imgs_per_group, H, W, C);

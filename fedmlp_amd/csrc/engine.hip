@@ -1576,7 +1576,10 @@ void backward_and_step(fm_engine* e, int groups, int B)
         // max-pool backward + BatchNorm backward of the stem in two passes, without the dense intermediate (elementwise.hip)
         Bn& b0 = e->bns[0];
         const int pooled_pg = B * (c0.hout / 2) * (c0.wout / 2), pix = B * c0.hout * c0.wout;
-        k_stem_pool_bn_reduce(ga, e->p0, e->idx0, c0.y, b0.mean, b0.istd, e->ws_part, groups, B, c0.hout, c0.wout, 64, e->st);
+        static const int from_pooled = fm_tune("FM_STEM_XHAT_FROM_POOLED", 1);
+        k_stem_pool_bn_reduce(ga, e->p0, e->idx0, c0.y, b0.mean, b0.istd, e->ws_part, groups, B, c0.hout, c0.wout, 64, e->st,
+                              from_pooled ? e->state + e->off_gamma + b0.ch_off : nullptr,
+                              from_pooled ? e->state + e->off_beta + b0.ch_off : nullptr);
         k_bn_bwd_finalize(e->ws_part, groups, stem_pool_bn_blocks(pooled_pg), 64, pix, e->state + e->off_gamma + b0.ch_off,
                           b0.mean, b0.istd, e->ca, e->cb, e->cc, e->grad + e->off_gamma + b0.ch_off,
                           e->grad + e->off_beta + b0.ch_off, e->st);

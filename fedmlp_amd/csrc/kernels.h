@@ -95,7 +95,8 @@ void k_stem_relu_bits(const float* y, const float* scale, const float* shift, ui
                       hipStream_t s);
 int stem_pool_bn_blocks(int pooled_per_group);
 void k_stem_pool_bn_reduce(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* mean,
-                           const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s);
+                           const float* istd, float* part, int groups, int imgs_per_group, int H, int W, int C, hipStream_t s,
+                           const float* gamma = nullptr, const float* beta = nullptr);    // gamma / beta: xhat from the pooled value
 void k_stem_pool_bn_apply(const float* dpooled, const float* pooled, const uint8_t* idx, const float* y, const float* ca,
                           const float* cb, const float* cc, float* dy, int groups, int imgs_per_group, int H, int W, int C,
                           hipStream_t s);
