@@ -66,6 +66,12 @@ template <int CTRL> __device__ __forceinline__ float pc_dpp(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
+// f(integral_constant<int, 0>) ... f(<3>): a loop whose index is a template argument inside f (the LDS reads' offsets are immediates)
+template <typename F> __device__ __forceinline__ void pc_for4(F f)
+{
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{});
+    f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+}
 template <int SP> __device__ __forceinline__ f32x4 pc_mfma(const sp_u32x4 (&a)[3], const sp_u32x4 (&b)[3], f32x4 v)
 {
     return mfma_split<SP>(a[0], a[1], a[2], b[0], b[1], b[2], v);
@@ -92,8 +98,14 @@ __device__ unsigned long long pc_prof[256 * 8];
 #else
 #define PC_T(i) do { } while (0)
 #endif
+#ifndef PC_WAVES_PER_EU
+#define PC_WAVES_PER_EU 2
+#endif
+#ifndef PC_ROW_MAJOR
+#define PC_ROW_MAJOR 1
+#endif
 template <int FR, int FC, int NS, int SP, bool TS = false>
-__global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
+__global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const IgemmParams p)
 {
 #if __HIP_DEVICE_COMPILE__
 #ifdef PC_PHASES
@@ -306,7 +318,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         // D2 (FR == 2: a column is only 12 MFMAs): the B fragments are read TWO columns ahead into one buffer per column
         constexpr bool D2 = FR == 2 && FC == 4;
-        sp_u32x4 A0[FR][3], A1[FR][3], Bb[D2 ? 4 : 2][3];
+        // RM (the 128-row tiles, round 6): the step's MFMAs run ROW by row -- all four B columns of the step sit in registers (48), the
+        // A rows roll through two buffers (24) -- instead of column by column with both steps' A fragments resident (96 + 24).  Same
+        // reads, MFMAs, stages and one barrier per step; 48 registers fewer, which is what lets a wave of a streaming kernel of the
+        // other stream (BatchNorm apply: 32 registers) live beside the two GEMM waves of a SIMD (512 registers per lane and SIMD)
+        constexpr bool RM = PC_ROW_MAJOR && FR == 4 && FC == 4 && NS == 2;
+        sp_u32x4 A0[RM ? 1 : FR][3], A1[RM ? 1 : FR][3], Bb[(D2 || RM) ? 4 : 2][3];
     // BASE = the fragment base address of the stage slot the read takes (Af0 + slot * SA, Bf0 + slot * SB)
 #define PC_READA(BASE, R, DST)                                                                  \
     {                                                                                           \
@@ -413,6 +430,17 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
             if (k0 + 2 < k1) issueA(cur, k0 + 2, 2);
             if constexpr (!TS) { if (k0 + 2 < k1) issueB(cur, 2); }
         }
+        if constexpr (RM) {
+            // row 0 of A(k0) and all four columns of B(k0); the other rows of A(k0) are read while the step runs, so its stage is
+            // not free yet: A(k0 + 2) goes out behind step k0's barrier like every other A stage
+            PC_READA(Af0, 0, A0[0]);
+            pc_for4([&](auto ic) {
+                constexpr int c = decltype(ic)::value;
+                if constexpr (TS) { PC_READB(colbase(c, tap_d(it_cur), 0u, bsel(tap_d(it_cur), 0u)), c, Bb[c]); }
+                else PC_READB(Bf0, c, Bb[c]);
+            });
+            PC_LGKM0();
+        } else {
         PC_READA(Af0, 0, A0[0]);
         PC_READA(Af0, 1, A0[1]);
         if constexpr (FR == 4) { PC_READA(Af0, 2, A0[2]); PC_READA(Af0, 3, A0[3]); }
@@ -428,6 +456,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + NS)
         asm volatile("" ::: "memory");
         if (k0 + NS < k1) issueA(cur, k0 + NS, 0);
+        }
 
         PC_T(2);
         int ib = 0;                            // stage slot of the current step
@@ -568,6 +597,109 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        if constexpr (RM) {
+            // ---- one K-step, row-major.  At its start: row 0 of A(s) in A0[0], B(s) columns 0 .. 3 in Bb (columns 1 .. 3 possibly
+            // still in flight: counted waits in pass 0).  Pass r = row r's 24 MFMAs with row r + 1 read behind them.  The barrier
+            // sits before pass 3: every wave holds all of A(s) and B(s), and A(s + 1), B(s + 1) have landed -- the stage of A(s) takes
+            // A(s + 2); pass 3 re-fills the registers column by column with B(s + 1) behind each column's last use ---------------
+            auto rstep = [&](auto full_c, int s) {
+                constexpr bool FULL = decltype(full_c)::value;
+                const int ib1 = ib ^ 1;
+                const unsigned a_cur = Af0 + ib * SA, a_nxt = Af0 + ib1 * SA;
+                unsigned b_nxt = 0, so_nxt = 0;
+                int d_nxt = 1;
+                bool row_end = false;
+                if constexpr (TS) {
+                    const int it1 = it_cur == 8 ? 0 : it_cur + 1;
+                    d_nxt = tap_d(it1);
+                    row_end = it_cur == 2 || it_cur == 5 || it_cur == 8;
+                    so_nxt = (unsigned)((row_end ? ub ^ 1 : ub) * SB);
+                    b_nxt = bsel(d_nxt, so_nxt);
+                } else
+                    b_nxt = Bf0 + ib1 * SB;
+                auto bn = [&](int c) { if constexpr (TS) return colbase(c, d_nxt, so_nxt, b_nxt); else return b_nxt; };
+                const bool more = FULL || s + 1 < k1;
+    // the wait in FRONT of column C of pass 0: columns C .. 3 of this step's B (read behind the previous step's pass 3) and
+    // row 1 of A (read at this pass's head) may still be in flight: LDS returns in order, so all but the youngest 3 (4 - C) reads
+    // are waited for.  The column's registers are operands: the MFMAs that read them stay behind the wait; so is the previous
+    // column's accumulator: the wait stays behind that column's MFMAs (three bare waits moved to the head of the pass together)
+#define PC_WAIT_BCOL(C)                                                                                                         \
+                asm volatile("s_waitcnt lgkmcnt(%4)"                                                                           \
+                             : "+v"(Bb[C][0]), "+v"(Bb[C][1]), "+v"(Bb[C][2]), "+v"(acc[0][(C) - 1])                            \
+                             : "n"(3 * (4 - (C)))                                                                               \
+                             : "memory")
+    // the wait at the END of pass R (row R + 1 has arrived), tied to the pass's accumulators (PC_LGKM0_COL)
+#define PC_WAIT_ROW(R)                                                                                                          \
+                do {                                                                                                            \
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[R][0]), "+v"(acc[R][1]), "+v"(acc[R][2]), "+v"(acc[R][3])::"memory"); \
+                    __builtin_amdgcn_sched_barrier(0);                                                                          \
+                } while (0)
+                // pass 0
+                PC_READA(a_cur, 1, A1[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = pc_mfma<SP>(A0[0], Bb[0], acc[0][0]);
+                PC_WAIT_BCOL(1);
+                acc[0][1] = pc_mfma<SP>(A0[0], Bb[1], acc[0][1]);
+                PC_WAIT_BCOL(2);
+                acc[0][2] = pc_mfma<SP>(A0[0], Bb[2], acc[0][2]);
+                PC_WAIT_BCOL(3);
+                acc[0][3] = pc_mfma<SP>(A0[0], Bb[3], acc[0][3]);
+                PC_WAIT_ROW(0);
+                // pass 1
+                PC_READA(a_cur, 2, A0[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < FC; ++c) acc[1][c] = pc_mfma<SP>(A1[0], Bb[c], acc[1][c]);
+                PC_WAIT_ROW(1);
+                // pass 2
+                PC_READA(a_cur, 3, A1[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < FC; ++c) acc[2][c] = pc_mfma<SP>(A0[0], Bb[c], acc[2][c]);
+                PC_WAIT_ROW(2);
+                // every wave holds A(s) and B(s): the barrier, then the DMA into the stages they came from
+                wait_dma(FULL);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                auto issue_dma = [&]() {
+                    if (FULL || s + 2 < k1) issueA(cur, s + 2, ib);
+                    if constexpr (TS) {
+                        if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
+                    } else {
+                        if (FULL || s + 2 < k1) issueB(cur, ib);
+                    }
+                };
+                if (!late) issue_dma();
+                // pass 3: row 0 of A(s + 1) at its head; column c of B(s + 1) behind column c's MFMAs
+                if (more) PC_READA(a_nxt, 0, A0[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                pc_for4([&](auto ic) {
+                    constexpr int c = decltype(ic)::value;
+                    acc[3][c] = pc_mfma<SP>(A1[0], Bb[c], acc[3][c]);
+                    // (the accumulator is an operand: the read of the next B(c) stays behind the MFMAs that read this one)
+                    asm volatile("" : "+v"(acc[3][c]), "+v"(Bb[c][0]), "+v"(Bb[c][1]), "+v"(Bb[c][2]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) PC_READB(bn(c), c, Bb[c]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if (late) issue_dma();
+                // row 0 of A(s + 1) and column 0 of B(s + 1) are the oldest six of the fifteen reads in flight
+                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(A0[0][0]), "+v"(A0[0][1]), "+v"(A0[0][2]), "+v"(Bb[0][0]), "+v"(Bb[0][1]),
+                             "+v"(Bb[0][2])::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+#undef PC_WAIT_BCOL
+#undef PC_WAIT_ROW
+                if constexpr (TS) {
+                    if (row_end) { ub ^= 1; ++Ucur; }
+                    it_cur = it_cur == 8 ? 0 : it_cur + 1;
+                    if (b_age < 3) ++b_age;
+                }
+                ib = ib1;
+            };
+            int s = k0;
+            for (; s + 3 <= k1; ++s) rstep(std::true_type{}, s);       // FULL: steps s + 1 and s + 2 exist
+            for (; s < k1; ++s) rstep(std::false_type{}, s);
+        } else {
         int s = k0;
         for (; s + NS + 3 <= k1; s += 2) {     // steps s and s + 1 are FULL: s + 1 + NS + 1 < k1
             step(I0{}, std::true_type{}, s, A0, A1);
@@ -576,6 +708,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(const IgemmParams p)
         for (; s < k1; s += 2) {
             step(I0{}, std::false_type{}, s, A0, A1);
             if (s + 1 < k1) step(I1{}, std::false_type{}, s + 1, A1, A0);
+        }
         }
 #undef PC_READA
 #undef PC_READB
