@@ -104,6 +104,9 @@ __device__ unsigned long long pc_prof[256 * 8];
 #ifndef PC_ROW_MAJOR
 #define PC_ROW_MAJOR 1
 #endif
+#ifndef PC_ROW_MAJOR_2
+#define PC_ROW_MAJOR_2 1           // the 64-row tiles too (two passes of 24 MFMAs per step)
+#endif
 template <int FR, int FC, int NS, int SP, bool TS = false>
 __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const IgemmParams p)
 {
@@ -317,12 +320,12 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
 #pragma unroll
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         // D2 (FR == 2: a column is only 12 MFMAs): the B fragments are read TWO columns ahead into one buffer per column
-        constexpr bool D2 = FR == 2 && FC == 4;
         // RM (the 128-row tiles, round 6): the step's MFMAs run ROW by row -- all four B columns of the step sit in registers (48), the
         // A rows roll through two buffers (24) -- instead of column by column with both steps' A fragments resident (96 + 24).  Same
         // reads, MFMAs, stages and one barrier per step; 48 registers fewer, which is what lets a wave of a streaming kernel of the
         // other stream (BatchNorm apply: 32 registers) live beside the two GEMM waves of a SIMD (512 registers per lane and SIMD)
-        constexpr bool RM = PC_ROW_MAJOR && FR == 4 && FC == 4 && NS == 2;
+        constexpr bool RM = FC == 4 && NS == 2 && ((PC_ROW_MAJOR && FR == 4) || (PC_ROW_MAJOR_2 && FR == 2));
+        constexpr bool D2 = FR == 2 && FC == 4 && !RM;
         sp_u32x4 A0[RM ? 1 : FR][3], A1[RM ? 1 : FR][3], Bb[(D2 || RM) ? 4 : 2][3];
     // BASE = the fragment base address of the stage slot the read takes (Af0 + slot * SA, Bf0 + slot * SB)
 #define PC_READA(BASE, R, DST)                                                                  \
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
         if constexpr (RM) {
             // ---- one K-step, row-major.  At its start: row 0 of A(s) in A0[0], B(s) columns 0 .. 3 in Bb (columns 1 .. 3 possibly
             // still in flight: counted waits in pass 0).  Pass r = row r's 24 MFMAs with row r + 1 read behind them.  The barrier
-            // sits before pass 3: every wave holds all of A(s) and B(s), and A(s + 1), B(s + 1) have landed -- the stage of A(s) takes
+            // sits before the LAST pass (3; 1 for the 64-row tiles): every wave holds all of A(s) and B(s), and A(s + 1), B(s + 1) have landed -- the stage of A(s) takes
             // A(s + 2); pass 3 re-fills the registers column by column with B(s + 1) behind each column's last use ---------------
             auto rstep = [&](auto full_c, int s) {
                 constexpr bool FULL = decltype(full_c)::value;
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
     // the wait at the END of pass R (row R + 1 has arrived), tied to the pass's accumulators (PC_LGKM0_COL)
 #define PC_WAIT_ROW(R)                                                                                                          \
                 do {                                                                                                            \
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[R][0]), "+v"(acc[R][1]), "+v"(acc[R][2]), "+v"(acc[R][3])::"memory"); \
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[R][0]), "+v"(acc[R][1]), "+v"(acc[R][2]), "+v"(acc[R][3])::"memory"); \
                     __builtin_amdgcn_sched_barrier(0);                                                                          \
                 } while (0)
                 // pass 0
@@ -645,18 +648,20 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
                 PC_WAIT_BCOL(3);
                 acc[0][3] = pc_mfma<SP>(A0[0], Bb[3], acc[0][3]);
                 PC_WAIT_ROW(0);
-                // pass 1
-                PC_READA(a_cur, 2, A0[0]);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FR == 4) {
+                    // pass 1
+                    PC_READA(a_cur, 2, A0[0]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < FC; ++c) acc[1][c] = pc_mfma<SP>(A1[0], Bb[c], acc[1][c]);
-                PC_WAIT_ROW(1);
-                // pass 2
-                PC_READA(a_cur, 3, A1[0]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int c = 0; c < FC; ++c) acc[1][c] = pc_mfma<SP>(A1[0], Bb[c], acc[1][c]);
+                    PC_WAIT_ROW(1);
+                    // pass 2
+                    PC_READA(a_cur, 3, A1[0]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < FC; ++c) acc[2][c] = pc_mfma<SP>(A0[0], Bb[c], acc[2][c]);
-                PC_WAIT_ROW(2);
+                    for (int c = 0; c < FC; ++c) acc[2][c] = pc_mfma<SP>(A0[0], Bb[c], acc[2][c]);
+                    PC_WAIT_ROW(2);
+                }
                 // every wave holds A(s) and B(s): the barrier, then the DMA into the stages they came from
                 wait_dma(FULL);
                 __builtin_amdgcn_s_barrier();
@@ -670,14 +675,14 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
                     }
                 };
                 if (!late) issue_dma();
-                // pass 3: row 0 of A(s + 1) at its head; column c of B(s + 1) behind column c's MFMAs
+                // the last pass: row 0 of A(s + 1) at its head; column c of B(s + 1) behind column c's MFMAs
                 if (more) PC_READA(a_nxt, 0, A0[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 pc_for4([&](auto ic) {
                     constexpr int c = decltype(ic)::value;
-                    acc[3][c] = pc_mfma<SP>(A1[0], Bb[c], acc[3][c]);
+                    acc[FR - 1][c] = pc_mfma<SP>(A1[0], Bb[c], acc[FR - 1][c]);
                     // (the accumulator is an operand: the read of the next B(c) stays behind the MFMAs that read this one)
-                    asm volatile("" : "+v"(acc[3][c]), "+v"(Bb[c][0]), "+v"(Bb[c][1]), "+v"(Bb[c][2]));
+                    asm volatile("" : "+v"(acc[FR - 1][c]), "+v"(Bb[c][0]), "+v"(Bb[c][1]), "+v"(Bb[c][2]));
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) PC_READB(bn(c), c, Bb[c]);
                 });

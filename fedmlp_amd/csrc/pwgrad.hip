@@ -41,6 +41,17 @@ template <int IMM> __device__ __forceinline__ uint2 pw_read_tr(unsigned addr)
 #endif
 
 // FR: 16-channel m tiles per wave (4 or 2: BM = 128 / 64); FC: 16-column n tiles per wave (4 or 3: BN = 256 / 192)
+#ifndef PW_ROW_MAJOR
+#define PW_ROW_MAJOR 1
+#endif
+// f(integral_constant<int, 0>) ... f(<N - 1>): a loop whose index is a template argument inside f (the LDS reads' offsets are immediates)
+template <int N, typename F> __device__ __forceinline__ void pw_for(F f)
+{
+    f(std::integral_constant<int, 0>{});
+    if constexpr (N > 1) f(std::integral_constant<int, 1>{});
+    if constexpr (N > 2) f(std::integral_constant<int, 2>{});
+    if constexpr (N > 3) f(std::integral_constant<int, 3>{});
+}
 template <int FR, int FC, int SP>
 __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
 {
@@ -155,7 +166,11 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
     for (int r = 0; r < FR; ++r)
 #pragma unroll
         for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    sp_u32x4 A0[FR][3], A1[FR][3], Bb[2][3];
+    // RM (round 6, as pconv.hip): the step's MFMAs run row by row -- all FC columns of X in registers, the dY rows rolling through
+    // two buffers -- instead of column by column with both steps' dY fragments resident: 48 registers fewer (room for a wave of a
+    // streaming kernel of the other stream beside the two GEMM waves of a SIMD), same reads, MFMAs, stages, one barrier per step
+    constexpr bool RM = PW_ROW_MAJOR != 0;
+    sp_u32x4 A0[RM ? 1 : FR][3], A1[RM ? 1 : FR][3], Bb[RM ? FC : 2][3];
     // T = tile index inside the block tile (compile-time after unrolling: wm / wn are folded into the base address instead)
     const unsigned a_w = (unsigned)((wm * FR >> 1) * 6144), b_w = (unsigned)((wn * FC >> 1) * 6144);
     // (wm * FR and wn * FC are even for FR = 2, 4 and FC = 4; for FC = 3 the wave's first n tile may be odd: handled by hh0)
@@ -197,6 +212,83 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
 #define PW_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
 #define PW_MFMA(R, C, AC, BI_) acc[R][C] = mfma_split<SP>(Bb[BI_][0], Bb[BI_][1], Bb[BI_][2], AC[R][0], AC[R][1], AC[R][2], acc[R][C])
 
+    if constexpr (RM) {
+      if (nsteps > 0) {
+        issueA(0);
+        issueB(0);
+        if (1 < nsteps) { issueA(1); issueB(1); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        PW_READA(0, 0, A0[0]);
+        pw_for<FC>([&](auto ic) { constexpr int c = decltype(ic)::value; PW_READB(0, c, Bb[c]); });
+        PW_LGKM0();
+        // one K-step: at its start row 0 of dY(s) sits in A0[0] and the FC columns of X(s) in Bb (columns 1 .. possibly in flight:
+        // counted waits in pass 0; a fragment = six LDS reads, the counter holds 15).  The barrier sits before the LAST pass: every
+        // wave holds dY(s), X(s); dY(s + 1), X(s + 1) have landed: the stages take step s + 2, the last pass re-fills the registers
+        auto rstep = [&](auto full_c, int s) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const int sl = s & 1, sl1 = sl ^ 1;
+            const bool more = FULL || s + 1 < nsteps;
+#define PW_WAIT_ROW(R)                                                                                                          \
+            do {                                                                                                                \
+                if constexpr (FC == 4)                                                                                          \
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[R][0]), "+v"(acc[R][1]), "+v"(acc[R][2]), "+v"(acc[R][3])::"memory"); \
+                else                                                                                                            \
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[R][0]), "+v"(acc[R][1]), "+v"(acc[R][2])::"memory");         \
+                __builtin_amdgcn_sched_barrier(0);                                                                              \
+            } while (0)
+            PW_READA(sl, 1, A1[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            pw_for<FC>([&](auto ic) {
+                constexpr int c = decltype(ic)::value;
+                if constexpr (c > 0) {
+                    // columns c .. FC - 1 and row 1 may still be in flight (LDS returns in order): all but the youngest are waited for
+                    constexpr int N = 6 * (FC - c) > 15 ? 15 : 6 * (FC - c);
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(Bb[c][0]), "+v"(Bb[c][1]), "+v"(Bb[c][2]), "+v"(acc[0][c - 1]) : "n"(N) : "memory");
+                }
+                acc[0][c] = mfma_split<SP>(Bb[c][0], Bb[c][1], Bb[c][2], A0[0][0], A0[0][1], A0[0][2], acc[0][c]);
+            });
+            PW_WAIT_ROW(0);
+            if constexpr (FR == 4) {
+                PW_READA(sl, 2, A0[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < FC; ++c) acc[1][c] = mfma_split<SP>(Bb[c][0], Bb[c][1], Bb[c][2], A1[0][0], A1[0][1], A1[0][2], acc[1][c]);
+                PW_WAIT_ROW(1);
+                PW_READA(sl, 3, A1[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < FC; ++c) acc[2][c] = mfma_split<SP>(Bb[c][0], Bb[c][1], Bb[c][2], A0[0][0], A0[0][1], A0[0][2], acc[2][c]);
+                PW_WAIT_ROW(2);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (FULL || s + 2 < nsteps) { issueA(sl); issueB(sl); }
+            if (more) PW_READA(sl1, 0, A0[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            pw_for<FC>([&](auto ic) {
+                constexpr int c = decltype(ic)::value;
+                acc[FR - 1][c] = mfma_split<SP>(Bb[c][0], Bb[c][1], Bb[c][2], A1[0][0], A1[0][1], A1[0][2], acc[FR - 1][c]);
+                asm volatile("" : "+v"(acc[FR - 1][c]), "+v"(Bb[c][0]), "+v"(Bb[c][1]), "+v"(Bb[c][2]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) PW_READB(sl1, c, Bb[c]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                constexpr int N = 6 * (FC - 1) > 15 ? 15 : 6 * (FC - 1);       // row 0 and column 0 of the next step are the oldest twelve
+                asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(A0[0][0]), "+v"(A0[0][1]), "+v"(A0[0][2]), "+v"(Bb[0][0]), "+v"(Bb[0][1]),
+                             "+v"(Bb[0][2]) : "n"(N) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#undef PW_WAIT_ROW
+        };
+        int s = 0;
+        for (; s + 3 <= nsteps; ++s) rstep(std::true_type{}, s);
+        for (; s < nsteps; ++s) rstep(std::false_type{}, s);
+      }
+    } else
     if (nsteps > 0) {
         // ---- prologue ----------------------------------------------------------------------------------------------------
         issueA(0);
