@@ -1549,26 +1549,42 @@ void backward_and_step(fm_engine* e, int groups, int B)
         if (pm && !last) bn_bwd(e, blk.c2, ga, nullptr, nullptr, ga, groups, B, false, gbp, blk.outp);
         else bn_bwd(e, blk.c2, ga, blk.out, pm ? nullptr : GB, ga, groups, B, false, gbp);
         if (blk.ds >= 0) { guard(1, par); bn_bwd(e, blk.ds, ga, nullptr, pm ? nullptr : GC, nullptr, groups, B, false, gcp); }
-        side_begin(0, par);
-        conv_wgrad(e, blk.c2, blk.z1, GB, imgs, nullptr, 0, pm ? blk.z1p : nullptr, gbp);
-        side_end(0, par);
-        guard(2, par);
-        conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false, gbp);
-        if (pm) bn_bwd(e, blk.c1, GD, nullptr, nullptr, nullptr, groups, B, true, gdp, blk.z1p);      // mask from y1 (z1 = relu(bn1(y1)))
-        else bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true);
-        side_begin(2, par);
+        // Where a weight gradient enters the side stream.  lag = 0: as soon as its dy exists, i.e. beside the data gradient of the
+        // SAME conv -- two GEMMs share the CUs, and the BatchNorm-backward passes that follow run with nothing beside them.
+        // lag = 1 (round 6): behind that data gradient, i.e. beside the NEXT BatchNorm-backward passes of the main stream: a
+        // streaming kernel lives beside a GEMM's waves on a CU (the GEMMs leave it the registers since their K-steps run row-major),
+        // two GEMMs do not (LDS).  Same kernels, same bits; the buffer guards are the same events.
+        static const int lag = fm_tune("FM_WGRAD_LAG", 1);
         const unsigned short* inp = pm ? (b == 0 ? e->p0p : e->blocks[b - 1].outp) : nullptr;
-        conv_wgrad(e, blk.c1, in, GD, imgs, nullptr, 0, inp, gdp);
-        side_end(2, par);
-        if (blk.ds >= 0) {
+        auto wgrad_c2 = [&]() {
+            side_begin(0, par);
+            conv_wgrad(e, blk.c2, blk.z1, GB, imgs, nullptr, 0, pm ? blk.z1p : nullptr, gbp);
+            side_end(0, par);
+        };
+        auto wgrad_c1 = [&]() {
+            side_begin(2, par);
+            conv_wgrad(e, blk.c1, in, GD, imgs, nullptr, 0, inp, gdp);
+            side_end(2, par);
+        };
+        auto wgrad_ds = [&]() {
             side_begin(1, par);
             conv_wgrad(e, blk.ds, in, GC, imgs, nullptr, 0, inp, gcp);
             side_end(1, par);
+        };
+        if (!lag) wgrad_c2();
+        guard(2, par);
+        conv_dgrad(e, blk.c2, S, GB, GD, imgs, nullptr, false, gbp);
+        if (lag) wgrad_c2();
+        if (pm) bn_bwd(e, blk.c1, GD, nullptr, nullptr, nullptr, groups, B, true, gdp, blk.z1p);      // mask from y1 (z1 = relu(bn1(y1)))
+        else bn_bwd(e, blk.c1, GD, blk.z1, GD, nullptr, groups, B, true);
+        if (!lag) { wgrad_c1(); if (blk.ds >= 0) wgrad_ds(); }
+        if (blk.ds >= 0) {
             conv_dgrad(e, blk.ds, S, GC, ge, imgs, nullptr, false, gcp);   // writes parity class (0,0)
             conv_dgrad(e, blk.c1, S, GD, ge, imgs, nullptr, true, gdp);    // all classes, (0,0) accumulates
         } else {
             conv_dgrad(e, blk.c1, S, GD, ge, imgs, ga, false, gdp);
         }
+        if (lag) { wgrad_c1(); if (blk.ds >= 0) wgrad_ds(); }
         std::swap(ga, ge);
     }
     const Conv& c0 = e->convs[0];

@@ -37,3 +37,15 @@ n_steps = len(ends) - len(ends) // 2
 print("streaming kernels by the GEMM family running beside them for more than half of their duration:")
 for f, (c, st, du) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
     print(f"   {f:14s} {c / n_steps:6.1f} per step, {du / n_steps / 1e6:6.3f} ms per step, duration / shortest same launch = {st / c:5.2f}")
+alone = defaultdict(float)
+for s, e, n, g in stream:
+    d = e - s
+    ov = 0.0
+    for gs, ge, gf in gem:
+        if ge <= s or gs >= e: continue
+        ov += min(e, ge) - max(s, gs)
+    if ov <= 0.5 * d: alone[n.split("(")[0][:48]] += d
+print("alone, by kernel (ms per step):")
+for n, t in sorted(alone.items(), key=lambda kv: -kv[1]):
+    print(f"   {t / n_steps / 1e6:7.3f}  {n}")
+# per-stream GEMM time and idle time of each stream inside the step (Stream_Id when the trace has it)
