@@ -175,8 +175,16 @@ def test_stage1_step_at_the_benchmarked_size_against_the_oracle_with_shared_relu
                           "worst_engine_vs_f64": list(max(e_eng.items(), key=lambda kv: kv[1])),
                           "worst_oracle_f32_vs_f64": list(max(e_o32.items(), key=lambda kv: kv[1])),
                           "median_engine_vs_f64": float(np.median(list(e_eng.values()))),
-                          "median_oracle_f32_vs_f64": float(np.median(list(e_o32.values())))}
-    _dump(rep, "parity_step_full_shared_masks.json")
+                          "median_oracle_f32_vs_f64": float(np.median(list(e_o32.values()))),
+                          # round 6: the whole trace, tensor by tensor in backward order -- where along the
+                          # network does the engine's distance from float64 leave the fp32 oracle's?
+                          "per_tensor": {k: [e_eng[k], e_o32[k]] for k in reversed(list(g64.keys()))}}
+    # the same record per product form (FM_MFMA_SPLIT=0: fp32 matrix pipe, 9: nine partial products): which part of the distance
+    # belongs to the six-product form and which to the matrix pipe's own accumulation
+    form = os.environ.get("FM_MFMA_SPLIT")
+    if os.environ.get("FM_PLANES") == "0":
+        form = (form or "6") + "_fp32_operand_kernels"
+    _dump(rep, "parity_step_full_shared_masks.json" if not form else f"parity_step_full_shared_masks_products{form}.json")
     assert rep["loss_rel_err"] < 1e-5, rep
     assert calls == 4 * 17                                  # 2 train-mode + 2 teacher forwards x 17 ReLUs
     assert flips <= 2e-6 * n_relu, rep                      # measured: 266 of 5.9e8
