@@ -221,6 +221,7 @@ struct PwgradParams {
     int pix_per_split;           // multiple of 32 (set by the launcher)
     int tilesM, tilesN, nblk_n;  // set by the launcher
     int sp;                      // product form: 6 / 9
+    int pw_flags = 0;            // bit 0: waves 4-7 issue a step's DMA behind the step's last MFMAs (their SIMD partners in front of them)
     // pwgrad_ring.hip (set by its launcher): images, padded positions in all, positions per split (multiple of 32), splits,
     // blocks of a split share an XCD, ceil(2^32 / (Wi + 1)), ceil(2^32 / (Hi + 1))
     int nimg, Qtot, q_per_split, splits, xcd_remap;

@@ -233,8 +233,10 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issueA(s + 3, slot0);
-            issueB(s + 7);
+            // (as pconv.hip: the two waves of a SIMD would issue their DMA at the same point; waves 4-7 issue theirs behind the step's
+            // last MFMAs -- still three instructions per wave and step, which is what the counted wait above relies on)
+            const bool late = (p.pw_flags & 1) && wave >= 4;
+            if (!late) { issueA(s + 3, slot0); issueB(s + 7); }
             const unsigned a_nxt = (unsigned)(slot1 * SA);
             PR_COLUMN(4, PR_READA(a_nxt, 0, An[0]))
             PR_COLUMN(5, PR_READA(a_nxt, 1, An[1]))
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void pwgrad_ring_kernel(const PwgradParams 
             __builtin_amdgcn_sched_barrier(0);
             PR_MFMA(8, Ac, (8 + PAR) & 1);
             PR_LGKM0_COL(8);
+            if (late) { issueA(s + 3, slot0); issueB(s + 7); }
             slot0 = slot1;
             slot1 = slot1 == PR_NSA - 1 ? 0 : slot1 + 1;
         };
@@ -317,6 +320,8 @@ int launch_pwgrad_ring(PwgradParams p, size_t slab_floats, hipStream_t s)
     splits = (int)std::min<size_t>((size_t)splits, std::max<size_t>(1, slab_floats / ((size_t)p.M * p.Nw)));
     if (splits >= 8) splits -= splits % 8;
     p.xcd_remap = splits % 8 == 0 ? 1 : 0;
+    static const int flags = fm_tune("FM_PWGRAD_FLAGS", 1);      // (measured: -0.2 ms per step)
+    p.pw_flags = flags;
     p.q_per_split = (((p.Qtot + splits - 1) / splits) + 31) & ~31;
     p.splits = splits;
     if (p.sp == 9) hipLaunchKernelGGL((pwgrad_ring_kernel<9>), dim3(tiles * splits), dim3(512), PR_LDS, s, p);
