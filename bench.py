@@ -95,8 +95,9 @@ def mfma_peak(sp=None):
 
 ARITHMETIC = {0: "fp32 operands, fp32 products and accumulation on v_mfma_f32_16x16x4_f32",
               6: "fp32 operands and fp32 accumulation; every product as 6 exact bf16 partial products on v_mfma_f32_16x16x32_bf16 "
-                 "(3-way exact split of both operands, the 3 partial products of at most 2^-24 of the product left out (at most 2 more unit roundoffs in a K-term sum that carries K); error against "
-                 "float64 is below the fp32-MFMA form's: tests/test_kernels_gpu.py::test_split_products_are_fp32_accurate; "
+                 "(3-way exact split of both operands, the 3 partial products of at most 2^-24 of the product left out (at most 2 more unit roundoffs in a K-term sum that carries K); PER CONV the "
+                 "error against float64 is within 1.25x of the fp32-MFMA form's: tests/test_kernels_gpu.py::test_split_products_are_fp32_accurate; over a "
+                 "whole step the bf16 pipe's accumulation shows in sums of ~1e6 cancelling terms (DESIGN.md section 2); "
                  "fm_config.reserved[2] = 1 selects the fp32 pipe)",
               9: "fp32 operands and fp32 accumulation; every product as its 9 exact bf16 partial products on "
                  "v_mfma_f32_16x16x32_bf16 (fm_config.reserved[2] = 2)"}
@@ -105,7 +106,7 @@ PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (
 EFFNET_FWD_BYTES = {"fp32": 73.8e6, "bf16": 36.9e6}
 RESNET_FWD_FLOP = 3.627e9             # 2 x 1 813 561 344 conv MACs per 224x224 image
 STEP_FLOP = {"stage1": 28.55e9, "train": 10.65e9, "stage2": 10.65e9}    # SURVEY.md 8(d), per sample
-PMC_FILES = [os.path.join("profiles", r, "pmc_traffic.json") for r in ("r05", "r04", "r03", "r02")]
+PMC_FILES = [os.path.join("profiles", r, "pmc_traffic.json") for r in ("r06", "r05", "r04", "r03", "r02")]
 METRIC = "images/sec/client (ICH 224x224 bs=128) at 1/2/4/8 GPUs; mAP vs ref"
 
 

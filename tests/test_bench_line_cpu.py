@@ -13,12 +13,13 @@ import bench  # noqa: E402
 
 import pytest  # noqa: E402
 
-RECORDS = [os.path.join(ROOT, "profiles", "r04", "bench_gpus1_with_legs.json"), os.path.join(ROOT, "profiles", "r05", "bench_legs.json")]
+RECORDS = [os.path.join(ROOT, "profiles", "r04", "bench_gpus1_with_legs.json"), os.path.join(ROOT, "profiles", "r05", "bench_legs.json"),
+           os.path.join(ROOT, "profiles", "r06", "bench_legs.json")]
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
-@pytest.fixture(params=RECORDS, ids=["r04", "r05"])
+@pytest.fixture(params=RECORDS, ids=["r04", "r05", "r06"])
 def canned(request):
     with open(request.param) as f:
         return json.load(f)
