@@ -452,6 +452,8 @@ import numpy as np, torch
 from fedmlp_amd.engine import Engine
 from fedmlp_amd import spec, _lib
 e = Engine('Resnet18', 5, 64, 64, 8)
+if not e.planes:
+    print('skip: the fault is injected in pconv.hip, which only runs in planes mode'); sys.exit(0)
 flat, cnt = spec.init_state('Resnet18', 5, 1037)
 e.set_state(flat, cnt); e.adam_reset(1e-3)
 g = torch.Generator().manual_seed(3)
@@ -483,4 +485,6 @@ e.close(); print('ok')
 '''
     env = dict(os.environ, FM_IGEMM_BLOCKS="61")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode == 0 and r.stdout.startswith("skip"):
+        pytest.skip(r.stdout.strip())
     assert r.returncode == 0 and "ok" in r.stdout, f"{r.stdout[-2000:]} {r.stderr[-3000:]}"
