@@ -15,7 +15,7 @@
 // writes planes without a shuffle).
 //
 // Roofline: bf16 MFMA dense peak 2 500 TFLOP/s / SP products = 416.7 TFLOP/s of fp32 products (SP = 6).
-// Structure (tools/pconv_probe.hip measured it in isolation against the one it replaces):
+// Structure:
 //  * ONE 8-wave block per CU (two waves per SIMD), block tile (32 FR) x 256: 128 x 256 for M >= 128, 64 x 256 for M = 64;
 //    wave tile (16 FR) x 64.
 //  * LDS: two stages of [A planes | B planes] = 2 x 3 x (BM + 256) x 64 B (144 KB / 120 KB), filled by LDS-DMA
@@ -23,12 +23,12 @@
 //    address is ONE 32-bit offset per 16-row group, computed once per tile; everything that changes per step is a scalar
 //    offset; padding / tail rows are an out-of-range offset, which the hardware answers with zeros.  Bank swizzle
 //    slot = chunk ^ ((row>>1)&3) on the SOURCE side and on the read (conflict-free ds_read_b128 on 64-B rows).
-//  * A wave's A fragments are double-buffered in REGISTERS: step s+1's are read during step s; the B fragments roll column
-//    by column one column ahead.  No VALU in the loop besides the padding select of the DMA offsets.
-//  * ONE barrier per K-step of 32, placed before the step's LAST column of MFMAs: by then every wave holds all the
-//    fragments the two stages can still be asked for, so the DMA of the steps after next starts there and has a whole step to land.
-//  * LDS reads are inline asm with explicit waits (issued at the head of a column's 6 FR MFMAs, waited for at its end): the
-//    compiler's own placement put them right in front of their first use.
+//  * Row-major K-step (round 6, RM below): a step's MFMAs run row by row -- the step's four B columns sit in registers, the A rows
+//    roll through two buffers, the next step's B columns are read behind the last row's MFMAs -- with ONE barrier per step, before
+//    the last row.  (Rounds 4-5 ran column by column with both steps' A fragments resident: 48 registers more, the whole file
+//    at two waves per SIMD; the row-major form leaves a wave of a streaming kernel of the other stream room beside the GEMM.)
+//  * LDS reads are inline asm with explicit waits; every wait carries the registers it guards as operands (a bare wait between
+//    two scheduling barriers gets moved by the machine scheduler: PC_LGKM0_COL).
 //  * Stream-K (as igemm.hip): the (tile, K-step) space is cut into equal contiguous ranges, one per block; partial tiles meet
 //    in a slab: the owner of a tile's head (the designated finisher) sums them in segment order (deterministic) and runs the
 //    epilogue; the others store their part (one slab slot per block: a range starts inside a tile at most once).  ResNet's pixel counts are
