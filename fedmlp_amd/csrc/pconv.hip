@@ -101,12 +101,6 @@ __device__ unsigned long long pc_prof[256 * 8];
 #ifndef PC_WAVES_PER_EU
 #define PC_WAVES_PER_EU 2
 #endif
-#ifndef PC_ROW_MAJOR
-#define PC_ROW_MAJOR 1
-#endif
-#ifndef PC_ROW_MAJOR_2
-#define PC_ROW_MAJOR_2 1           // the 64-row tiles too (two passes of 24 MFMAs per step)
-#endif
 template <int FR, int FC, int NS, int SP, bool TS = false>
 __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const IgemmParams p)
 {
@@ -124,7 +118,7 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
     static_assert(!TS || FC == 4, "tap-row sharing: 256-pixel tiles");
     constexpr int JA = (3 * GA + 7) / 8;                       // A DMA instructions per wave per stage (waves past 3 GA - 8 (JA - 1): one fewer)
     constexpr int RGB = (GB + 7) / 8;                          // B row groups per wave (wave + 8 i < GB), each x 3 planes
-    static_assert(NS == 2 || NS == 3, "two or three LDS stages");
+    static_assert(NS == 2 && FC == 4 && (FR == 2 || FR == 4), "two LDS stages, 256-pixel tiles, 64 or 128 rows");
     typedef __attribute__((address_space(3))) void lds_void;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -173,11 +167,8 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
     unsigned Zc[FC];
 #pragma unroll
     for (int c = 0; c < FC; ++c) Zc[c] = Bs + (unsigned)((BN + 2 + (li & 7) - 16 * c) * 64 + lg * 16);
-    // DMA instructions this wave issues per K-step (A jobs + 3 planes x its B row groups): the counted vmcnt of NS = 3
+    // B row groups this wave issues (wave + 8 i < GB)
     const int ngrpB = (wave + 8 * (RGB - 1) < GB) ? RGB : RGB - 1;
-    constexpr int NW_HI = JA + 3 * RGB;                                            // waves that hold the full share
-    constexpr int NW_LO = ((3 * GA) % 8 ? JA - 1 : JA) + 3 * (GB % 8 ? RGB - 1 : RGB);   // waves 4 .. 7 when the job counts are odd multiples of 4
-    static_assert(NS == 2 || TS || (((3 * GA) % 8 == 0 || (3 * GA) % 8 == 4) && (GB % 8 == 0 || GB % 8 == 4)), "job split by wave < 4");
     // TS: kernel-row offset and column shifts from the tap table: taps 3 j .. 3 j + 2 share dh; d = dw + 1 of tap t
     auto tap_d = [&](int t) { return (int)((unsigned)(p.tapcode >> (4 * t + 2)) & 3u); };
 
@@ -319,14 +310,13 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
         for (int r = 0; r < FR; ++r)
 #pragma unroll
             for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // D2 (FR == 2: a column is only 12 MFMAs): the B fragments are read TWO columns ahead into one buffer per column
-        // RM (the 128-row tiles, round 6): the step's MFMAs run ROW by row -- all four B columns of the step sit in registers (48), the
+        // Round 6: the step's MFMAs run ROW by row -- all four B columns of the step sit in registers (48), the
         // A rows roll through two buffers (24) -- instead of column by column with both steps' A fragments resident (96 + 24).  Same
         // reads, MFMAs, stages and one barrier per step; 48 registers fewer, which is what lets a wave of a streaming kernel of the
         // other stream (BatchNorm apply: 32 registers) live beside the two GEMM waves of a SIMD (512 registers per lane and SIMD)
-        constexpr bool RM = FC == 4 && NS == 2 && ((PC_ROW_MAJOR && FR == 4) || (PC_ROW_MAJOR_2 && FR == 2));
-        constexpr bool D2 = FR == 2 && FC == 4 && !RM;
-        sp_u32x4 A0[RM ? 1 : FR][3], A1[RM ? 1 : FR][3], Bb[(D2 || RM) ? 4 : 2][3];
+        // (the column-major step of rounds 4-5 -- both steps' A fragments resident, B rolling through two buffers -- is in the history
+        // of this file and in profiles/HISTORY.md)
+        sp_u32x4 A0[1][3], A1[1][3], Bb[FC][3];
     // BASE = the fragment base address of the stage slot the read takes (Af0 + slot * SA, Bf0 + slot * SB)
 #define PC_READA(BASE, R, DST)                                                                  \
     {                                                                                           \
@@ -341,9 +331,6 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
         DST[1] = pc_lds_read128<(1 * BROWS + 16 * (C)) * 64>(base_);                            \
         DST[2] = pc_lds_read128<(2 * BROWS + 16 * (C)) * 64>(base_);                            \
     }
-    // the rolling B buffers: column c of a step of register parity PAR sits in Bb[(c + PAR * FC) & 1] (odd FC: the parity of the
-    // first column alternates from step to step, so the next step's column 0 never lands on the column still in use)
-#define PC_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
 #define PC_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     // the wait at the END of column C's MFMAs.  The accumulators are operands of the statement: without that dependence the machine
     // scheduler is free to move the bare wait anywhere between the two scheduling barriers, and it put it behind the column's FIRST
@@ -379,29 +366,16 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
         // TS: kernel rows (super-steps of three taps) U = s / 3; this segment covers U0 .. U1; B slot of U = (U - U0) & 1
         int it_cur = 0, Ucur = 0, ub = 0;
         int b_age = 3;                         // TS: barriers since the last B row was issued (it goes out AFTER that barrier's A stage)
-        // TS: the step's barrier needs A(s + 2) (and, at a row's last step, the next row, issued three steps back).  Vector-memory
-        // operations complete in issue order, so everything YOUNGER than A(s + 2) may stay in flight: the A stages issued since
-        // (NS - 2 of them, when every step issues one: `full`) and a B row issued one or NS - 1 barriers ago
-        const int ja_w = ((3 * GA) % 8 != 0 && wave >= 4) ? JA - 1 : JA;
+        // The step's barrier needs A(s + 1) and B(s + 1) landed.  Vector-memory operations complete in issue order, and a TS row goes
+        // out AFTER its barrier's A stage: a row issued one barrier ago may stay in flight.  Every wave waits with the count of the
+        // waves that hold the SMALLER share of a row (the others wait for three of their pieces more): ONE branch -- the count as a
+        // run-time switch over vmcnt immediates had compiled into a chain of ~25 scalar branches per step
         auto wait_dma = [&](bool full) {
-            if constexpr (TS && NS == 2) {
-                // two stages: the only DMA that may stay in flight is a B row issued one barrier ago.  Every wave waits with the
-                // count of the waves that hold the SMALLER share of a row (the others wait for three of their pieces more): ONE
-                // branch -- the count as a run-time switch over vmcnt immediates compiled into a chain of ~25 scalar branches
-                // between a step's third and fourth column
+            if constexpr (TS) {
                 constexpr int NROW = 3 * (GB % 8 ? RGB - 1 : RGB);
-                if (full && b_age == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NROW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                return;
+                if (full && b_age == 1) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NROW) : "memory"); return; }
             }
-            int n = 0;
-            if (TS && full) n = (NS - 2) * ja_w + ((b_age >= 1 && b_age <= NS - 1) ? 3 * ngrpB : 0);
-            switch (n) {
-#define PC_VM(N_) case N_: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); break;
-                PC_VM(1) PC_VM(2) PC_VM(3) PC_VM(6) PC_VM(7) PC_VM(8) PC_VM(9) PC_VM(10) PC_VM(11) PC_VM(12)
-#undef PC_VM
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
         const int U1 = (k1 - 1) / 3;
         // c ? b : a for a wave-uniform c, as ONE v_cndmask (the compiler's own form of a uniform select between vector
@@ -429,11 +403,7 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
         } else {
             if (k0 + 1 < k1) issueB(cur, 1);
         }
-        if constexpr (NS == 3) {
-            if (k0 + 2 < k1) issueA(cur, k0 + 2, 2);
-            if constexpr (!TS) { if (k0 + 2 < k1) issueB(cur, 2); }
-        }
-        if constexpr (RM) {
+        {
             // row 0 of A(k0) and all four columns of B(k0); the other rows of A(k0) are read while the step runs, so its stage is
             // not free yet: A(k0 + 2) goes out behind step k0's barrier like every other A stage
             PC_READA(Af0, 0, A0[0]);
@@ -443,22 +413,6 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
                 else PC_READB(Bf0, c, Bb[c]);
             });
             PC_LGKM0();
-        } else {
-        PC_READA(Af0, 0, A0[0]);
-        PC_READA(Af0, 1, A0[1]);
-        if constexpr (FR == 4) { PC_READA(Af0, 2, A0[2]); PC_READA(Af0, 3, A0[3]); }
-        if constexpr (TS) {
-            PC_READB(colbase(0, tap_d(it_cur), 0u, bsel(tap_d(it_cur), 0u)), 0, Bb[0]);
-        } else
-            PC_READB(Bf0, 0, Bb[0]);
-        if constexpr (D2) {
-            if constexpr (TS) { PC_READB(colbase(1, tap_d(it_cur), 0u, bsel(tap_d(it_cur), 0u)), 1, Bb[1]); }
-            else PC_READB(Bf0, 1, Bb[1]);
-        }
-        PC_LGKM0();
-        __builtin_amdgcn_s_barrier();          // every wave holds A(k0): its slot takes A(k0 + NS)
-        asm volatile("" ::: "memory");
-        if (k0 + NS < k1) issueA(cur, k0 + NS, 0);
         }
 
         PC_T(2);
@@ -466,141 +420,7 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
         // the two waves of a SIMD (w, w + 4) run this loop in lockstep between barriers: when both issue a step's DMA at the same
         // point the matrix pipe idles behind them.  `late`: waves 4-7 issue theirs BEHIND the last column's MFMAs
         const bool late = (p.pc_flags & 1) && wave >= 4;
-        // one K-step (register parity PAR): Ac = this step's A fragments (in registers), An <- the next step's.
-        // FULL: steps up to s + NS + 1 exist (the main loop: no branch inside, counted vmcnt); otherwise the conditions are tested
-        auto step = [&](auto par_c, auto full_c, int s, sp_u32x4 (&Ac)[FR][3], sp_u32x4 (&An)[FR][3]) {
-            constexpr int PAR = decltype(par_c)::value;
-            constexpr bool FULL = decltype(full_c)::value;
-            const int ib1 = (ib + 1 == NS) ? 0 : ib + 1;
-            const unsigned a_nxt = Af0 + ib1 * SA;
-            unsigned b_cur = 0, b_nxt = 0, so_cur = 0, so_nxt = 0;       // (TS: slot byte offsets; the bases come from colbase)
-            int d_cur = 1, d_nxt = 1;                // TS: dw + 1 of this step's / the next step's tap
-            bool row_end = false;                    // TS: this step is the last of its kernel row
-            if constexpr (TS) {
-                const int it1 = it_cur == 8 ? 0 : it_cur + 1;
-                d_cur = tap_d(it_cur); d_nxt = tap_d(it1);
-                row_end = it_cur == 2 || it_cur == 5 || it_cur == 8;
-                so_cur = (unsigned)(ub * SB);
-                so_nxt = (unsigned)((row_end ? ub ^ 1 : ub) * SB);
-            } else {
-                b_cur = Bf0 + ib * SB; b_nxt = Bf0 + ib1 * SB;
-            }
-            if constexpr (TS) { b_cur = bsel(d_cur, so_cur); b_nxt = bsel(d_nxt, so_nxt); }
-            auto bc = [&](int c) { if constexpr (TS) return colbase(c, d_cur, so_cur, b_cur); else return b_cur; };
-            auto bn = [&](int c) { if constexpr (TS) return colbase(c, d_nxt, so_nxt, b_nxt); else return b_nxt; };
-            if constexpr (D2) {
-                // B fragments two columns ahead: Bb[c] = column c.  At the start of a step columns 0 and 1 are in registers (read
-                // during the previous step's columns 2, 3); columns 2, 3 and the next step's A fragments are read behind the
-                // MFMAs of columns 0, 1 (24 MFMAs of cover instead of 12).  The barrier sits before column 2: by then all of this
-                // stage's B columns and the next step's A fragments are in registers.
-                const bool more = FULL || s + 1 < k1;
-                if (more) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }
-                PC_READB(bc(2), 2, Bb[2]);
-                PC_READB(bc(3), 3, Bb[3]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < FR; ++r) acc[r][0] = pc_mfma<SP>(Ac[r], Bb[0], acc[r][0]);
-#pragma unroll
-                for (int r = 0; r < FR; ++r) acc[r][1] = pc_mfma<SP>(Ac[r], Bb[1], acc[r][1]);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[0][1]), "+v"(acc[1][1])::"memory");
-                wait_dma(FULL);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (more) { PC_READB(bn(0), 0, Bb[0]); PC_READB(bn(1), 1, Bb[1]); }
-                auto issue_dma = [&]() {
-                    if constexpr (TS) {
-                        // A first, then the B row: the next barrier waits for the A stage only and leaves the row in flight
-                        if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                        if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
-                    } else {
-                        if (FULL || s + NS < k1) issueB(cur, ib);
-                        if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                    }
-                };
-                if (!late) issue_dma();
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < FR; ++r) acc[r][2] = pc_mfma<SP>(Ac[r], Bb[2], acc[r][2]);
-#pragma unroll
-                for (int r = 0; r < FR; ++r) acc[r][3] = pc_mfma<SP>(Ac[r], Bb[3], acc[r][3]);
-                asm volatile("" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[0][3]), "+v"(acc[1][3]));
-                __builtin_amdgcn_sched_barrier(0);
-                if (late) issue_dma();
-                PC_LGKM0();
-                if constexpr (TS) {
-                    if (row_end) { ub ^= 1; ++Ucur; }
-                    it_cur = it_cur == 8 ? 0 : it_cur + 1;
-                    if (b_age < 3) ++b_age;
-                }
-                ib = ib1;
-                return;
-            }
-            // columns 0 .. FC - 2: the next column's B fragments and a share of the next step's A fragments go out at the head
-            // of the column's MFMAs and are waited for at its end
-#define PC_COLUMN(C)                                                                                             \
-            {                                                                                                    \
-                PC_READB(bc((C) + 1), (C) + 1, Bb[PC_BI((C) + 1, PAR)]);                                         \
-                if (FULL || s + 1 < k1) {                                                                        \
-                    if constexpr (FR == 4 && FC == 4) {                                                          \
-                        if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }        \
-                        if constexpr ((C) == 1) { PC_READA(a_nxt, 2, An[2]); }                                   \
-                        if constexpr ((C) == 2) { PC_READA(a_nxt, 3, An[3]); }                                   \
-                    } else if constexpr (FR == 4) {                                                              \
-                        if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); PC_READA(a_nxt, 1, An[1]); }        \
-                        if constexpr ((C) == 1) { PC_READA(a_nxt, 2, An[2]); PC_READA(a_nxt, 3, An[3]); }        \
-                    } else {                                                                                     \
-                        if constexpr ((C) == 0) { PC_READA(a_nxt, 0, An[0]); }                                   \
-                        if constexpr ((C) == 1) { PC_READA(a_nxt, 1, An[1]); }                                   \
-                    }                                                                                            \
-                }                                                                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-                _Pragma("unroll") for (int r = 0; r < FR; ++r) acc[r][C] = pc_mfma<SP>(Ac[r], Bb[PC_BI(C, PAR)], acc[r][C]); \
-                PC_LGKM0_COL(C);                                                                                 \
-            }
-            PC_COLUMN(0)
-            PC_COLUMN(1)
-            if constexpr (FC == 4) PC_COLUMN(2)
-#undef PC_COLUMN
-            // last column: every wave holds all of this step's fragments and step s+1's A fragments: slot ib of B and slot ib1 of A
-            // are free.  B(s + 1) and A(s + 2) must have landed: with three stages the youngest group of DMA (B(s + 2), A(s + 3),
-            // issued one step ago) may stay in flight
-            if constexpr (NS == 3 && FULL && !TS) {
-                if constexpr (NW_HI == NW_LO) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
-                else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_HI) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW_LO) : "memory");
-            } else
-                wait_dma(FULL);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (FULL || s + 1 < k1) PC_READB(bn(0), 0, Bb[PC_BI(0, PAR ^ 1)]);
-            auto issue_dma = [&]() {
-                if constexpr (TS) {
-                    // the last tap of a kernel row has consumed its B slot: it takes the row after next.  A first, then the B row:
-                    // the next barrier waits for the A stage only and leaves the row in flight
-                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                    if (row_end && Ucur + 2 <= U1) { issueB(cur, ub); b_age = 0; }
-                } else {
-                    if (FULL || s + NS < k1) issueB(cur, ib);
-                    if (FULL || s + NS + 1 < k1) issueA(cur, s + NS + 1, ib1);
-                }
-            };
-            if (!late) issue_dma();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < FR; ++r) acc[r][FC - 1] = pc_mfma<SP>(Ac[r], Bb[PC_BI(FC - 1, PAR)], acc[r][FC - 1]);
-            PC_LGKM0_COL(FC - 1);
-            if (late) issue_dma();
-            if constexpr (TS) {
-                if (row_end) { ub ^= 1; ++Ucur; }
-                it_cur = it_cur == 8 ? 0 : it_cur + 1;
-                if (b_age < 3) ++b_age;
-            }
-            ib = ib1;
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        if constexpr (RM) {
+        {
             // ---- one K-step, row-major.  At its start: row 0 of A(s) in A0[0], B(s) columns 0 .. 3 in Bb (columns 1 .. 3 possibly
             // still in flight: counted waits in pass 0).  Pass r = row r's 24 MFMAs with row r + 1 read behind them.  The barrier
             // sits before the LAST pass (3; 1 for the 64-row tiles): every wave holds all of A(s) and B(s), and A(s + 1), B(s + 1) have landed -- the stage of A(s) takes
@@ -704,22 +524,11 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
             int s = k0;
             for (; s + 3 <= k1; ++s) rstep(std::true_type{}, s);       // FULL: steps s + 1 and s + 2 exist
             for (; s < k1; ++s) rstep(std::false_type{}, s);
-        } else {
-        int s = k0;
-        for (; s + NS + 3 <= k1; s += 2) {     // steps s and s + 1 are FULL: s + 1 + NS + 1 < k1
-            step(I0{}, std::true_type{}, s, A0, A1);
-            step(I1{}, std::true_type{}, s + 1, A1, A0);
-        }
-        for (; s < k1; s += 2) {
-            step(I0{}, std::false_type{}, s, A0, A1);
-            if (s + 1 < k1) step(I1{}, std::false_type{}, s + 1, A1, A0);
-        }
         }
 #undef PC_READA
 #undef PC_READB
 #undef PC_LGKM0
 #undef PC_LGKM0_COL
-#undef PC_BI
         PC_SYNC_LDS();         // every wave is done reading both stages: they can take the next segment's lead DMA
         PC_T(3);
 

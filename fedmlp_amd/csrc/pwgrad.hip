@@ -41,9 +41,6 @@ template <int IMM> __device__ __forceinline__ uint2 pw_read_tr(unsigned addr)
 #endif
 
 // FR: 16-channel m tiles per wave (4 or 2: BM = 128 / 64); FC: 16-column n tiles per wave (4 or 3: BN = 256 / 192)
-#ifndef PW_ROW_MAJOR
-#define PW_ROW_MAJOR 1
-#endif
 // f(integral_constant<int, 0>) ... f(<N - 1>): a loop whose index is a template argument inside f (the LDS reads' offsets are immediates)
 template <int N, typename F> __device__ __forceinline__ void pw_for(F f)
 {
@@ -169,8 +166,8 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
     // RM (round 6, as pconv.hip): the step's MFMAs run row by row -- all FC columns of X in registers, the dY rows rolling through
     // two buffers -- instead of column by column with both steps' dY fragments resident: 48 registers fewer (room for a wave of a
     // streaming kernel of the other stream beside the two GEMM waves of a SIMD), same reads, MFMAs, stages, one barrier per step
-    constexpr bool RM = PW_ROW_MAJOR != 0;
-    sp_u32x4 A0[RM ? 1 : FR][3], A1[RM ? 1 : FR][3], Bb[RM ? FC : 2][3];
+    // (the column-major step of round 5 is in the history of this file)
+    sp_u32x4 A0[1][3], A1[1][3], Bb[FC][3];
     // T = tile index inside the block tile (compile-time after unrolling: wm / wn are folded into the base address instead)
     const unsigned a_w = (unsigned)((wm * FR >> 1) * 6144), b_w = (unsigned)((wn * FC >> 1) * 6144);
     // (wm * FR and wn * FC are even for FR = 2, 4 and FC = 4; for FC = 3 the wave's first n tile may be odd: handled by hh0)
@@ -197,22 +194,8 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
         else PW_READ(DST, Bf, b_w, (SLOT) * SB, (C) + 1)                                           \
     }
 #define PW_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-    // the wait at the END of column C's MFMAs: the accumulators are operands, so that the machine scheduler cannot move the bare
-    // wait up behind the column's first MFMA (which is where it put it: pconv.hip PC_LGKM0_COL)
-#define PW_LGKM0_COL(C)                                                                                                           \
-    do {                                                                                                                          \
-        if constexpr (FR == 4)                                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C]), "+v"(acc[2][C]), "+v"(acc[3][C])::"memory"); \
-        else                                                                                                                      \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][C]), "+v"(acc[1][C])::"memory");                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                        \
-    } while (0)
-    // the rolling X buffers: column c of a step of parity PAR sits in Bb[(c + PAR * FC) & 1] (FC = 3: the parity of the first column
-    // alternates from step to step, so that the next step's column 0 never lands on the column still in use)
-#define PW_BI(C, PAR_) (((C) + (PAR_) * FC) & 1)
-#define PW_MFMA(R, C, AC, BI_) acc[R][C] = mfma_split<SP>(Bb[BI_][0], Bb[BI_][1], Bb[BI_][2], AC[R][0], AC[R][1], AC[R][2], acc[R][C])
 
-    if constexpr (RM) {
+    {
       if (nsteps > 0) {
         issueA(0);
         issueB(0);
@@ -290,82 +273,11 @@ __global__ __launch_bounds__(512, 2) void pwgrad_kernel(const PwgradParams p)
         for (; s + 3 <= nsteps; ++s) rstep(std::true_type{}, s);
         for (; s < nsteps; ++s) rstep(std::false_type{}, s);
       }
-    } else
-    if (nsteps > 0) {
-        // ---- prologue ----------------------------------------------------------------------------------------------------
-        issueA(0);
-        issueB(0);
-        if (1 < nsteps) issueA(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (1 < nsteps) issueB(1);
-        PW_READA(0, 0, A0[0]);
-        PW_READA(0, 1, A0[1]);
-        if constexpr (FR == 4) { PW_READA(0, 2, A0[2]); PW_READA(0, 3, A0[3]); }
-        PW_READB(0, 0, Bb[0]);
-        PW_LGKM0();
-        __builtin_amdgcn_s_barrier();          // every wave holds A(0): its slot takes A(2)
-        asm volatile("" ::: "memory");
-        if (2 < nsteps) issueA(0);
-
-        auto step = [&](auto par_c, auto full_c, int s, sp_u32x4 (&Ac)[FR][3], sp_u32x4 (&An)[FR][3]) {
-            constexpr int PAR = decltype(par_c)::value;
-            constexpr bool FULL = decltype(full_c)::value;
-#define PW_COLUMN(C)                                                                                             \
-            {                                                                                                    \
-                PW_READB(PAR, (C) + 1, Bb[PW_BI((C) + 1, PAR)]);                                                 \
-                if (FULL || s + 1 < nsteps) {                                                                    \
-                    if constexpr (FR == 4 && FC == 4) {                                                          \
-                        if constexpr ((C) == 0) { PW_READA(PAR ^ 1, 0, An[0]); PW_READA(PAR ^ 1, 1, An[1]); }    \
-                        if constexpr ((C) == 1) { PW_READA(PAR ^ 1, 2, An[2]); }                                 \
-                        if constexpr ((C) == 2) { PW_READA(PAR ^ 1, 3, An[3]); }                                 \
-                    } else if constexpr (FR == 4) {                                                              \
-                        if constexpr ((C) == 0) { PW_READA(PAR ^ 1, 0, An[0]); PW_READA(PAR ^ 1, 1, An[1]); }    \
-                        if constexpr ((C) == 1) { PW_READA(PAR ^ 1, 2, An[2]); PW_READA(PAR ^ 1, 3, An[3]); }    \
-                    } else {                                                                                     \
-                        if constexpr ((C) == 0) { PW_READA(PAR ^ 1, 0, An[0]); }                                 \
-                        if constexpr ((C) == 1) { PW_READA(PAR ^ 1, 1, An[1]); }                                 \
-                    }                                                                                            \
-                }                                                                                                \
-                __builtin_amdgcn_sched_barrier(0);                                                               \
-                _Pragma("unroll") for (int r = 0; r < FR; ++r) PW_MFMA(r, C, Ac, PW_BI(C, PAR));                 \
-                PW_LGKM0_COL(C);                                                                                 \
-            }
-            PW_COLUMN(0)
-            PW_COLUMN(1)
-            if constexpr (FC == 4) PW_COLUMN(2)
-#undef PW_COLUMN
-            // last column: every wave holds all of this step's fragments and step s+1's A fragments: both read slots are free
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (FULL || s + 1 < nsteps) PW_READB(PAR ^ 1, 0, Bb[PW_BI(0, PAR ^ 1)]);
-            if (FULL || s + 2 < nsteps) issueB(PAR);
-            if (FULL || s + 3 < nsteps) issueA(PAR ^ 1);
-#pragma unroll
-            for (int r = 0; r < FR; ++r) PW_MFMA(r, FC - 1, Ac, PW_BI(FC - 1, PAR));
-            PW_LGKM0_COL(FC - 1);
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        int s = 0;
-        for (; s + 5 <= nsteps; s += 2) {
-            step(I0{}, std::true_type{}, s, A0, A1);
-            step(I1{}, std::true_type{}, s + 1, A1, A0);
-        }
-        for (; s < nsteps; s += 2) {
-            step(I0{}, std::false_type{}, s, A0, A1);
-            if (s + 1 < nsteps) step(I1{}, std::false_type{}, s + 1, A1, A0);
-        }
     }
 #undef PW_READ
 #undef PW_READA
 #undef PW_READB
 #undef PW_LGKM0
-#undef PW_LGKM0_COL
-#undef PW_MFMA
-#undef PW_BI
 
     // ---- epilogue: acc[r][c][q] = dW[m of (m tile wm*FR + r, position li)][n of (n tile wn*FC + c, positions 4 lg + q)]
     // position j of a 32-channel block -> channel: chunk g = j >> 3 holds channels 4g..4g+3 (j & 7 < 4) and 16+4g..16+4g+3
