@@ -595,11 +595,21 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
                     for (int c = 0; c < FC; ++c) acc[r][c] = f32x4{first, first, first, first} + acc[r][c];
                 for (int bb = b_first + 1; bb <= b_last; ++bb) {
                     const float* src = p.slab + (size_t)bb * 2 * (BM * BN);
+                    // eight loads in flight at a time (two row tiles x four columns), then their sums: load by load, each was waited
+                    // for alone
 #pragma unroll
-                    for (int r = 0; r < FR; ++r)
+                    for (int r = 0; r < FR; r += 2) {
+                        f32x4 part[2][FC];
 #pragma unroll
-                        for (int c = 0; c < FC; ++c)
-                            acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * FC + c) * 512 + tid) * 4);
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int c = 0; c < FC; ++c)
+                                part[q][c] = *reinterpret_cast<const f32x4*>(src + (((r + q) * FC + c) * 512 + tid) * 4);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int c = 0; c < FC; ++c) acc[r + q][c] += part[q][c];
+                    }
                 }
             }
         }
@@ -648,33 +658,44 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
                 st[p.M + m0 + ch] = v;
             }
         }
+        // Round 6: the output loop runs PAIR of row tiles by pair (a pair = one 32-channel block: one plane chunk), columns inside: the
+        // folded BatchNorm of a pair is loaded once, and a column's residual loads are issued together.  (Column by column with one
+        // branch per load, every load -- seven per column in the eval / data-gradient forms -- was waited for alone.)  The register
+        // count of the kernel is set here as much as in the main loop: nothing is kept across pairs or columns beyond opix.
+        size_t opix[FC];
+        bool ok[FC];
 #pragma unroll
         for (int c = 0; c < FC; ++c) {
             const int n = n0 + wn * (16 * FC) + 16 * c + li;
-            if (n >= npix) continue;
+            ok[c] = n < npix;
             int img, rem, hg, wg;
-            pc_divmod(n, HWg, rcpHW, img, rem);
+            pc_divmod(ok[c] ? n : npix - 1, HWg, rcpHW, img, rem);          // (a pixel past the end reads the last one's, stores nothing)
             pc_divmod(rem, p.Wg, rcpW, hg, wg);
-            const size_t opix = (size_t)((grp * p.imgs_per_group + img) * p.Ho + hg * p.os + p.oh0) * p.Wo + (wg * p.os + p.ow0);
-            const size_t o = opix * p.Co;
-            f32x4 v[FR];
+            opix[c] = (size_t)((grp * p.imgs_per_group + img) * p.Ho + hg * p.os + p.oh0) * p.Wo + (wg * p.os + p.ow0);
+        }
 #pragma unroll
-            for (int r = 0; r < FR; ++r) {
-                const int m = mbase + 16 * r;
-                v[r] = acc[r][c];
-                if (p.scale) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + m);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + m);
-                    v[r] = v[r] * sc + sh;
-                }
-                if (p.res) v[r] += *reinterpret_cast<const f32x4*>(p.res + o + m);
+        for (int r = 0; r < FR; r += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = mbase + 16 * r;
+            const size_t cb = (size_t)(m0 + wm * (16 * FR) + 16 * r) >> 5;
+            f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+            if (p.scale) {
+                sc0 = *reinterpret_cast<const f32x4*>(p.scale + m); sc1 = *reinterpret_cast<const f32x4*>(p.scale + m + 16);
+                sh0 = *reinterpret_cast<const f32x4*>(p.shift + m); sh1 = *reinterpret_cast<const f32x4*>(p.shift + m + 16);
             }
-            if (p.resp) {
-                // residual kept only as planes: rows r, r + 1 of this lane are chunk lg of a 32-channel block; x = (h + m) + l exactly
 #pragma unroll
-                for (int r = 0; r < FR; r += 2) {
-                    const size_t cb = (size_t)(m0 + wm * (16 * FR) + 16 * r) >> 5;
-                    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.resp) + ((cb * 3) * (size_t)p.yp_pix + opix) * 64 + lg * 16;
+            for (int c = 0; c < FC; ++c) {
+                __builtin_amdgcn_sched_barrier(0);
+                const size_t o = opix[c] * p.Co;
+                f32x4 v0 = acc[r][c], v1 = acc[r + 1][c];
+                if (p.scale) { v0 = v0 * sc0 + sh0; v1 = v1 * sc1 + sh1; }
+                if (p.res) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.res + o + m), b = *reinterpret_cast<const f32x4*>(p.res + o + m + 16);
+                    v0 += a; v1 += b;
+                }
+                if (p.resp) {
+                    // residual kept only as planes: this lane's two row tiles are chunk lg of block cb; x = (h + m) + l exactly
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.resp) + ((cb * 3) * (size_t)p.yp_pix + opix[c]) * 64 + lg * 16;
                     const sp_u32x4 H = *reinterpret_cast<const sp_u32x4*>(src);
                     const sp_u32x4 M = *reinterpret_cast<const sp_u32x4*>(src + (size_t)p.yp_pix * 64);
                     const sp_u32x4 L = *reinterpret_cast<const sp_u32x4*>(src + (size_t)p.yp_pix * 128);
@@ -685,28 +706,24 @@ __global__ __launch_bounds__(512, PC_WAVES_PER_EU) void pconv_kernel(const Igemm
                         const float hi = (__builtin_bit_cast(float, H[i] & 0xffff0000u) + __builtin_bit_cast(float, M[i] & 0xffff0000u)) +
                                          __builtin_bit_cast(float, L[i] & 0xffff0000u);
                         // words 0, 1 = the first row tile's channels 4 lg .. 4 lg + 3, words 2, 3 = the second's
-                        v[r + (i >> 1)][2 * (i & 1)] += lo;
-                        v[r + (i >> 1)][2 * (i & 1) + 1] += hi;
+                        if (i < 2) { v0[2 * i] += lo; v0[2 * i + 1] += hi; }
+                        else { v1[2 * (i - 2)] += lo; v1[2 * (i - 2) + 1] += hi; }
                     }
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < FR; ++r) {
-                const int m = mbase + 16 * r;
                 if (p.relu == 1) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[r][q] = fmaxf(v[r][q], 0.f);
+                    for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
                 }
-                if (p.Y) *reinterpret_cast<f32x4*>(p.Y + o + m) = v[r];
-            }
-            if (p.Yp) {
-                // planes of the output: rows r, r + 1 of this lane are chunk lg of the 32-channel block (m0 + wm*16FR + 16r) / 32
-#pragma unroll
-                for (int r = 0; r < FR; r += 2) {
+                if (!ok[c]) continue;
+                if (p.Y) {
+                    *reinterpret_cast<f32x4*>(p.Y + o + m) = v0;
+                    *reinterpret_cast<f32x4*>(p.Y + o + m + 16) = v1;
+                }
+                if (p.Yp) {
+                    // planes of the output: the pair is chunk lg of the 32-channel block cb
                     sp_u32x4 H, M, L;
-                    split3(v[r], v[r + 1], H, M, L);
-                    const size_t cb = (size_t)(m0 + wm * (16 * FR) + 16 * r) >> 5;
-                    unsigned char* dst = reinterpret_cast<unsigned char*>(p.Yp) + ((cb * 3) * (size_t)p.yp_pix + opix) * 64 + lg * 16;
+                    split3(v0, v1, H, M, L);
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(p.Yp) + ((cb * 3) * (size_t)p.yp_pix + opix[c]) * 64 + lg * 16;
                     *reinterpret_cast<sp_u32x4*>(dst) = H;
                     *reinterpret_cast<sp_u32x4*>(dst + (size_t)p.yp_pix * 64) = M;
                     *reinterpret_cast<sp_u32x4*>(dst + (size_t)p.yp_pix * 128) = L;
