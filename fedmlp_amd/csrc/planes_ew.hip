@@ -128,23 +128,34 @@ __global__ __launch_bounds__(256) void stem_pool_planes_kernel(const float* __re
     if (scale) { sc = ld4(scale + grp * C + c); sh = ld4(shift + grp * C + c); }
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int code[4] = {0, 0, 0, 0};
+    // Round 6: the nine window loads are UNCONDITIONAL (clamped coordinates) and a position outside the map takes -inf afterwards
+    // -- never chosen under the strict >, exactly like the skipped position it was: with `continue` in front of each load the
+    // compiler waited for every load before it issued the next (nine dependent round trips per thread, tools/wait_chains.py)
+    f32x4 win[9];
+    bool inside[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * 2 - 1 + kh;
-        if ((unsigned)ih >= (unsigned)H) continue;
+        const bool rok = (unsigned)ih < (unsigned)H;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             const int iw = ow * 2 - 1 + kw;
-            if ((unsigned)iw >= (unsigned)W) continue;
-            f32x4 v = ld4(y + ((size_t)(img * H + ih) * W + iw) * C + c);
-            if (scale) {
-                v = v * sc + sh;
+            inside[kh * 3 + kw] = rok && (unsigned)iw < (unsigned)W;
+            win[kh * 3 + kw] = ld4(y + ((size_t)(img * H + (rok ? ih : oh * 2)) * W + ((unsigned)iw < (unsigned)W ? iw : ow * 2)) * C + c);
+        }
+    }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-            }
+    for (int t = 0; t < 9; ++t) {
+        f32x4 v = win[t];
+        if (scale) {
+            v = v * sc + sh;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (v[k] > best[k]) { best[k] = v[k]; code[k] = kh * 3 + kw; }
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float u = inside[t] ? v[k] : -INFINITY;
+            if (u > best[k]) { best[k] = u; code[k] = t; }
         }
     }
     const size_t o = ((size_t)(img * Hp + oh) * Wp + ow) * C + c;
