@@ -886,6 +886,23 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
     int nblk = p.total_steps >= 4LL * pconv_max_blocks() ? pconv_max_blocks() : (int)std::min<long long>(pconv_max_blocks(), T);
     if (forced > 0) nblk = (int)std::min<long long>(std::min(forced, pconv_max_blocks()), p.total_steps);
     p.steps_per_block = (int)((p.total_steps + nblk - 1) / nblk);
+    // Quantized ranges (round 6; PMC per layer: tools/pmc_convs.sh).  A block's K phase is (range start) mod nsteps; 256 ranges of
+    // 111 steps give the 32 blocks of an XCD 32 different phases, and the 512-channel layers -- a 3.5 MB weight slice per M-tile, all
+    // of it live at once beside the streaming activation rows in a 4 MB L2 -- fetched the slice about once per TILE: 662 MB per
+    // launch for 52 MB of operands.  With the range length a multiple of nsteps / P only P phases exist, and the blocks that share
+    // one read the same weight rows at the same time: 112 = 7 x 16 steps, nine phases, 420 MB.  Taken when it lengthens the ranges
+    // by <= 2 %; only for slices that do not fit beside the rest (the 256-channel layers' 1.8 MB: 278 -> 326 MB, not taken).
+    // Measured and not kept: the M-tiles of a pixel tile as sibling blocks on one XCD (every slice live on every XCD: 770 MB);
+    // the non-temporal hint on the activation rows (their kernel-row re-reads miss: step +1.1 ms).
+    static const int quant_on = fm_tune("FM_PCONV_QUANT", 1);
+    if (quant_on && forced <= 0 && p.steps_per_block > p.nsteps / 2 && (long long)p.nsteps * 128 * 192 > (2LL << 20)) {
+        for (int P = 1; P <= 12; ++P) {
+            if (p.nsteps % P) continue;
+            const int q = p.nsteps / P;
+            const int sq = (p.steps_per_block + q - 1) / q * q;
+            if ((long long)sq * 100 <= (long long)p.steps_per_block * 102) { p.steps_per_block = sq; break; }
+        }
+    }
     dim3 grid(nblk);
     // tap-row sharing: 3x3, stride 1, the taps in three groups of one kernel row each whose column shifts cover -1, 0, +1
     // (forward convs and their data gradients alike); FM_PCONV_TS=0 (tuning builds) keeps the per-tap stages

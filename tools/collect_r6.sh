@@ -13,4 +13,5 @@ done
 cp gpurun_out/$TAG/parity_*.json $D/ 2>/dev/null
 cp gpurun_out/$TAG/pmc_traffic.json $D/pmc_traffic.json 2>/dev/null
 cp gpurun_out/$TAG/mfma_busy_pconv_conv16_1024imgs.txt $D/ 2>/dev/null
+cp gpurun_out/$TAG/pmc_convs_per_layer.txt $D/ 2>/dev/null
 ls $D | wc -l

@@ -23,6 +23,7 @@ timeout 400 bash tools/pmc_run.sh ebf "Efficient_b0/bf16/stage1/bs512/hw224/C14"
 timeout 400 bash tools/pmc_run.sh ef32 "Efficient_b0/fp32/stage1/bs256/hw224/C5" 3 1 --model Efficient_b0 --batch 256 > $OUT/pmc_ef32.log 2>&1
 cp gpurun_out/pmc/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null
 FM_DEBUG_REUSE_PLANES=1 timeout 300 bash tools/mfma_busy.sh 16 > $OUT/mfma_busy.log 2>&1; cp gpurun_out/mfma_busy.txt $OUT/mfma_busy_pconv_conv16_1024imgs.txt 2>/dev/null
+timeout 300 bash tools/pmc_convs.sh $TAG 256 1,6,11,16 0,1 > $OUT/pmc_convs.log 2>&1; cp gpurun_out/pmc_convs_$TAG.txt $OUT/pmc_convs_per_layer.txt 2>/dev/null
 for f in $OUT/pmc_*.log; do tail -n 2 $f; done
 for s in s1 cf ebf ef32; do tail -c 250 gpurun_out/${TAG}_$s/bench.json 2>/dev/null; echo; done
 cat $OUT/mfma_busy_pconv_conv16_1024imgs.txt 2>/dev/null
