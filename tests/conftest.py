@@ -17,7 +17,7 @@ def pytest_configure(config):
     # (the gloo groups are created with a 3-minute timeout; with pytest-timeout present every test is also bounded: its own
     # configure has run by now and left None when no --timeout / ini value was given)
     if config.pluginmanager.hasplugin("timeout") and not getattr(config, "_env_timeout", None):
-        config._env_timeout = 1500.0
+        config._env_timeout = 420.0
 
 
 @pytest.fixture(scope="session")
