@@ -852,7 +852,6 @@ void launch_pconv(IgemmParams p, int groups, hipStream_t s)
 {
     static bool attr_done = false;
     // two stages + the fix-up / epilogue scratch behind them (statistics partials [4][BM][2] floats, the last-arriver flag)
-    // the stages + the fix-up / epilogue scratch behind them (statistics partials [4][BM][2] floats, the last-arriver flag)
     constexpr int LDS_L = 2 * 3 * (128 + 256) * 64 + 4 * 128 * 2 * 4;      // 148 KB: 128 x 256, two stages
     constexpr int LDS_S = 2 * 3 * (64 + 256) * 64 + 4 * 128 * 2 * 4;       // 124 KB: 64 x 256, two stages
     // tap-row sharing: two A stages + two B row stages of 272 rows + the scratch
